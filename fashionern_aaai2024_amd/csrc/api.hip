@@ -1,0 +1,841 @@
+// C-ABI layer of libfern.so: context, weight repacking, and the per-model launch sequences
+// (ViT / text towers, DVR fusion, index fusion, ranking).  See include/fern.h for the contract and the
+// reference interface each entry point replaces.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fern.h"
+#include "kernels.h"
+
+using namespace fern;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorInvalidValue ? FERN_ERR_ARG : FERN_ERR_HIP,                       \
+                        std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+#define FERN_TRY(expr)              \
+    do {                            \
+        int r_ = (expr);            \
+        if (r_ != FERN_OK) return r_; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<float> f;
+    std::vector<int64_t> shape;
+    size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+
+struct LinearW { const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0; };
+struct LNW { const float* g = nullptr; const float* b = nullptr; };
+struct CombinerW { LinearW text, image, hidden; const float* w2 = nullptr; const float* b2 = nullptr; };
+struct SRW {
+    LinearW local, global;
+    const float *bn13_mean = nullptr, *bn13_inv = nullptr, *bn13_beta = nullptr;   // per patch
+    const float *bnd_scale = nullptr, *bnd_shift = nullptr;                         // per column
+    const float *wc = nullptr, *bc = nullptr;
+};
+struct BertLayerW { LinearW qkv, attn_out, inter, out; LNW ln1, ln2; };
+struct FusionW {
+    bool ready = false;
+    int D = 0;
+    const float *cls = nullptr, *pos = nullptr, *type = nullptr;
+    LNW emb_ln;
+    BertLayerW layer[2];
+    LinearW mha_q, mha_kv, mha_out;
+    SRW sr[2];          // fern_sr_id
+    CombinerW comb[4];  // fern_combiner_id
+};
+struct ClipBlockW { LNW ln1, ln2; LinearW qkv, out, fc, proj; };
+struct ClipW {
+    bool ready = false;
+    fern_clip_config cfg{};
+    const float *conv_w = nullptr, *cls = nullptr, *vpos = nullptr, *vproj_t = nullptr;
+    LNW ln_pre, ln_post, ln_final;
+    std::vector<ClipBlockW> vblocks, tblocks;
+    const float *tok_emb = nullptr, *tpos = nullptr, *tproj_t = nullptr;
+};
+
+enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_TOPK = 2, PROF_SWEEP = 3 };
+struct ProfRec { hipEvent_t a, b; int kind; double work; };
+
+struct fern_ctx {
+    int device = 0;
+    std::map<std::string, HostTensor> host;
+    std::vector<void*> owned;        // device weight buffers
+    FusionW fusion;
+    ClipW clip;
+    // workspace arena (bump allocator; blocks are consolidated at the start of the next op)
+    struct Block { char* p; size_t cap; };
+    std::vector<Block> blocks;
+    size_t used = 0;                 // offset into blocks.back()
+    size_t op_total = 0;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static int ws_begin(fern_ctx* c, hipStream_t s) {
+    if (c->blocks.size() > 1) {      // grew during the previous op: merge into one block (outside capture only)
+        size_t total = 0;
+        for (auto& b : c->blocks) total += b.cap;
+        HIP_TRY(hipStreamSynchronize(s));
+        for (auto& b : c->blocks) HIP_TRY(hipFree(b.p));
+        c->blocks.clear();
+        char* p = nullptr;
+        HIP_TRY(hipMalloc(&p, total));
+        c->blocks.push_back({p, total});
+    }
+    c->used = 0;
+    return FERN_OK;
+}
+static int ws_alloc(fern_ctx* c, size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (c->blocks.empty() || c->used + bytes > c->blocks.back().cap) {
+        size_t cap = bytes;
+        if (!c->blocks.empty()) cap = std::max(bytes, c->blocks.back().cap);   // geometric growth
+        cap = std::max(cap, (size_t)64 << 20);
+        char* p = nullptr;
+        HIP_TRY(hipMalloc(&p, cap));
+        c->blocks.push_back({p, cap});
+        c->used = 0;
+    }
+    *out = c->blocks.back().p + c->used;
+    c->used += bytes;
+    return FERN_OK;
+}
+template <class T>
+static int ws_get(fern_ctx* c, size_t count, T** out) {
+    void* p = nullptr;
+    FERN_TRY(ws_alloc(c, count * sizeof(T), &p));
+    *out = reinterpret_cast<T*>(p);
+    return FERN_OK;
+}
+
+// ---- profiling hooks ----------------------------------------------------------------------------
+static int prof_open(fern_ctx* c, int kind, double work, hipStream_t s, int* slot) {
+    *slot = -1;
+    if (!c->prof_on) return FERN_OK;
+    hipEvent_t ev[2];
+    for (int i = 0; i < 2; ++i) {
+        if (!c->ev_pool.empty()) { ev[i] = c->ev_pool.back(); c->ev_pool.pop_back(); }
+        else HIP_TRY(hipEventCreate(&ev[i]));
+    }
+    HIP_TRY(hipEventRecord(ev[0], s));
+    c->recs.push_back({ev[0], ev[1], kind, work});
+    *slot = (int)c->recs.size() - 1;
+    return FERN_OK;
+}
+static int prof_close(fern_ctx* c, int slot, hipStream_t s) {
+    if (slot < 0) return FERN_OK;
+    HIP_TRY(hipEventRecord(c->recs[slot].b, s));
+    return FERN_OK;
+}
+
+static int run_gemm(fern_ctx* c, const GemmParams& p, hipStream_t s, int kind = PROF_GEMM, double work = -1.0) {
+    int slot;
+    FERN_TRY(prof_open(c, kind, work >= 0 ? work : 2.0 * p.M * (double)p.N * p.K, s, &slot));
+    HIP_TRY(launch_gemm(p, s));
+    return prof_close(c, slot, s);
+}
+static GemmParams gemm_desc(const float* A, long lda, const LinearW& L, float* C, long ldc, int M, int epi) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.in; p.bias = L.b; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = L.out; p.K = L.in; p.epi = epi; p.aload = ALOAD_PLAIN;
+    return p;
+}
+static int run_attention(fern_ctx* c, const AttnParams& a, hipStream_t s) {
+    int slot;
+    FERN_TRY(prof_open(c, PROF_ATTN, 4.0 * a.batch * a.heads * (double)a.s_q * a.s_k * a.hd, s, &slot));
+    HIP_TRY(launch_attention(a, s));
+    return prof_close(c, slot, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+static int upload(fern_ctx* c, const float* h, size_t n, const float** out) {
+    float* d = nullptr;
+    HIP_TRY(hipMalloc(&d, std::max<size_t>(n, 4) * sizeof(float)));
+    HIP_TRY(hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice));
+    c->owned.push_back(d);
+    *out = d;
+    return FERN_OK;
+}
+static int need(fern_ctx* c, const std::string& key, std::vector<int64_t> shape, const HostTensor** out) {
+    auto it = c->host.find(key);
+    if (it == c->host.end()) return fail(FERN_ERR_STATE, "missing weight: " + key);
+    if (!shape.empty() && it->second.shape != shape) {
+        std::string got, want;
+        for (auto s : it->second.shape) got += std::to_string(s) + ",";
+        for (auto s : shape) want += std::to_string(s) + ",";
+        return fail(FERN_ERR_STATE, "weight " + key + " has shape [" + got + "] expected [" + want + "]");
+    }
+    *out = &it->second;
+    return FERN_OK;
+}
+static int up_key(fern_ctx* c, const std::string& key, std::vector<int64_t> shape, const float** out) {
+    const HostTensor* t;
+    FERN_TRY(need(c, key, shape, &t));
+    return upload(c, t->f.data(), t->f.size(), out);
+}
+static int up_linear(fern_ctx* c, const std::string& prefix, int out_f, int in_f, LinearW* L) {
+    FERN_TRY(up_key(c, prefix + ".weight", {out_f, in_f}, &L->w));
+    FERN_TRY(up_key(c, prefix + ".bias", {out_f}, &L->b));
+    L->out = out_f; L->in = in_f;
+    return FERN_OK;
+}
+static int up_ln(fern_ctx* c, const std::string& prefix, int n, LNW* L) {
+    FERN_TRY(up_key(c, prefix + ".weight", {n}, &L->g));
+    return up_key(c, prefix + ".bias", {n}, &L->b);
+}
+// concat several [rows_i, in] weights (+ biases) into one packed Linear
+static int up_packed(fern_ctx* c, const std::vector<std::string>& prefixes, int out_each, int in_f, LinearW* L) {
+    std::vector<float> w, b;
+    for (auto& p : prefixes) {
+        const HostTensor *tw, *tb;
+        FERN_TRY(need(c, p + ".weight", {out_each, in_f}, &tw));
+        FERN_TRY(need(c, p + ".bias", {out_each}, &tb));
+        w.insert(w.end(), tw->f.begin(), tw->f.end());
+        b.insert(b.end(), tb->f.begin(), tb->f.end());
+    }
+    FERN_TRY(upload(c, w.data(), w.size(), &L->w));
+    FERN_TRY(upload(c, b.data(), b.size(), &L->b));
+    L->out = out_each * (int)prefixes.size(); L->in = in_f;
+    return FERN_OK;
+}
+static int up_transposed(fern_ctx* c, const std::string& key, int rows, int cols, const float** out) {   // [rows, cols] -> [cols, rows]
+    const HostTensor* t;
+    FERN_TRY(need(c, key, {rows, cols}, &t));
+    std::vector<float> tr((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+        for (int q = 0; q < cols; ++q) tr[(size_t)q * rows + r] = t->f[(size_t)r * cols + q];
+    return upload(c, tr.data(), tr.size(), out);
+}
+
+static int up_sr(fern_ctx* c, const std::string& p, int D, SRW* W) {
+    FERN_TRY(up_linear(c, p + ".embedding_local.0", D, D, &W->local));
+    FERN_TRY(up_linear(c, p + ".embedding_global.0", D, D, &W->global));
+    const HostTensor *w, *b, *rm, *rv;
+    // BatchNorm1d(13) over the PATCH axis (fusion_model.py:117-123 applied to [n,13,D])
+    FERN_TRY(need(c, p + ".embedding_local.1.weight", {13}, &w));
+    FERN_TRY(need(c, p + ".embedding_local.1.bias", {13}, &b));
+    FERN_TRY(need(c, p + ".embedding_local.1.running_mean", {13}, &rm));
+    FERN_TRY(need(c, p + ".embedding_local.1.running_var", {13}, &rv));
+    std::vector<float> inv(13);
+    for (int i = 0; i < 13; ++i) inv[i] = w->f[i] / std::sqrt(rv->f[i] + 1e-5f);
+    FERN_TRY(upload(c, rm->f.data(), 13, &W->bn13_mean));
+    FERN_TRY(upload(c, inv.data(), 13, &W->bn13_inv));
+    FERN_TRY(upload(c, b->f.data(), 13, &W->bn13_beta));
+    // BatchNorm1d(D) over the feature axis, folded to scale/shift
+    FERN_TRY(need(c, p + ".embedding_global.1.weight", {D}, &w));
+    FERN_TRY(need(c, p + ".embedding_global.1.bias", {D}, &b));
+    FERN_TRY(need(c, p + ".embedding_global.1.running_mean", {D}, &rm));
+    FERN_TRY(need(c, p + ".embedding_global.1.running_var", {D}, &rv));
+    std::vector<float> sc(D), sh(D);
+    for (int i = 0; i < D; ++i) {
+        sc[i] = w->f[i] / std::sqrt(rv->f[i] + 1e-5f);
+        sh[i] = b->f[i] - rm->f[i] * sc[i];
+    }
+    FERN_TRY(upload(c, sc.data(), D, &W->bnd_scale));
+    FERN_TRY(upload(c, sh.data(), D, &W->bnd_shift));
+    FERN_TRY(up_key(c, p + ".embedding_common.weight", {1, D}, &W->wc));
+    return up_key(c, p + ".embedding_common.bias", {1}, &W->bc);
+}
+static int up_combiner(fern_ctx* c, const std::string& p, int D, CombinerW* W) {
+    FERN_TRY(up_linear(c, p + ".text_projection_layer.0", 4 * D, D, &W->text));
+    FERN_TRY(up_linear(c, p + ".image_projection_layer.0", 4 * D, D, &W->image));
+    FERN_TRY(up_linear(c, p + ".dynamic_scalar.0", 8 * D, 8 * D, &W->hidden));
+    FERN_TRY(up_key(c, p + ".dynamic_scalar.3.weight", {1, 8 * D}, &W->w2));
+    return up_key(c, p + ".dynamic_scalar.3.bias", {1}, &W->b2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// exported: lifetime, weights
+// ------------------------------------------------------------------------------------------------
+extern "C" int fern_abi_version(void) { return FERN_ABI_VERSION; }
+extern "C" const char* fern_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int fern_ctx_create(int device, fern_ctx** out) {
+    if (!out) return fail(FERN_ERR_ARG, "fern_ctx_create: out is NULL");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(FERN_ERR_ARG, "fern_ctx_create: no such device " + std::to_string(device));
+    HIP_TRY(hipSetDevice(device));
+    auto* c = new fern_ctx();
+    c->device = device;
+    *out = c;
+    return FERN_OK;
+}
+extern "C" int fern_ctx_destroy(fern_ctx* c) {
+    if (!c) return FERN_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : c->owned) (void)hipFree(p);
+    for (auto& b : c->blocks) (void)hipFree(b.p);
+    for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    delete c;
+    return FERN_OK;
+}
+extern "C" int fern_sync(fern_ctx* c, void* stream) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_sync: ctx is NULL");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return FERN_OK;
+}
+
+extern "C" int fern_load_tensor(fern_ctx* c, const char* key, const void* host_ptr, int dtype, int ndim, const int64_t* shape) {
+    if (!c || !key) return fail(FERN_ERR_ARG, "fern_load_tensor: NULL argument");
+    if (ndim < 0 || ndim > 8 || (ndim > 0 && !shape)) return fail(FERN_ERR_ARG, "fern_load_tensor: bad ndim/shape");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return fail(FERN_ERR_ARG, "fern_load_tensor: negative dimension");
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    if (n && !host_ptr) return fail(FERN_ERR_ARG, "fern_load_tensor: host_ptr is NULL");
+    t.f.resize(n);
+    if (dtype == FERN_F32) std::memcpy(t.f.data(), host_ptr, n * sizeof(float));
+    else if (dtype == FERN_I64) for (size_t i = 0; i < n; ++i) t.f[i] = (float)((const int64_t*)host_ptr)[i];
+    else return fail(FERN_ERR_ARG, "fern_load_tensor: unsupported dtype");
+    c->host[key] = std::move(t);
+    return FERN_OK;
+}
+
+extern "C" int fern_finalize_fusion(fern_ctx* c, int D) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_finalize_fusion: ctx is NULL");
+    if (D <= 0 || D % 32 || D > 768) return fail(FERN_ERR_ARG, "fern_finalize_fusion: feature_dim must be a multiple of 32, <= 768");
+    HIP_TRY(hipSetDevice(c->device));
+    FusionW& F = c->fusion;
+    F = FusionW();
+    F.D = D;
+    const std::string tl = "DVR.transformer_layer";
+    const std::string bm = tl + ".bert_encoder.bert_model";
+    if (c->host.count(tl + ".cls_token")) FERN_TRY(up_key(c, tl + ".cls_token", {1, 1, D}, &F.cls));
+    else {   // absent in GPU-trained checkpoints: `nn.Parameter(...).to(device)` is not registered (fusion_model.py:185)
+        std::vector<float> z(D, 0.f);
+        FERN_TRY(upload(c, z.data(), D, &F.cls));
+    }
+    const HostTensor* pos;
+    FERN_TRY(need(c, bm + ".embeddings.position_embeddings.weight", {}, &pos));
+    if (pos->shape.size() != 2 || pos->shape[1] != D) return fail(FERN_ERR_STATE, "position_embeddings has the wrong width");
+    FERN_TRY(upload(c, pos->f.data(), pos->f.size(), &F.pos));
+    FERN_TRY(up_key(c, bm + ".embeddings.token_type_embeddings.weight", {2, D}, &F.type));
+    FERN_TRY(up_ln(c, bm + ".embeddings.LayerNorm", D, &F.emb_ln));
+    for (int i = 0; i < 2; ++i) {
+        const std::string lp = bm + ".encoder.layer." + std::to_string(i);
+        BertLayerW& L = F.layer[i];
+        FERN_TRY(up_packed(c, {lp + ".attention.self.query", lp + ".attention.self.key", lp + ".attention.self.value"}, D, D, &L.qkv));
+        FERN_TRY(up_linear(c, lp + ".attention.output.dense", D, D, &L.attn_out));
+        FERN_TRY(up_ln(c, lp + ".attention.output.LayerNorm", D, &L.ln1));
+        const HostTensor* iw;
+        FERN_TRY(need(c, lp + ".intermediate.dense.weight", {}, &iw));
+        const int inter = (int)iw->shape[0];
+        FERN_TRY(up_linear(c, lp + ".intermediate.dense", inter, D, &L.inter));
+        FERN_TRY(up_linear(c, lp + ".output.dense", D, inter, &L.out));
+        FERN_TRY(up_ln(c, lp + ".output.LayerNorm", D, &L.ln2));
+    }
+    {   // nn.MultiheadAttention packed in-proj: rows [0,D) = q, [D,3D) = k,v
+        const float *w, *b;
+        FERN_TRY(up_key(c, "DVR.MR_component.in_proj_weight", {3 * D, D}, &w));
+        FERN_TRY(up_key(c, "DVR.MR_component.in_proj_bias", {3 * D}, &b));
+        F.mha_q = {w, b, D, D};
+        F.mha_kv = {w + (size_t)D * D, b + D, 2 * D, D};
+        FERN_TRY(up_linear(c, "DVR.MR_component.out_proj", D, D, &F.mha_out));
+    }
+    FERN_TRY(up_sr(c, "SR_module", D, &F.sr[FERN_SR_TARGET]));
+    FERN_TRY(up_sr(c, "DVR.SR_module", D, &F.sr[FERN_SR_DVR]));
+    FERN_TRY(up_combiner(c, "Combiner_module", D, &F.comb[FERN_COMBINER_TARGET]));
+    FERN_TRY(up_combiner(c, "DVR.combiner_global", D, &F.comb[FERN_COMBINER_DVR_GLOBAL]));
+    FERN_TRY(up_combiner(c, "DVR.combiner_local", D, &F.comb[FERN_COMBINER_DVR_LOCAL]));
+    FERN_TRY(up_combiner(c, "DVR.combiner", D, &F.comb[FERN_COMBINER_DVR_FINAL]));
+    F.ready = true;
+    return FERN_OK;
+}
+
+static int up_clip_block(fern_ctx* c, const std::string& p, int width, int mlp, ClipBlockW* B) {
+    FERN_TRY(up_ln(c, p + ".ln_1", width, &B->ln1));
+    FERN_TRY(up_key(c, p + ".attn.in_proj_weight", {3 * width, width}, &B->qkv.w));
+    FERN_TRY(up_key(c, p + ".attn.in_proj_bias", {3 * width}, &B->qkv.b));
+    B->qkv.out = 3 * width; B->qkv.in = width;
+    FERN_TRY(up_linear(c, p + ".attn.out_proj", width, width, &B->out));
+    FERN_TRY(up_ln(c, p + ".ln_2", width, &B->ln2));
+    FERN_TRY(up_linear(c, p + ".mlp.c_fc", mlp, width, &B->fc));
+    return up_linear(c, p + ".mlp.c_proj", width, mlp, &B->proj);
+}
+
+extern "C" int fern_finalize_clip(fern_ctx* c, const fern_clip_config* cfg) {
+    if (!c || !cfg) return fail(FERN_ERR_ARG, "fern_finalize_clip: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    ClipW& W = c->clip;
+    W = ClipW();
+    W.cfg = *cfg;
+    auto bad = [](int w, int heads) { return w <= 0 || w % 32 || w > 1024 || heads <= 0 || w % heads || (w / heads) % 4 || w / heads > 96; };
+    if (cfg->embed_dim <= 0 || cfg->embed_dim % 4 || cfg->embed_dim > 1024) return fail(FERN_ERR_ARG, "clip: unsupported embed_dim");
+    if (cfg->t_layers > 0 && (bad(cfg->t_width, cfg->t_heads) || cfg->t_mlp % 32 || cfg->context_length > 96))
+        return fail(FERN_ERR_ARG, "clip: unsupported text tower shape");
+    if (cfg->v_layers > 0) {
+        const int g = cfg->patch_size > 0 ? cfg->image_size / cfg->patch_size : 0;
+        if (bad(cfg->v_width, cfg->v_heads) || cfg->v_mlp % 32 || cfg->patch_size % 4 || g * cfg->patch_size != cfg->image_size ||
+            (3 * cfg->patch_size * cfg->patch_size) % 32 || g * g + 1 > 224)
+            return fail(FERN_ERR_ARG, "clip: unsupported image tower shape");
+        const int vw = cfg->v_width, P = cfg->patch_size, tokens = g * g + 1;
+        FERN_TRY(up_key(c, "visual.conv1.weight", {vw, 3, P, P}, &W.conv_w));
+        FERN_TRY(up_key(c, "visual.class_embedding", {vw}, &W.cls));
+        FERN_TRY(up_key(c, "visual.positional_embedding", {tokens, vw}, &W.vpos));
+        FERN_TRY(up_ln(c, "visual.ln_pre", vw, &W.ln_pre));
+        FERN_TRY(up_ln(c, "visual.ln_post", vw, &W.ln_post));
+        FERN_TRY(up_transposed(c, "visual.proj", vw, cfg->embed_dim, &W.vproj_t));
+        W.vblocks.resize(cfg->v_layers);
+        for (int i = 0; i < cfg->v_layers; ++i)
+            FERN_TRY(up_clip_block(c, "visual.transformer.resblocks." + std::to_string(i), vw, cfg->v_mlp, &W.vblocks[i]));
+    }
+    if (cfg->t_layers > 0) {
+        const int tw = cfg->t_width;
+        FERN_TRY(up_key(c, "token_embedding.weight", {cfg->vocab_size, tw}, &W.tok_emb));
+        FERN_TRY(up_key(c, "positional_embedding", {cfg->context_length, tw}, &W.tpos));
+        FERN_TRY(up_ln(c, "ln_final", tw, &W.ln_final));
+        FERN_TRY(up_transposed(c, "text_projection", tw, cfg->embed_dim, &W.tproj_t));
+        W.tblocks.resize(cfg->t_layers);
+        for (int i = 0; i < cfg->t_layers; ++i)
+            FERN_TRY(up_clip_block(c, "transformer.resblocks." + std::to_string(i), tw, cfg->t_mlp, &W.tblocks[i]));
+    }
+    W.ready = true;
+    return FERN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fusion building blocks (internal; workspace comes from the caller's arena)
+// ------------------------------------------------------------------------------------------------
+// VisualSR.forward (fusion_model.py:141-154): the [13n, D] local embedding is never materialised --
+// the GEMM epilogue applies BN13+tanh, multiplies by the global embedding and reduces against w_common.
+static int run_visual_sr(fern_ctx* c, const SRW& W, const float* local, float* out, long n, int D, hipStream_t s) {
+    float *raw, *g, *partial;
+    FERN_TRY(ws_get(c, (size_t)n * D, &raw));
+    FERN_TRY(ws_get(c, (size_t)n * D, &g));
+    HIP_TRY(launch_mean_rows(local, D, raw, D, n, 13, D, 13, 0, s));
+    GemmParams pg = gemm_desc(raw, D, W.global, g, D, (int)n, EPI_COLAFFINE_TANH);
+    pg.aux0 = W.bnd_scale; pg.aux1 = W.bnd_shift;
+    FERN_TRY(run_gemm(c, pg, s));
+    const int M = (int)(n * 13);
+    const int nb = gemm_num_col_blocks(M, D);
+    FERN_TRY(ws_get(c, (size_t)M * nb, &partial));
+    GemmParams pl = gemm_desc(local, D, W.local, nullptr, D, M, EPI_SR_LOCAL);
+    pl.aux0 = W.wc; pl.aux1 = W.bn13_mean; pl.aux2 = W.bn13_inv; pl.aux3 = W.bn13_beta;
+    pl.G = g; pl.ldg = D; pl.partial = partial;
+    FERN_TRY(run_gemm(c, pl, s));
+    HIP_TRY(launch_sr_finalize(partial, nb, W.bc, local, out, n, D, s));
+    return FERN_OK;
+}
+
+// CombinerSimple.forward (fusion_model.py:86-94): the 8D hidden layer only exists inside the GEMM
+// epilogue, which reduces it against dynamic_scalar.3.weight on the fly.
+static int run_combiner(fern_ctx* c, const CombinerW& W, const float* image, const float* text, float* out, long n, int D, hipStream_t s) {
+    float *cat, *partial;
+    const int H = 8 * D;
+    FERN_TRY(ws_get(c, (size_t)n * H, &cat));
+    FERN_TRY(run_gemm(c, gemm_desc(text, D, W.text, cat, H, (int)n, EPI_BIAS_RELU), s));            // :87,:90 text first
+    FERN_TRY(run_gemm(c, gemm_desc(image, D, W.image, cat + 4 * D, H, (int)n, EPI_BIAS_RELU), s));  // :88
+    const int nb = gemm_num_col_blocks((int)n, H);
+    FERN_TRY(ws_get(c, (size_t)n * nb, &partial));
+    GemmParams ph = gemm_desc(cat, H, W.hidden, nullptr, H, (int)n, EPI_RELU_DOT);
+    ph.aux0 = W.w2; ph.partial = partial;
+    FERN_TRY(run_gemm(c, ph, s));
+    HIP_TRY(launch_combiner_finalize(partial, nb, W.b2, image, text, out, n, D, s));
+    return FERN_OK;
+}
+
+static int check_fusion(fern_ctx* c, const char* fn) {
+    if (!c) return fail(FERN_ERR_ARG, std::string(fn) + ": ctx is NULL");
+    if (!c->fusion.ready) return fail(FERN_ERR_STATE, std::string(fn) + ": fusion weights not finalised (fern_finalize_fusion)");
+    HIP_TRY(hipSetDevice(c->device));
+    return FERN_OK;
+}
+
+extern "C" int fern_combiner(fern_ctx* c, int which, const float* image, const float* text, float* out, int64_t n, void* stream) {
+    FERN_TRY(check_fusion(c, "fern_combiner"));
+    if (which < 0 || which > 3 || n < 0 || (n && (!image || !text || !out))) return fail(FERN_ERR_ARG, "fern_combiner: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = c->fusion.D;
+    const long CH = 8192;
+    for (long o = 0; o < n; o += CH) {
+        const long m = std::min(CH, (long)n - o);
+        FERN_TRY(ws_begin(c, s));
+        FERN_TRY(run_combiner(c, c->fusion.comb[which], image + o * D, text + o * D, out + o * D, m, D, s));
+    }
+    return FERN_OK;
+}
+
+extern "C" int fern_visual_sr(fern_ctx* c, int which, const float* local, float* out, int64_t n, void* stream) {
+    FERN_TRY(check_fusion(c, "fern_visual_sr"));
+    if (which < 0 || which > 1 || n < 0 || (n && (!local || !out))) return fail(FERN_ERR_ARG, "fern_visual_sr: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = c->fusion.D;
+    const long CH = 8192;
+    for (long o = 0; o < n; o += CH) {
+        const long m = std::min(CH, (long)n - o);
+        FERN_TRY(ws_begin(c, s));
+        FERN_TRY(run_visual_sr(c, c->fusion.sr[which], local + o * 13 * D, out + o * D, m, D, s));
+    }
+    return FERN_OK;
+}
+
+extern "C" int fern_l2_normalize(fern_ctx* c, const float* x, float* out, int64_t n, int d, void* stream) {
+    if (!c || n < 0 || (n && (!x || !out))) return fail(FERN_ERR_ARG, "fern_l2_normalize: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_l2norm(x, d, out, d, n, d, 1e-12f, 0, (hipStream_t)stream));
+    return FERN_OK;
+}
+
+extern "C" int fern_index_fuse(fern_ctx* c, const float* tar_feats, const float* tar_local, float* out, int64_t n, int normalize_input,
+                               void* stream) {
+    FERN_TRY(check_fusion(c, "fern_index_fuse"));
+    if (n < 0 || (n && (!tar_feats || !tar_local || !out))) return fail(FERN_ERR_ARG, "fern_index_fuse: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = c->fusion.D;
+    const long CH = 8192;   // gallery rows per tile: bounds the [rows, 8D] Combiner buffer (the reference runs the whole gallery as ONE batch)
+    for (long o = 0; o < n; o += CH) {
+        const long m = std::min(CH, (long)n - o);
+        FERN_TRY(ws_begin(c, s));
+        const float* img = tar_feats + o * D;
+        if (normalize_input) {
+            float* tn;
+            FERN_TRY(ws_get(c, (size_t)m * D, &tn));
+            HIP_TRY(launch_l2norm(img, D, tn, D, m, D, 1e-12f, 0, s));      // F.normalize, test_fiq.py:45
+            img = tn;
+        }
+        float* sr;
+        FERN_TRY(ws_get(c, (size_t)m * D, &sr));
+        FERN_TRY(run_visual_sr(c, c->fusion.sr[FERN_SR_TARGET], tar_local + o * 13 * D, sr, m, D, s));      // model.py:65
+        FERN_TRY(run_combiner(c, c->fusion.comb[FERN_COMBINER_TARGET], img, sr, out + o * D, m, D, s));     // model.py:66
+    }
+    return FERN_OK;
+}
+
+// ERN mode="test" (model.py:68-69 -> DVR_module.forward, fusion_model.py:26-55)
+static int dvr_chunk(fern_ctx* c, const float* ref_global, const float* ref_local, const float* text_global, const float* text_seq,
+                     float* out, int B, int T, hipStream_t s) {
+    const FusionW& F = c->fusion;
+    const int D = F.D, P = 13, S = 1 + P + T, heads = 8, hd = D / heads;
+    const long R = (long)B * S;
+    const int inter = F.layer[0].inter.out;
+    float *X, *X1, *QKV, *ATT, *H;
+    FERN_TRY(ws_get(c, (size_t)R * D, &X));
+    FERN_TRY(ws_get(c, (size_t)R * D, &X1));
+    FERN_TRY(ws_get(c, (size_t)R * 3 * D, &QKV));
+    FERN_TRY(ws_get(c, (size_t)R * D, &ATT));
+    FERN_TRY(ws_get(c, (size_t)R * inter, &H));
+    // PlusModel / BertEmbeddings (fusion_model.py:199-212)
+    HIP_TRY(launch_bert_embed(F.cls, ref_local, text_seq, F.type, F.pos, F.emb_ln.g, F.emb_ln.b, X, B, P, T, D, 1e-12f, s));
+    for (int l = 0; l < 2; ++l) {
+        const BertLayerW& L = F.layer[l];
+        FERN_TRY(run_gemm(c, gemm_desc(X, D, L.qkv, QKV, 3 * D, (int)R, EPI_BIAS), s));
+        AttnParams a{QKV, QKV + D, QKV + 2 * D, ATT, 3L * D, 3L * D, 3L * D, (long)D, B, heads, hd, S, S, 0, 1.0f / std::sqrt((float)hd)};
+        FERN_TRY(run_attention(c, a, s));
+        GemmParams po = gemm_desc(ATT, D, L.attn_out, X1, D, (int)R, EPI_BIAS_RESIDUAL);
+        po.R = X;
+        FERN_TRY(run_gemm(c, po, s));
+        HIP_TRY(launch_layernorm(X1, nullptr, L.ln1.g, L.ln1.b, X1, R, D, D, D, 1e-12f, s));
+        FERN_TRY(run_gemm(c, gemm_desc(X1, D, L.inter, H, inter, (int)R, EPI_BIAS_GELU), s));
+        GemmParams p2 = gemm_desc(H, inter, L.out, X, D, (int)R, EPI_BIAS_RESIDUAL);
+        p2.R = X1;
+        FERN_TRY(run_gemm(c, p2, s));
+        HIP_TRY(launch_layernorm(X, nullptr, L.ln2.g, L.ln2.b, X, R, D, D, D, 1e-12f, s));
+    }
+    // F.normalize every row of last_hidden_state (rows 1..13 image, 14.. text; row 0 is never read) -- :38-41
+    float* XN = X1;
+    HIP_TRY(launch_l2norm(X, D, XN, D, R, D, 1e-12f, 0, s));
+    // MR_component: only output rows 0..12 survive (:47), so Q is projected for the first 13 text rows only
+    const long Rp = (long)B * P;
+    float *IMG, *TXT, *Q13, *KV, *CA, *CROSS, *PV, *TM, *G, *Lf;
+    FERN_TRY(ws_get(c, (size_t)Rp * D, &IMG));
+    FERN_TRY(ws_get(c, (size_t)Rp * D, &TXT));
+    FERN_TRY(ws_get(c, (size_t)Rp * D, &Q13));
+    FERN_TRY(ws_get(c, (size_t)Rp * 2 * D, &KV));
+    FERN_TRY(ws_get(c, (size_t)Rp * D, &CA));
+    FERN_TRY(ws_get(c, (size_t)Rp * D, &CROSS));
+    FERN_TRY(ws_get(c, (size_t)B * D, &PV));
+    FERN_TRY(ws_get(c, (size_t)B * D, &TM));
+    FERN_TRY(ws_get(c, (size_t)B * D, &G));
+    FERN_TRY(ws_get(c, (size_t)B * D, &Lf));
+    HIP_TRY(launch_gather_rows(XN, D, IMG, D, Rp, D, P, S, 1, nullptr, s));
+    HIP_TRY(launch_gather_rows(XN, D, TXT, D, Rp, D, P, S, 1 + P, nullptr, s));
+    FERN_TRY(run_gemm(c, gemm_desc(TXT, D, F.mha_q, Q13, D, (int)Rp, EPI_BIAS), s));
+    FERN_TRY(run_gemm(c, gemm_desc(IMG, D, F.mha_kv, KV, 2 * D, (int)Rp, EPI_BIAS), s));
+    AttnParams ca{Q13, KV, KV + D, CA, (long)D, 2L * D, 2L * D, (long)D, B, heads, hd, P, P, 0, 1.0f / std::sqrt((float)hd)};
+    FERN_TRY(run_attention(c, ca, s));
+    FERN_TRY(run_gemm(c, gemm_desc(CA, D, F.mha_out, CROSS, D, (int)Rp, EPI_BIAS), s));
+    FERN_TRY(run_visual_sr(c, F.sr[FERN_SR_DVR], CROSS, PV, B, D, s));                                   // :48
+    HIP_TRY(launch_mean_rows(XN, D, TM, D, B, T, D, S, 1 + P, s));                                       // :49
+    FERN_TRY(run_combiner(c, F.comb[FERN_COMBINER_DVR_GLOBAL], ref_global, text_global, G, B, D, s));    // :52
+    FERN_TRY(run_combiner(c, F.comb[FERN_COMBINER_DVR_LOCAL], PV, TM, Lf, B, D, s));                     // :53
+    return run_combiner(c, F.comb[FERN_COMBINER_DVR_FINAL], G, Lf, out, B, D, s);                        // :54
+}
+
+extern "C" int fern_dvr_fuse(fern_ctx* c, const float* ref_global, const float* ref_local, const float* text_global, const float* text_seq,
+                             float* out, int B, int seq_len, void* stream) {
+    FERN_TRY(check_fusion(c, "fern_dvr_fuse"));
+    if (B < 0 || (B && (!ref_global || !ref_local || !text_global || !text_seq || !out))) return fail(FERN_ERR_ARG, "fern_dvr_fuse: bad argument");
+    if (seq_len < 1 || 1 + 13 + seq_len > 96) return fail(FERN_ERR_ARG, "fern_dvr_fuse: 1 + 13 + seq_len must be <= 96");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = c->fusion.D, CH = 256;
+    for (int o = 0; o < B; o += CH) {
+        const int m = std::min(CH, B - o);
+        FERN_TRY(ws_begin(c, s));
+        FERN_TRY(dvr_chunk(c, ref_global + (long)o * D, ref_local + (long)o * 13 * D, text_global + (long)o * D,
+                           text_seq + (long)o * seq_len * D, out + (long)o * D, m, seq_len, s));
+    }
+    return FERN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CLIP towers
+// ------------------------------------------------------------------------------------------------
+// pre-LN residual block (modeling_clip.py:354-401): x += attn(ln_1(x)); x += mlp(ln_2(x))
+static int clip_block(fern_ctx* c, const ClipBlockW& Bk, float* X, float* XN, float* QKV, float* ATT, float* H, int batch, int S,
+                      int width, int heads, int causal, hipStream_t s) {
+    const long R = (long)batch * S;
+    const int hd = width / heads;
+    HIP_TRY(launch_layernorm(X, nullptr, Bk.ln1.g, Bk.ln1.b, XN, R, width, width, width, 1e-5f, s));
+    FERN_TRY(run_gemm(c, gemm_desc(XN, width, Bk.qkv, QKV, 3 * width, (int)R, EPI_BIAS), s));
+    AttnParams a{QKV, QKV + width, QKV + 2 * width, ATT, 3L * width, 3L * width, 3L * width, (long)width,
+                 batch, heads, hd, S, S, causal, 1.0f / std::sqrt((float)hd)};
+    FERN_TRY(run_attention(c, a, s));
+    GemmParams po = gemm_desc(ATT, width, Bk.out, X, width, (int)R, EPI_BIAS_RESIDUAL);
+    po.R = X;
+    FERN_TRY(run_gemm(c, po, s));
+    HIP_TRY(launch_layernorm(X, nullptr, Bk.ln2.g, Bk.ln2.b, XN, R, width, width, width, 1e-5f, s));
+    FERN_TRY(run_gemm(c, gemm_desc(XN, width, Bk.fc, H, Bk.fc.out, (int)R, EPI_BIAS_GELU), s));
+    GemmParams p2 = gemm_desc(H, Bk.fc.out, Bk.proj, X, width, (int)R, EPI_BIAS_RESIDUAL);
+    p2.R = X;
+    return run_gemm(c, p2, s);
+}
+
+static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStream_t s) {
+    const ClipW& W = c->clip;
+    const fern_clip_config& cf = W.cfg;
+    const int vw = cf.v_width, g = cf.image_size / cf.patch_size, g2 = g * g, S = g2 + 1;
+    const long R = (long)b * S;
+    float *X, *XN, *QKV, *ATT, *H, *CLS;
+    FERN_TRY(ws_get(c, (size_t)R * vw, &X));
+    FERN_TRY(ws_get(c, (size_t)R * vw, &XN));
+    FERN_TRY(ws_get(c, (size_t)R * 3 * vw, &QKV));
+    FERN_TRY(ws_get(c, (size_t)R * vw, &ATT));
+    FERN_TRY(ws_get(c, (size_t)R * cf.v_mlp, &H));
+    FERN_TRY(ws_get(c, (size_t)b * vw, &CLS));
+    // conv1 as an im2col-free GEMM; epilogue adds the positional embedding and skips the class slot
+    GemmParams pe{};
+    pe.A = images; pe.W = W.conv_w; pe.ldw = 3L * cf.patch_size * cf.patch_size; pe.C = X; pe.ldc = vw;
+    pe.M = b * g2; pe.N = vw; pe.K = 3 * cf.patch_size * cf.patch_size;
+    pe.epi = EPI_PATCH_EMBED; pe.aload = ALOAD_IM2COL; pe.aux0 = W.vpos;
+    pe.img = cf.image_size; pe.patch = cf.patch_size; pe.grid = g;
+    FERN_TRY(run_gemm(c, pe, s));
+    HIP_TRY(launch_vit_cls(W.cls, W.vpos, X, b, S, vw, s));
+    HIP_TRY(launch_layernorm(X, nullptr, W.ln_pre.g, W.ln_pre.b, X, R, vw, vw, vw, 1e-5f, s));
+    for (int l = 0; l < cf.v_layers; ++l) FERN_TRY(clip_block(c, W.vblocks[l], X, XN, QKV, ATT, H, b, S, vw, cf.v_heads, 0, s));
+    HIP_TRY(launch_gather_rows(X, vw, CLS, vw, b, vw, 1, S, 0, nullptr, s));
+    HIP_TRY(launch_layernorm(CLS, nullptr, W.ln_post.g, W.ln_post.b, CLS, b, vw, vw, vw, 1e-5f, s));
+    LinearW proj{W.vproj_t, nullptr, cf.embed_dim, vw};
+    return run_gemm(c, gemm_desc(CLS, vw, proj, out, cf.embed_dim, b, EPI_BIAS), s);
+}
+
+extern "C" int fern_vit_encode_image(fern_ctx* c, const float* images, float* out, int b, void* stream) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_vit_encode_image: ctx is NULL");
+    if (!c->clip.ready || c->clip.cfg.v_layers <= 0) return fail(FERN_ERR_STATE, "fern_vit_encode_image: image tower not finalised (fern_finalize_clip)");
+    if (b < 0 || (b && (!images || !out))) return fail(FERN_ERR_ARG, "fern_vit_encode_image: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const fern_clip_config& cf = c->clip.cfg;
+    const long img_sz = 3L * cf.image_size * cf.image_size;
+    const int CH = 64;
+    for (int o = 0; o < b; o += CH) {
+        const int m = std::min(CH, b - o);
+        FERN_TRY(ws_begin(c, s));
+        FERN_TRY(vit_chunk(c, images + o * img_sz, out + (long)o * cf.embed_dim, m, s));
+    }
+    return FERN_OK;
+}
+
+static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, float* out_seq, int B, hipStream_t s) {
+    const ClipW& W = c->clip;
+    const fern_clip_config& cf = W.cfg;
+    const int tw = cf.t_width, T = cf.context_length, E = cf.embed_dim;
+    const long R = (long)B * T;
+    float *X, *XN, *QKV, *ATT, *H;
+    int* eot;
+    FERN_TRY(ws_get(c, (size_t)R * tw, &X));
+    FERN_TRY(ws_get(c, (size_t)R * tw, &XN));
+    FERN_TRY(ws_get(c, (size_t)R * 3 * tw, &QKV));
+    FERN_TRY(ws_get(c, (size_t)R * tw, &ATT));
+    FERN_TRY(ws_get(c, (size_t)R * cf.t_mlp, &H));
+    FERN_TRY(ws_get(c, (size_t)B, &eot));
+    HIP_TRY(launch_text_embed(tokens, W.tok_emb, W.tpos, X, eot, B, T, tw, cf.vocab_size, s));
+    for (int l = 0; l < cf.t_layers; ++l) FERN_TRY(clip_block(c, W.tblocks[l], X, XN, QKV, ATT, H, B, T, tw, cf.t_heads, 1, s));
+    HIP_TRY(launch_layernorm(X, nullptr, W.ln_final.g, W.ln_final.b, XN, R, tw, tw, tw, 1e-5f, s));
+    LinearW proj{W.tproj_t, nullptr, E, tw};
+    if (out_seq) {
+        FERN_TRY(run_gemm(c, gemm_desc(XN, tw, proj, out_seq, E, (int)R, EPI_BIAS), s));
+        if (out_global) HIP_TRY(launch_gather_rows(out_seq, E, out_global, E, B, E, 1, T, 0, eot, s));   // global == seq[EOT]
+    } else if (out_global) {
+        float* pooled;
+        FERN_TRY(ws_get(c, (size_t)B * tw, &pooled));
+        HIP_TRY(launch_gather_rows(XN, tw, pooled, tw, B, tw, 1, T, 0, eot, s));
+        FERN_TRY(run_gemm(c, gemm_desc(pooled, tw, proj, out_global, E, B, EPI_BIAS), s));
+    }
+    return FERN_OK;
+}
+
+extern "C" int fern_text_encode(fern_ctx* c, const int64_t* tokens, float* out_global, float* out_seq, int B, void* stream) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_text_encode: ctx is NULL");
+    if (!c->clip.ready || c->clip.cfg.t_layers <= 0) return fail(FERN_ERR_STATE, "fern_text_encode: text tower not finalised (fern_finalize_clip)");
+    if (B < 0 || (B && (!tokens || (!out_global && !out_seq)))) return fail(FERN_ERR_ARG, "fern_text_encode: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const fern_clip_config& cf = c->clip.cfg;
+    const int CH = 256;
+    for (int o = 0; o < B; o += CH) {
+        const int m = std::min(CH, B - o);
+        FERN_TRY(ws_begin(c, s));
+        FERN_TRY(text_chunk(c, tokens + (long)o * cf.context_length, out_global ? out_global + (long)o * cf.embed_dim : nullptr,
+                            out_seq ? out_seq + (long)o * cf.context_length * cf.embed_dim : nullptr, m, s));
+    }
+    return FERN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rank
+// ------------------------------------------------------------------------------------------------
+extern "C" int fern_sim_topk(fern_ctx* c, const float* q, const float* gallery, int B, int64_t N, int D, int K, float* out_scores,
+                             int32_t* out_idx, int64_t idx_offset, const int32_t* exclude_idx, void* stream) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_sim_topk: ctx is NULL");
+    if (B < 0 || N < 0 || K < 1 || K > 64 || D <= 0 || D % 32) return fail(FERN_ERR_ARG, "fern_sim_topk: need 1<=K<=64, D % 32 == 0");
+    if (B && (!q || !out_scores || !out_idx || (N && !gallery))) return fail(FERN_ERR_ARG, "fern_sim_topk: NULL argument");
+    if (N > 0x7FFFFFF0LL) return fail(FERN_ERR_ARG, "fern_sim_topk: N too large for int32 indices");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) return FERN_OK;
+    // queries are processed in chunks so the [chunk, N] score tile stays cache-sized
+    long chunk = std::max<long>(64, std::min<long>(1024, ((long)64 << 20) / std::max<long>(1, (long)N * 4)));
+    chunk = (chunk / 64) * 64;
+    const int nseg = topk_num_segments(N);
+    for (long o = 0; o < B; o += chunk) {
+        const int m = (int)std::min<long>(chunk, B - o);
+        FERN_TRY(ws_begin(c, s));
+        float* scores = nullptr;
+        unsigned long long* keys;
+        const long ld = ((long)N + 3) & ~3L;
+        FERN_TRY(ws_get(c, (size_t)m * std::max<long>(ld, 4), &scores));
+        FERN_TRY(ws_get(c, (size_t)m * nseg * 64, &keys));
+        if (N > 0) {
+            GemmParams p{};
+            p.A = q + o * D; p.lda = D; p.W = gallery; p.ldw = D; p.C = scores; p.ldc = ld;
+            p.M = m; p.N = (int)N; p.K = D; p.epi = EPI_BIAS; p.aload = ALOAD_PLAIN;
+            FERN_TRY(run_gemm(c, p, s, PROF_SWEEP, (double)N * D * 4 + (double)m * D * 4 + (double)m * N * 4));
+        }
+        int slot;
+        FERN_TRY(prof_open(c, PROF_TOPK, 0, s, &slot));
+        HIP_TRY(launch_topk_rows(scores, ld, m, N, K, idx_offset, exclude_idx ? exclude_idx + o : nullptr, keys, out_scores + o * K,
+                                 out_idx + o * K, s));
+        FERN_TRY(prof_close(c, slot, s));
+    }
+    return FERN_OK;
+}
+
+extern "C" int fern_gather_scores(fern_ctx* c, const float* q, const float* gallery, const int32_t* idx, float* out, int B, int m, int D,
+                                  void* stream) {
+    if (!c || B < 0 || m < 0 || D <= 0 || ((long)B * m && (!q || !gallery || !idx || !out))) return fail(FERN_ERR_ARG, "fern_gather_scores: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_gather_scores(q, gallery, idx, out, B, m, D, (hipStream_t)stream));
+    return FERN_OK;
+}
+
+extern "C" int fern_topk_merge(fern_ctx* c, const float* scores, const int32_t* idx, float* out_scores, int32_t* out_idx, int R, int B, int K,
+                               void* stream) {
+    if (!c || R < 1 || B < 0 || K < 1 || K > 64 || (B && (!scores || !idx || !out_scores || !out_idx))) return fail(FERN_ERR_ARG, "fern_topk_merge: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_topk_merge(scores, idx, out_scores, out_idx, R, B, K, (hipStream_t)stream));
+    return FERN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// building blocks
+// ------------------------------------------------------------------------------------------------
+extern "C" int fern_gemm(fern_ctx* c, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* residual,
+                         float* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream) {
+    if (!c || !A || !W || !C || M < 0 || N < 0 || K <= 0) return fail(FERN_ERR_ARG, "fern_gemm: bad argument");
+    if (epilogue < FERN_EPI_BIAS || epilogue > FERN_EPI_BIAS_RESIDUAL) return fail(FERN_ERR_ARG, "fern_gemm: unknown epilogue");
+    if (epilogue == FERN_EPI_BIAS_RESIDUAL && !residual) return fail(FERN_ERR_ARG, "fern_gemm: residual is NULL");
+    if (K % 32) return fail(FERN_ERR_ARG, "fern_gemm: K must be a multiple of 32");
+    HIP_TRY(hipSetDevice(c->device));
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.R = residual; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aload = ALOAD_PLAIN;
+    return run_gemm(c, p, (hipStream_t)stream);
+}
+
+extern "C" int fern_layernorm(fern_ctx* c, const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                              int64_t rows, int d, float eps, void* stream) {
+    if (!c || !x || !gamma || !beta || !y || rows < 0) return fail(FERN_ERR_ARG, "fern_layernorm: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_layernorm(x, residual, gamma, beta, y, rows, d, d, d, eps, (hipStream_t)stream));
+    return FERN_OK;
+}
+
+extern "C" int fern_attention(fern_ctx* c, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* out,
+                              int64_t ldo, int batch, int heads, int head_dim, int s_q, int s_k, int causal, float scale, void* stream) {
+    if (!c || !q || !k || !v || !out) return fail(FERN_ERR_ARG, "fern_attention: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    AttnParams a{q, k, v, out, (long)ldq, (long)ldk, (long)ldv, (long)ldo, batch, heads, head_dim, s_q, s_k, causal, scale};
+    return run_attention(c, a, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling
+// ------------------------------------------------------------------------------------------------
+extern "C" int fern_prof_enable(fern_ctx* c, int on) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_prof_enable: ctx is NULL");
+    c->prof_on = on != 0;
+    return FERN_OK;
+}
+extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
+    if (!c || !out) return fail(FERN_ERR_ARG, "fern_prof_collect: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::memset(out, 0, sizeof(*out));
+    for (auto& r : c->recs) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        switch (r.kind) {
+            case PROF_GEMM: out->gemm_ms += ms; out->gemm_flops += r.work; out->gemm_launches++; break;
+            case PROF_ATTN: out->attn_ms += ms; out->attn_flops += r.work; out->attn_launches++; break;
+            case PROF_TOPK: out->topk_ms += ms; out->topk_launches++; break;
+            default: out->sweep_ms += ms; out->sweep_bytes += r.work; out->sweep_launches++; break;
+        }
+        c->ev_pool.push_back(r.a);
+        c->ev_pool.push_back(r.b);
+    }
+    c->recs.clear();
+    return FERN_OK;
+}

@@ -1,0 +1,342 @@
+// Row-wise kernels of the encode -> fuse -> rank path (HBM-bound; one wave64 per row, 16-byte accesses).
+//
+// LayerNorm (CLIP eps 1e-5, BERT eps 1e-12 with fused residual), F.normalize / VisualSR.l2norm,
+// patch means, embedding gathers, and the scalar-gate / attention-pooling tails of
+// CombinerSimple (fusion_model.py:92-94) and VisualSR (fusion_model.py:149-154).
+#include "kernels.h"
+
+namespace fern {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ROWS_PER_BLOCK = 4;   // 4 waves per workgroup, one row each
+constexpr int MAXV = 4;             // row width <= 64 lanes * 4 floats * MAXV = 1024
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// A row of width d (d % 4 == 0, d <= 1024) held as up to MAXV float4 per lane: element c = (i*64 + lane)*4.
+struct RowRegs {
+    f32x4 v[MAXV];
+};
+
+__device__ __forceinline__ void row_load(RowRegs& r, const float* x, int d, int lane) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (c < d) t = *reinterpret_cast<const f32x4*>(x + c);
+        r.v[i] = t;
+    }
+}
+__device__ __forceinline__ void row_store(const RowRegs& r, float* y, int d, int lane) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) *reinterpret_cast<f32x4*>(y + c) = r.v[i];
+    }
+}
+__device__ __forceinline__ float row_sumsq(const RowRegs& r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s += r.v[i][0] * r.v[i][0] + r.v[i][1] * r.v[i][1] + r.v[i][2] * r.v[i][2] + r.v[i][3] * r.v[i][3];
+    return wave_sum(s);
+}
+
+// y = (x - mean) / sqrt(var + eps) * gamma + beta with the two-pass variance torch uses
+__device__ __forceinline__ void row_layernorm(RowRegs& r, const float* gamma, const float* beta, int d, int lane, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s += r.v[i][0] + r.v[i][1] + r.v[i][2] + r.v[i][3];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float t = r.v[i][e] - mean; q += t * t; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r.v[i][e] = (r.v[i][e] - mean) * rstd * g[e] + bb[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* res, const float* gamma, const float* beta,
+                                                        float* y, long rows, int d, long ldx, long ldy, float eps) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    RowRegs r;
+    row_load(r, x + row * ldx, d, lane);
+    if (res) {
+        RowRegs q;
+        row_load(q, res + row * ldx, d, lane);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) r.v[i] += q.v[i];
+    }
+    row_layernorm(r, gamma, beta, d, lane, eps);
+    row_store(r, y + row * ldy, d, lane);
+}
+
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    RowRegs r;
+    row_load(r, x + row * ldx, d, lane);
+    const float nrm = sqrtf(row_sumsq(r));
+    const float den = mode == 0 ? fmaxf(nrm, eps) : nrm + eps;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) r.v[i] = r.v[i] / den;
+    row_store(r, y + row * ldy, d, lane);
+}
+
+// y[row] = mean_{p<P} x[row*group_stride + row_add + p]
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* x, long ldx, float* y, long ldy, long n, int P, int d,
+                                                        long group_stride, long row_add) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    RowRegs acc;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) acc.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < P; ++p) {
+        RowRegs r;
+        row_load(r, x + (row * group_stride + row_add + p) * ldx, d, lane);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) acc.v[i] += r.v[i];
+    }
+    const float invp = 1.0f / (float)P;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) acc.v[i] = acc.v[i] * invp;
+    row_store(acc, y + row * ldy, d, lane);
+}
+
+// y[i] = x[(i / group)*group_stride + (i % group) + (idx ? idx[i] : row_add)]
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* x, long ldx, float* y, long ldy, long n, int d, int group,
+                                                          long group_stride, long row_add, const int* idx) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const long src = (row / group) * group_stride + (row % group) + (idx ? (long)idx[row] : row_add);
+    RowRegs r;
+    row_load(r, x + src * ldx, d, lane);
+    row_store(r, y + row * ldy, d, lane);
+}
+
+__global__ __launch_bounds__(256) void bert_embed_kernel(const float* cls, const float* local, const float* seq, const float* type_emb,
+                                                         const float* pos_emb, const float* gamma, const float* beta, float* X,
+                                                         int B, int P, int T, int d, float eps) {
+    const int S = 1 + P + T;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= (long)B * S) return;
+    const int b = (int)(row / S), s = (int)(row % S);
+    const float* src = s == 0 ? cls : (s <= P ? local + ((long)b * P + (s - 1)) * d : seq + ((long)b * T + (s - 1 - P)) * d);
+    RowRegs r, t, q;
+    row_load(r, src, d, lane);
+    row_load(t, type_emb + (s > P ? d : 0), d, lane);
+    row_load(q, pos_emb + (long)s * d, d, lane);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) r.v[i] = (r.v[i] + t.v[i]) + q.v[i];     // HF BertEmbeddings order: inputs + type, then + position
+    row_layernorm(r, gamma, beta, d, lane, eps);
+    row_store(r, X + row * d, d, lane);
+}
+
+__global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* text, const float* tok_emb, const float* pos_emb, float* X,
+                                                         int B, int T, int d, int vocab) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= (long)B * T) return;
+    const int s = (int)(row % T);
+    long tok = text[row];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    RowRegs r, q;
+    row_load(r, tok_emb + tok * d, d, lane);
+    row_load(q, pos_emb + (long)s * d, d, lane);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) r.v[i] += q.v[i];
+    row_store(r, X + row * d, d, lane);
+}
+
+// eot[b] = first position of the maximum token id (torch.argmax semantics on the reference's EOT pooling)
+__global__ void text_eot_kernel(const int64_t* text, int* eot, int B, int T) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    long best = text[(long)b * T];
+    int pos = 0;
+    for (int s = 1; s < T; ++s) {
+        const long v = text[(long)b * T + s];
+        if (v > best) { best = v; pos = s; }
+    }
+    eot[b] = pos;
+}
+
+__global__ __launch_bounds__(256) void vit_cls_kernel(const float* cls, const float* pos, float* X, int B, int tokens, int d) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    RowRegs r, q;
+    row_load(r, cls, d, lane);
+    row_load(q, pos, d, lane);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) r.v[i] += q.v[i];
+    row_store(r, X + row * tokens * d, d, lane);
+}
+
+__global__ __launch_bounds__(256) void combiner_finalize_kernel(const float* partial, int nb, const float* b2, const float* image,
+                                                                const float* text, float* out, long n, int d) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float z = b2[0];
+    for (int j = 0; j < nb; ++j) z += partial[row * nb + j];           // fixed order: deterministic
+    const float s = 1.0f / (1.0f + expf(-z));
+    RowRegs im, tx;
+    row_load(im, image + row * d, d, lane);
+    row_load(tx, text + row * d, d, lane);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) im.v[i] = tx.v[i] * s + im.v[i] * (1.0f - s);
+    const float den = fmaxf(sqrtf(row_sumsq(im)), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) im.v[i] = im.v[i] / den;
+    row_store(im, out + row * d, d, lane);
+}
+
+__global__ __launch_bounds__(256) void sr_finalize_kernel(const float* partial, int nb, const float* bc, const float* local, float* out,
+                                                          long n, int d) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float w[13];
+    float m = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < 13; ++p) {
+        float z = bc[0];
+        for (int j = 0; j < nb; ++j) z += partial[(row * 13 + p) * nb + j];
+        w[p] = z;
+        m = fmaxf(m, z);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int p = 0; p < 13; ++p) { w[p] = expf(w[p] - m); sum += w[p]; }
+    RowRegs acc;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) acc.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 13; ++p) {
+        RowRegs r;
+        row_load(r, local + (row * 13 + p) * d, d, lane);
+        const float wp = w[p] / sum;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) acc.v[i] += r.v[i] * wp;
+    }
+    const float den = sqrtf(row_sumsq(acc)) + 1e-8f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) acc.v[i] = acc.v[i] / den;
+    row_store(acc, out + row * d, d, lane);
+}
+
+// one wave per (query, named row): a coalesced d-wide dot product
+__global__ __launch_bounds__(256) void gather_scores_kernel(const float* q, const float* gallery, const int* idx, float* out, int B, int m, int d) {
+    const long item = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (item >= (long)B * m) return;
+    const int gi = idx[item];
+    if (gi < 0) { if (lane == 0) out[item] = -INFINITY; return; }
+    RowRegs a, g;
+    row_load(a, q + (item / m) * d, d, lane);
+    row_load(g, gallery + (long)gi * d, d, lane);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s += a.v[i][0] * g.v[i][0] + a.v[i][1] * g.v[i][1] + a.v[i][2] * g.v[i][2] + a.v[i][3] * g.v[i][3];
+    s = wave_sum(s);
+    if (lane == 0) out[item] = s;
+}
+
+static inline bool bad_width(int d) { return d <= 0 || (d & 3) || d > 64 * 4 * MAXV; }
+static inline dim3 row_grid(long rows) { return dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)); }
+
+hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* y, long rows, int d,
+                            long ldx, long ldy, float eps, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (bad_width(d) || (ldx & 3) || (ldy & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel, row_grid(rows), dim3(256), 0, s, x, res, gamma, beta, y, rows, d, ldx, ldy, eps);
+    return hipGetLastError();
+}
+hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (bad_width(d) || (ldx & 3) || (ldy & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(l2norm_kernel, row_grid(rows), dim3(256), 0, s, x, ldx, y, ldy, rows, d, eps, mode);
+    return hipGetLastError();
+}
+hipError_t launch_mean_rows(const float* x, long ldx, float* y, long ldy, long n, int P, int d, long group_stride, long row_add,
+                            hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (bad_width(d) || (ldx & 3) || (ldy & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mean_rows_kernel, row_grid(n), dim3(256), 0, s, x, ldx, y, ldy, n, P, d, group_stride, row_add);
+    return hipGetLastError();
+}
+hipError_t launch_gather_rows(const float* x, long ldx, float* y, long ldy, long n, int d, int group, long group_stride, long row_add,
+                              const int* idx, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (bad_width(d) || (ldx & 3) || (ldy & 3) || group < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_rows_kernel, row_grid(n), dim3(256), 0, s, x, ldx, y, ldy, n, d, group, group_stride, row_add, idx);
+    return hipGetLastError();
+}
+hipError_t launch_bert_embed(const float* cls, const float* local, const float* seq, const float* type_emb, const float* pos_emb,
+                             const float* gamma, const float* beta, float* X, int B, int P, int T, int d, float eps, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (bad_width(d)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bert_embed_kernel, row_grid((long)B * (1 + P + T)), dim3(256), 0, s, cls, local, seq, type_emb, pos_emb, gamma,
+                       beta, X, B, P, T, d, eps);
+    return hipGetLastError();
+}
+hipError_t launch_text_embed(const int64_t* text, const float* tok_emb, const float* pos_emb, float* X, int* eot, int B, int T, int d,
+                             int vocab, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (bad_width(d)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(text_embed_kernel, row_grid((long)B * T), dim3(256), 0, s, text, tok_emb, pos_emb, X, B, T, d, vocab);
+    hipLaunchKernelGGL(text_eot_kernel, dim3((B + 63) / 64), dim3(64), 0, s, text, eot, B, T);
+    return hipGetLastError();
+}
+hipError_t launch_vit_cls(const float* cls, const float* pos, float* X, int B, int tokens, int d, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (bad_width(d)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vit_cls_kernel, row_grid(B), dim3(256), 0, s, cls, pos, X, B, tokens, d);
+    return hipGetLastError();
+}
+hipError_t launch_combiner_finalize(const float* partial, int nb, const float* b2, const float* image, const float* text, float* out,
+                                    long n, int d, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (bad_width(d)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(combiner_finalize_kernel, row_grid(n), dim3(256), 0, s, partial, nb, b2, image, text, out, n, d);
+    return hipGetLastError();
+}
+hipError_t launch_sr_finalize(const float* partial, int nb, const float* bc, const float* local, float* out, long n, int d, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (bad_width(d)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sr_finalize_kernel, row_grid(n), dim3(256), 0, s, partial, nb, bc, local, out, n, d);
+    return hipGetLastError();
+}
+hipError_t launch_gather_scores(const float* q, const float* gallery, const int* idx, float* out, int B, int m, int d, hipStream_t s) {
+    if ((long)B * m <= 0) return hipSuccess;
+    if (bad_width(d)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_scores_kernel, row_grid((long)B * m), dim3(256), 0, s, q, gallery, idx, out, B, m, d);
+    return hipGetLastError();
+}
+
+}  // namespace fern

@@ -1,0 +1,93 @@
+// Internal launcher interface between the C-ABI layer (api.hip) and the kernel translation units.
+// gfx950 only; no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fern {
+
+// ---- GEMM: C[M,N] = A[M,K] * W[N,K]^T with fused epilogue (gemm.hip) ---------------------------
+enum GemmEpi : int {
+    EPI_BIAS = 0,            // C = acc + bias[col]                       (bias may be null)
+    EPI_BIAS_GELU = 1,       // exact erf GELU
+    EPI_BIAS_RELU = 2,
+    EPI_BIAS_RESIDUAL = 3,   // C = acc + bias + R[row*ldc + col]
+    EPI_COLAFFINE_TANH = 4,  // C = tanh((acc + bias[col]) * aux0[col] + aux1[col])   (Linear + BatchNorm1d(D) eval + Tanh)
+    EPI_PATCH_EMBED = 5,     // C[(row + row/G2 + 1)] = acc + aux0[((row % G2) + 1)*N + col]   (conv1 patches + pos-emb, cls slot skipped)
+    EPI_RELU_DOT = 6,        // partial[row][nb] = sum_col relu(acc + bias[col]) * aux0[col]       (Combiner hidden layer . w2)
+    EPI_SR_LOCAL = 7         // p = row % 13: v = tanh((acc + bias[col] - aux1[p]) * aux2[p] + aux3[p]);
+                             // partial[row][nb] = sum_col v * G[(row/13)*ldg + col] * aux0[col]     (VisualSR local branch)
+};
+enum GemmALoad : int { ALOAD_PLAIN = 0, ALOAD_IM2COL = 1 };
+
+struct GemmParams {
+    const float* A;
+    const float* W;
+    float* C;
+    const float* bias;
+    const float* R;        // residual (EPI_BIAS_RESIDUAL)
+    const float* aux0;
+    const float* aux1;
+    const float* aux2;
+    const float* aux3;
+    const float* G;        // EPI_SR_LOCAL: g_emb [n, ldg]
+    float* partial;        // reduce epilogues: [M, nbn]
+    long lda, ldw, ldc, ldg;
+    int M, N, K;
+    int epi, aload;
+    int img, patch, grid;  // ALOAD_IM2COL: image side, patch side, patches per side; EPI_PATCH_EMBED uses grid*grid
+};
+// Number of column blocks the reduce epilogues write per row (depends on the tile chosen for this shape).
+int gemm_num_col_blocks(int M, int N);
+hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+
+// ---- attention (attn.hip) ---------------------------------------------------------------------
+struct AttnParams {
+    const float* q; const float* k; const float* v; float* out;
+    long ldq, ldk, ldv, ldo;     // row strides (floats)
+    int batch, heads, hd, s_q, s_k, causal;
+    float scale;
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t s);   // hipErrorInvalidValue for unsupported shapes
+
+// ---- row-wise / element-wise kernels (elem.hip) -------------------------------------------------
+hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                            long rows, int d, long ldx, long ldy, float eps, hipStream_t s);
+// mode 0: x / max(||x||, eps) (F.normalize); mode 1: x / (||x|| + eps) (VisualSR.l2norm)
+hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s);
+// y[i, :] = mean_{p<P} x[i*group_stride + row_add + p, :]
+hipError_t launch_mean_rows(const float* x, long ldx, float* y, long ldy, long n, int P, int d, long group_stride, long row_add,
+                            hipStream_t s);
+// y[i, :] = x[(i / group)*group_stride + (i % group) + (idx ? idx[i] : row_add), :]
+hipError_t launch_gather_rows(const float* x, long ldx, float* y, long ldy, long n, int d, int group, long group_stride, long row_add,
+                              const int* idx, hipStream_t s);
+// BERT embeddings of the fusion encoder: X[b,s] = LN(cat(cls, local, seq)[b,s] + type[s >= P+1] + pos[s]) (eps 1e-12)
+hipError_t launch_bert_embed(const float* cls, const float* local, const float* seq, const float* type_emb,
+                             const float* pos_emb, const float* gamma, const float* beta, float* X,
+                             int B, int P, int T, int d, float eps, hipStream_t s);
+// CLIP text embeddings: X[b,s] = tok_emb[text[b,s]] + pos[s]; also eot[b] = argmax_s text[b,s]
+hipError_t launch_text_embed(const int64_t* text, const float* tok_emb, const float* pos_emb, float* X, int* eot,
+                             int B, int T, int d, int vocab, hipStream_t s);
+// ViT class rows: X[b, 0, :] = cls + pos[0]
+hipError_t launch_vit_cls(const float* cls, const float* pos, float* X, int B, int tokens, int d, hipStream_t s);
+// CombinerSimple tail: s = sigmoid(sum_nb partial[row][nb] + b2); out = normalize(s*text + (1-s)*image)
+hipError_t launch_combiner_finalize(const float* partial, int nb, const float* b2, const float* image, const float* text,
+                                    float* out, long n, int d, hipStream_t s);
+// VisualSR tail: logits[p] = sum_nb partial[row*13+p][nb] + bc; w = softmax_13; new = sum w_p local_p; out = new/(||new||+1e-8)
+hipError_t launch_sr_finalize(const float* partial, int nb, const float* bc, const float* local, float* out,
+                              long n, int d, hipStream_t s);
+// scores[b, j] = q[b] . gallery[idx[b, j]]  (idx < 0 -> -inf)
+hipError_t launch_gather_scores(const float* q, const float* gallery, const int* idx, float* out, int B, int m, int d,
+                                hipStream_t s);
+
+// ---- top-K (topk.hip) ------------------------------------------------------------------------
+// Per row of `scores` [B, ld] (n valid columns): K best (score desc, index asc).  out idx = col + idx_offset.
+// `keys_ws` must hold B * nseg * 64 uint64 (nseg = topk_num_segments(n)).
+int topk_num_segments(long n);
+hipError_t launch_topk_rows(const float* scores, long ld, int B, long n, int K, long idx_offset, const int* exclude_idx,
+                            unsigned long long* keys_ws, float* out_scores, int* out_idx, hipStream_t s);
+// Merge R lists [R,B,K] (score, idx) -> [B,K]
+hipError_t launch_topk_merge(const float* scores, const int* idx, float* out_scores, int* out_idx, int R, int B, int K,
+                             hipStream_t s);
+
+}  // namespace fern

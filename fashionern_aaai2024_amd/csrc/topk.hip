@@ -1,0 +1,153 @@
+// Wavefront-reduced exact top-K (K <= 64) over score rows; replaces the reference's full
+// torch.argsort of the [Q, N] distance matrix (run/test/test_fiq.py:50), of which only ranks
+// < 50 (51 for CIRR) are ever consumed.
+//
+// Ordering = score descending, gallery index ascending.  Both are packed into one 64-bit key
+//     key = orderable(score) << 32 | (0xFFFFFFFF - index)
+// so a plain unsigned compare implements the whole rule and ties are deterministic.
+//
+// A wave keeps its current best-64 list SORTED, ONE ENTRY PER LANE.  Scores are streamed 64 at a time
+// (coalesced); a candidate enters only if it beats the list's K-th entry, so after warm-up almost every
+// 64-wide step is a single compare + ballot.  An insertion is O(1) wave operations:
+// position = popcount(ballot(list > cand)), shift the tail down one lane, drop the candidate in.
+// Level 1: grid (segments, B), 4 waves per workgroup each streaming a slice; the 4 lists are merged
+// through LDS by streaming them into wave 0's list.  Level 2: one wave per query merges the segment lists.
+#include "kernels.h"
+
+namespace fern {
+
+typedef unsigned long long u64;
+constexpr int SEG = 8192;          // scores per level-1 workgroup
+
+__device__ __forceinline__ unsigned orderable(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unorderable(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ u64 make_key(float score, unsigned idx) {
+    return ((u64)orderable(score) << 32) | (u64)(0xFFFFFFFFu - idx);
+}
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+    const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_up64(u64 v) {
+    const unsigned lo = __shfl_up((unsigned)v, 1), hi = __shfl_up((unsigned)(v >> 32), 1);
+    return ((u64)hi << 32) | lo;
+}
+
+// Offer one candidate per lane (key 0 = no candidate) to the wave's sorted list `best` (lane i = i-th best).
+__device__ __forceinline__ void wave_offer(u64& best, u64 cand, int K, int lane) {
+    u64 thr = shfl64(best, K - 1);
+    u64 mask = __ballot(cand > thr);
+    while (mask) {
+        const int src = __ffsll((long long)mask) - 1;
+        const u64 c = shfl64(cand, src);
+        mask &= mask - 1;
+        if (c > thr) {                                            // wave-uniform
+            const int pos = __popcll(__ballot(best > c));        // entries that stay ahead of c
+            const u64 up = shfl_up64(best);
+            best = lane < pos ? best : (lane == pos ? c : up);
+            thr = shfl64(best, K - 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, long ld, long n, int K, const int* exclude_idx,
+                                                        long idx_offset, u64* keys_ws, int nseg) {
+    __shared__ u64 lists[4][64];
+    const int seg = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* row = scores + (long)b * ld;
+    const long seg_lo = (long)seg * SEG;
+    const long seg_hi = seg_lo + SEG < n ? seg_lo + SEG : n;
+    const long per_wave = (SEG / 4);
+    const long lo = seg_lo + wave * per_wave;
+    const long hi = lo + per_wave < seg_hi ? lo + per_wave : seg_hi;
+    const long excl = exclude_idx ? (long)exclude_idx[b] - idx_offset : -1;   // local column to drop
+
+    u64 best = 0;
+    for (long base = lo; base < hi; base += 64) {
+        const long j = base + lane;
+        u64 cand = 0;
+        if (j < hi && j != excl) cand = make_key(row[j], (unsigned)j);
+        wave_offer(best, cand, K, lane);
+    }
+    lists[wave][lane] = best;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll 1
+        for (int w = 1; w < 4; ++w) wave_offer(best, lists[w][lane], K, lane);
+        keys_ws[((long)b * nseg + seg) * 64 + lane] = best;
+    }
+}
+
+// one wave per query: merge `nlists` sorted 64-entry lists, decode to (score, global index)
+__global__ __launch_bounds__(64) void topk_final_kernel(const u64* keys_ws, int nlists, int K, long idx_offset, float* out_scores,
+                                                        int* out_idx) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    u64 best = keys_ws[(long)b * nlists * 64 + lane];
+#pragma unroll 1
+    for (int l = 1; l < nlists; ++l) wave_offer(best, keys_ws[((long)b * nlists + l) * 64 + lane], K, lane);
+    if (lane < K) {
+        float s = -INFINITY;
+        int idx = -1;
+        if (best != 0) {
+            s = unorderable((unsigned)(best >> 32));
+            idx = (int)((long)(0xFFFFFFFFu - (unsigned)best) + idx_offset);
+        }
+        out_scores[(long)b * K + lane] = s;
+        out_idx[(long)b * K + lane] = idx;
+    }
+}
+
+// merge R per-shard lists given as (score, global idx) pairs [R,B,K]
+__global__ __launch_bounds__(64) void topk_merge_kernel(const float* scores, const int* idx, float* out_scores, int* out_idx, int R,
+                                                        int B, int K) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    u64 best = 0;
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+        u64 cand = 0;
+        if (lane < K) {
+            const long o = ((long)r * B + b) * K + lane;
+            const int gi = idx[o];
+            if (gi >= 0) cand = make_key(scores[o], (unsigned)gi);
+        }
+        wave_offer(best, cand, K, lane);
+    }
+    if (lane < K) {
+        float s = -INFINITY;
+        int gi = -1;
+        if (best != 0) {
+            s = unorderable((unsigned)(best >> 32));
+            gi = (int)(0xFFFFFFFFu - (unsigned)best);
+        }
+        out_scores[(long)b * K + lane] = s;
+        out_idx[(long)b * K + lane] = gi;
+    }
+}
+
+int topk_num_segments(long n) { return (int)((n + SEG - 1) / SEG > 0 ? (n + SEG - 1) / SEG : 1); }
+
+hipError_t launch_topk_rows(const float* scores, long ld, int B, long n, int K, long idx_offset, const int* exclude_idx, u64* keys_ws,
+                            float* out_scores, int* out_idx, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (K < 1 || K > 64 || n < 0 || n > 0x7FFFFFF0L) return hipErrorInvalidValue;
+    const int nseg = topk_num_segments(n);
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(nseg, B), dim3(256), 0, s, scores, ld, n, K, exclude_idx, idx_offset, keys_ws, nseg);
+    hipLaunchKernelGGL(topk_final_kernel, dim3(B), dim3(64), 0, s, keys_ws, nseg, K, idx_offset, out_scores, out_idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_topk_merge(const float* scores, const int* idx, float* out_scores, int* out_idx, int R, int B, int K, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (K < 1 || K > 64 || R < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(64), 0, s, scores, idx, out_scores, out_idx, R, B, K);
+    return hipGetLastError();
+}
+
+}  // namespace fern

@@ -1,0 +1,258 @@
+"""Thin torch-facing wrapper over the libfern C ABI.
+
+torch is used for what it is good at here -- device memory, streams, process groups -- and nothing
+else: every op below hands raw ``data_ptr()``s of caller/torch-allocated buffers to a HIP kernel
+sequence in libfern.so on torch's current stream.  There is no eager/CPU fallback: constructing an
+engine without a ROCm device or without the library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synth import ClipConfig
+
+COMBINER_TARGET, COMBINER_DVR_GLOBAL, COMBINER_DVR_LOCAL, COMBINER_DVR_FINAL = 0, 1, 2, 3
+SR_TARGET, SR_DVR = 0, 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
+PATCH_NUM = 13
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class FernEngine:
+    """One native context on one GPU.  Not thread-safe (one per device per process)."""
+
+    def __init__(self, device="cuda:0"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("FernEngine needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"FernEngine runs on a GPU only, got device {device!r}")
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        h = C.c_void_p()
+        _lib.check(self.lib.fern_ctx_create(index, C.byref(h)), "fern_ctx_create")
+        self._h = h
+        self.feature_dim: Optional[int] = None
+        self.clip_cfg: Optional[ClipConfig] = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.fern_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tensors ------------------------------------------------------------------------------
+    def _f32(self, t, shape=None) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def _empty(self, *shape, dtype=torch.float32) -> torch.Tensor:
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    # ---- weights ------------------------------------------------------------------------------
+    def load_tensors(self, state_dict: Mapping[str, object], prefix: str = "") -> None:
+        """Push a state dict (reference key names; torch tensors or numpy arrays) to the native side."""
+        for key, val in state_dict.items():
+            if isinstance(val, torch.Tensor):
+                val = val.detach().cpu().numpy()
+            arr = np.asarray(val)
+            if arr.dtype.kind == "f":
+                arr, dt = np.ascontiguousarray(arr, dtype=np.float32), 0
+            else:
+                arr, dt = np.ascontiguousarray(arr, dtype=np.int64), 1
+            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            _lib.check(self.lib.fern_load_tensor(self._h, (prefix + key).encode(), arr.ctypes.data_as(C.c_void_p), dt,
+                                                 arr.ndim, shape), f"fern_load_tensor({key})")
+
+    def finalize_fusion(self, feature_dim: int) -> None:
+        _lib.check(self.lib.fern_finalize_fusion(self._h, int(feature_dim)), "fern_finalize_fusion")
+        self.feature_dim = int(feature_dim)
+
+    def finalize_clip(self, cfg: ClipConfig) -> None:
+        cc = _lib.ClipConfigC(cfg.embed_dim, cfg.image_size, cfg.patch_size, cfg.v_width, cfg.v_layers, cfg.v_heads,
+                              cfg.v_mlp, cfg.context_length, cfg.vocab_size, cfg.t_width, cfg.t_heads, cfg.t_layers, cfg.t_mlp)
+        _lib.check(self.lib.fern_finalize_clip(self._h, C.byref(cc)), "fern_finalize_clip")
+        self.clip_cfg = cfg
+
+    # ---- encoders -----------------------------------------------------------------------------
+    def encode_image(self, images: torch.Tensor) -> torch.Tensor:
+        cfg = self.clip_cfg
+        if cfg is None:
+            raise _lib.FernError("encode_image: CLIP weights not finalised")
+        x = self._f32(images)
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, cfg.image_size, cfg.image_size):
+            raise ValueError(f"images must be [b,3,{cfg.image_size},{cfg.image_size}], got {tuple(x.shape)}")
+        out = self._empty(x.shape[0], cfg.embed_dim)
+        _lib.check(self.lib.fern_vit_encode_image(self._h, _ptr(x), _ptr(out), x.shape[0], _stream()), "fern_vit_encode_image")
+        return out
+
+    def encode_text(self, tokens: torch.Tensor, want_global=True, want_seq=True):
+        cfg = self.clip_cfg
+        if cfg is None:
+            raise _lib.FernError("encode_text: CLIP weights not finalised")
+        t = tokens.to(device=self.device, dtype=torch.int64).contiguous()
+        if t.dim() != 2 or t.shape[1] != cfg.context_length:
+            raise ValueError(f"text must be int64 [B,{cfg.context_length}], got {tuple(t.shape)}")
+        b = t.shape[0]
+        g = self._empty(b, cfg.embed_dim) if want_global else None
+        s = self._empty(b, cfg.context_length, cfg.embed_dim) if want_seq else None
+        _lib.check(self.lib.fern_text_encode(self._h, _ptr(t), _ptr(g), _ptr(s), b, _stream()), "fern_text_encode")
+        return g, s
+
+    # ---- fusion -------------------------------------------------------------------------------
+    def _d(self) -> int:
+        if self.feature_dim is None:
+            raise _lib.FernError("fusion weights not finalised")
+        return self.feature_dim
+
+    def dvr_fuse(self, ref_global, ref_local, text_global, text_seq) -> torch.Tensor:
+        d = self._d()
+        rl = self._f32(ref_local)
+        b = rl.shape[0]
+        ts = self._f32(text_seq)
+        if rl.dim() != 3 or rl.shape[1] != PATCH_NUM or rl.shape[2] != d:
+            raise ValueError(f"ref_local_feats must be [B,{PATCH_NUM},{d}], got {tuple(rl.shape)}")
+        if ts.dim() != 3 or ts.shape[0] != b or ts.shape[2] != d:
+            raise ValueError(f"text_seq_feats must be [B,T,{d}], got {tuple(ts.shape)}")
+        rg, tg = self._f32(ref_global, (b, d)), self._f32(text_global, (b, d))
+        out = self._empty(b, d)
+        _lib.check(self.lib.fern_dvr_fuse(self._h, _ptr(rg), _ptr(rl), _ptr(tg), _ptr(ts), _ptr(out), b, ts.shape[1],
+                                          _stream()), "fern_dvr_fuse")
+        return out
+
+    def index_fuse(self, tar_feats, tar_local, normalize_input=False) -> torch.Tensor:
+        d = self._d()
+        tl = self._f32(tar_local)
+        n = tl.shape[0]
+        if tl.dim() != 3 or tl.shape[1] != PATCH_NUM or tl.shape[2] != d:
+            raise ValueError(f"tar_local_feats must be [n,{PATCH_NUM},{d}], got {tuple(tl.shape)}")
+        tf = self._f32(tar_feats, (n, d))
+        out = self._empty(n, d)
+        _lib.check(self.lib.fern_index_fuse(self._h, _ptr(tf), _ptr(tl), _ptr(out), n, int(bool(normalize_input)), _stream()),
+                   "fern_index_fuse")
+        return out
+
+    def combiner(self, which: int, image, text) -> torch.Tensor:
+        d = self._d()
+        im = self._f32(image)
+        if im.dim() != 2 or im.shape[1] != d:
+            raise ValueError(f"image_features must be [n,{d}], got {tuple(im.shape)}")
+        tx = self._f32(text, tuple(im.shape))
+        out = self._empty(*im.shape)
+        _lib.check(self.lib.fern_combiner(self._h, which, _ptr(im), _ptr(tx), _ptr(out), im.shape[0], _stream()), "fern_combiner")
+        return out
+
+    def visual_sr(self, which: int, local) -> torch.Tensor:
+        d = self._d()
+        x = self._f32(local)
+        if x.dim() != 3 or x.shape[1] != PATCH_NUM or x.shape[2] != d:
+            raise ValueError(f"local_feature must be [n,{PATCH_NUM},{d}], got {tuple(x.shape)}")
+        out = self._empty(x.shape[0], d)
+        _lib.check(self.lib.fern_visual_sr(self._h, which, _ptr(x), _ptr(out), x.shape[0], _stream()), "fern_visual_sr")
+        return out
+
+    def l2_normalize(self, x) -> torch.Tensor:
+        x = self._f32(x)
+        out = torch.empty_like(x)
+        _lib.check(self.lib.fern_l2_normalize(self._h, _ptr(x), _ptr(out), x.shape[0], x.shape[1], _stream()), "fern_l2_normalize")
+        return out
+
+    # ---- rank ---------------------------------------------------------------------------------
+    def sim_topk(self, q, gallery, k: int, idx_offset: int = 0, exclude_idx=None):
+        q, g = self._f32(q), self._f32(gallery)
+        if q.dim() != 2 or g.dim() != 2 or q.shape[1] != g.shape[1]:
+            raise ValueError(f"q [B,D] and gallery [N,D] must share D, got {tuple(q.shape)} and {tuple(g.shape)}")
+        b = q.shape[0]
+        scores = self._empty(b, k)
+        idx = self._empty(b, k, dtype=torch.int32)
+        ex = None
+        if exclude_idx is not None:
+            ex = torch.as_tensor(exclude_idx).to(device=self.device, dtype=torch.int32).contiguous()
+            if tuple(ex.shape) != (b,):
+                raise ValueError("exclude_idx must be [B]")
+        _lib.check(self.lib.fern_sim_topk(self._h, _ptr(q), _ptr(g), b, g.shape[0], q.shape[1], int(k), _ptr(scores), _ptr(idx),
+                                          int(idx_offset), _ptr(ex), _stream()), "fern_sim_topk")
+        return scores, idx
+
+    def gather_scores(self, q, gallery, idx):
+        q, g = self._f32(q), self._f32(gallery)
+        ix = torch.as_tensor(idx).to(device=self.device, dtype=torch.int32).contiguous()
+        out = self._empty(*ix.shape)
+        _lib.check(self.lib.fern_gather_scores(self._h, _ptr(q), _ptr(g), _ptr(ix), _ptr(out), ix.shape[0], ix.shape[1],
+                                               q.shape[1], _stream()), "fern_gather_scores")
+        return out
+
+    def topk_merge(self, scores, idx):
+        s = self._f32(scores)
+        ix = torch.as_tensor(idx).to(device=self.device, dtype=torch.int32).contiguous()
+        r, b, k = s.shape
+        os_, oi = self._empty(b, k), self._empty(b, k, dtype=torch.int32)
+        _lib.check(self.lib.fern_topk_merge(self._h, _ptr(s), _ptr(ix), _ptr(os_), _ptr(oi), r, b, k, _stream()), "fern_topk_merge")
+        return os_, oi
+
+    # ---- building blocks ----------------------------------------------------------------------
+    def gemm(self, a, w, bias=None, residual=None, epilogue=EPI_BIAS) -> torch.Tensor:
+        a, w = self._f32(a), self._f32(w)
+        m, k = a.shape
+        n = w.shape[0]
+        bias = None if bias is None else self._f32(bias, (n,))
+        residual = None if residual is None else self._f32(residual, (m, n))
+        out = self._empty(m, n)
+        _lib.check(self.lib.fern_gemm(self._h, _ptr(a), k, _ptr(w), k, _ptr(bias), _ptr(residual), _ptr(out), n, m, n, k,
+                                      int(epilogue), _stream()), "fern_gemm")
+        return out
+
+    def layernorm(self, x, gamma, beta, eps: float, residual=None) -> torch.Tensor:
+        x = self._f32(x)
+        rows, d = x.shape
+        residual = None if residual is None else self._f32(residual, (rows, d))
+        out = torch.empty_like(x)
+        _lib.check(self.lib.fern_layernorm(self._h, _ptr(x), _ptr(residual), _ptr(self._f32(gamma, (d,))),
+                                           _ptr(self._f32(beta, (d,))), _ptr(out), rows, d, float(eps), _stream()), "fern_layernorm")
+        return out
+
+    def attention(self, q, k, v, heads: int, causal=False, scale=None) -> torch.Tensor:
+        """q [B,Sq,W], k/v [B,Sk,W] -> [B,Sq,W] (W = heads * head_dim)."""
+        q, k, v = self._f32(q), self._f32(k), self._f32(v)
+        b, sq, w = q.shape
+        sk = k.shape[1]
+        hd = w // heads
+        out = torch.empty_like(q)
+        sc = float(scale) if scale is not None else hd ** -0.5
+        _lib.check(self.lib.fern_attention(self._h, _ptr(q), w, _ptr(k), w, _ptr(v), w, _ptr(out), w, b, heads, hd, sq, sk,
+                                           int(bool(causal)), sc, _stream()), "fern_attention")
+        return out
+
+    # ---- profiling ----------------------------------------------------------------------------
+    def prof_enable(self, on: bool) -> None:
+        _lib.check(self.lib.fern_prof_enable(self._h, int(on)), "fern_prof_enable")
+
+    def prof_collect(self) -> Dict[str, float]:
+        st = _lib.ProfStats()
+        _lib.check(self.lib.fern_prof_collect(self._h, C.byref(st)), "fern_prof_collect")
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
+    def sync(self) -> None:
+        _lib.check(self.lib.fern_sync(self._h, _stream()), "fern_sync")

@@ -1,0 +1,177 @@
+/*
+ * fern.h -- C ABI of libfern.so: the MI355X (gfx950) implementation of FashionERN's
+ * encode -> fuse -> rank inference path.
+ *
+ * The reference has no FFI: the path sits behind a Python object protocol
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference repository root).  All pointers are raw device pointers
+ * unless a parameter is called `host_*`; matrices are row-major, contiguous unless an ld* is
+ * given; fp32 throughout (the reference evaluates in fp32: run/test/test_fiq.py:145,169).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative fern_status otherwise;
+ *     fern_last_error() returns a message for the calling thread's last failure;
+ *   - launch functions are asynchronous on `stream` (a hipStream_t passed as void*) and never
+ *     synchronise; workspaces grow on first use (hipMalloc), so run one warm-up call per shape
+ *     before capturing into a hipGraph;
+ *   - a context is bound to one device and is not thread-safe (one per device per process).
+ */
+#ifndef FERN_H
+#define FERN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FERN_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define FERN_API __attribute__((visibility("default")))
+#else
+#define FERN_API
+#endif
+
+typedef struct fern_ctx fern_ctx;
+
+typedef enum {
+    FERN_OK = 0,
+    FERN_ERR_ARG = -1,      /* bad argument / unsupported shape */
+    FERN_ERR_HIP = -2,      /* HIP runtime error */
+    FERN_ERR_STATE = -3,    /* weights missing / not finalised */
+    FERN_ERR_NOMEM = -4
+} fern_status;
+
+typedef enum { FERN_F32 = 0, FERN_I64 = 1 } fern_dtype;
+
+/* which CombinerSimple / VisualSR instance of ERN (models/model.py:16-20, fusion_model.py:17-24) */
+typedef enum {
+    FERN_COMBINER_TARGET = 0,      /* ERN.Combiner_module      (model.py:20)  */
+    FERN_COMBINER_DVR_GLOBAL = 1,  /* DVR.combiner_global      (fusion_model.py:22) */
+    FERN_COMBINER_DVR_LOCAL = 2,   /* DVR.combiner_local       (fusion_model.py:23) */
+    FERN_COMBINER_DVR_FINAL = 3    /* DVR.combiner             (fusion_model.py:24) */
+} fern_combiner_id;
+
+typedef enum {
+    FERN_SR_TARGET = 0,            /* ERN.SR_module            (model.py:19) */
+    FERN_SR_DVR = 1                /* DVR.SR_module            (fusion_model.py:17) */
+} fern_sr_id;
+
+/* CLIP tower shapes (open_clip model config) */
+typedef struct {
+    int embed_dim;
+    int image_size, patch_size, v_width, v_layers, v_heads, v_mlp;   /* v_layers == 0: no image tower */
+    int context_length, vocab_size, t_width, t_heads, t_layers, t_mlp;
+} fern_clip_config;
+
+/* GEMM epilogues exposed for tests and for reference-side composition */
+typedef enum {
+    FERN_EPI_BIAS = 0,          /* C = A W^T + bias (bias may be NULL)            */
+    FERN_EPI_BIAS_GELU = 1,     /* exact erf GELU                                 */
+    FERN_EPI_BIAS_RELU = 2,
+    FERN_EPI_BIAS_RESIDUAL = 3  /* C = A W^T + bias + R  (R has leading dim ldc)  */
+} fern_epilogue;
+
+/* kernel-time accounting for bench.py's roofline block */
+typedef struct {
+    double gemm_ms;        /* sum of HIP-event durations of every fp32-MFMA GEMM launch */
+    double gemm_flops;     /* sum of 2*M*N*K of those launches */
+    int64_t gemm_launches;
+    double attn_ms;
+    double attn_flops;
+    int64_t attn_launches;
+    double topk_ms;        /* top-K selection kernels */
+    int64_t topk_launches;
+    double sweep_ms;       /* similarity sweep (scores GEMM inside fern_sim_topk) */
+    double sweep_bytes;    /* algorithmic bytes of those sweeps: N*D*4 + B*D*4 + B*N*4 */
+    int64_t sweep_launches;
+} fern_prof_stats;
+
+FERN_API int fern_abi_version(void);
+FERN_API const char* fern_last_error(void);
+
+/* lifetime ------------------------------------------------------------------------------ */
+FERN_API int fern_ctx_create(int device, fern_ctx** out);
+FERN_API int fern_ctx_destroy(fern_ctx* ctx);
+FERN_API int fern_sync(fern_ctx* ctx, void* stream);
+
+/* weights: replaces nn.Module.load_state_dict (run/test/test_fiq.py:143,149) ----------------
+ * `key` is the reference state-dict key (open_clip names for the CLIP
+ * towers).  Data is copied; unknown keys are kept but unused (e.g. pooler, position_ids,
+ * num_batches_tracked, logit_scale).  host_ptr is HOST memory. */
+FERN_API int fern_load_tensor(fern_ctx* ctx, const char* key, const void* host_ptr, int dtype, int ndim,
+                     const int64_t* shape);
+/* repack for the kernels (packed QKV, folded BatchNorm, transposed projections) and upload */
+FERN_API int fern_finalize_fusion(fern_ctx* ctx, int feature_dim);          /* ERN(clip, feature_dim, device) model.py:8 */
+FERN_API int fern_finalize_clip(fern_ctx* ctx, const fern_clip_config* cfg); /* open_clip.create_model_and_transforms test_fiq.py:141 */
+
+/* encoders ------------------------------------------------------------------------------ */
+/* clip_model.encode_image(images) -- call site utils/utils.py:64, models/clip_model.py:13-15.
+ * images [b,3,S,S] f32 NCHW -> out [b,embed_dim], un-normalised. */
+FERN_API int fern_vit_encode_image(fern_ctx* ctx, const float* images, float* out, int b, void* stream);
+/* clip_model.encode_text(text, mode=, visual_emb=) -- call sites run/test/test_fiq.py:102-103,
+ * models/clip_model.py:23-31.  tokens [B,ctx] int64 -> out_global [B,D] (may be NULL) and
+ * out_seq [B,ctx,D] (may be NULL); one tower pass serves both (SURVEY.md 8c definition). */
+FERN_API int fern_text_encode(fern_ctx* ctx, const int64_t* tokens, float* out_global, float* out_seq, int B,
+                     void* stream);
+
+/* fusion -------------------------------------------------------------------------------- */
+/* ERN.forward(mode="test") = DVR_module.forward -- models/model.py:68-69, fusion_model.py:26-55 */
+FERN_API int fern_dvr_fuse(fern_ctx* ctx, const float* ref_global /*[B,D]*/, const float* ref_local /*[B,13,D]*/,
+                  const float* text_global /*[B,D]*/, const float* text_seq /*[B,77,D]*/,
+                  float* out /*[B,D]*/, int B, int seq_len, void* stream);
+/* ERN.forward(mode="index") -- models/model.py:64-66; normalize_input folds the caller's
+ * F.normalize(index_features) (run/test/test_fiq.py:45).  Tiles over n internally. */
+FERN_API int fern_index_fuse(fern_ctx* ctx, const float* tar_feats /*[n,D]*/, const float* tar_local /*[n,13,D]*/,
+                    float* out /*[n,D]*/, int64_t n, int normalize_input, void* stream);
+/* CombinerSimple.forward(image_features, text_features) -- fusion_model.py:86-94 */
+FERN_API int fern_combiner(fern_ctx* ctx, int which, const float* image /*[n,D]*/, const float* text /*[n,D]*/,
+                  float* out /*[n,D]*/, int64_t n, void* stream);
+/* VisualSR.forward(local_feature) -- fusion_model.py:141-154 */
+FERN_API int fern_visual_sr(fern_ctx* ctx, int which, const float* local /*[n,13,D]*/, float* out /*[n,D]*/,
+                   int64_t n, void* stream);
+/* F.normalize(x, dim=-1) -- run/test/test_fiq.py:45 */
+FERN_API int fern_l2_normalize(fern_ctx* ctx, const float* x, float* out, int64_t n, int d, void* stream);
+
+/* rank ---------------------------------------------------------------------------------- */
+/* distances = 1 - q @ g.T ; argsort(distances)[:, :K] -- run/test/test_fiq.py:49-50.
+ * Scores are cosines (q.g), sorted descending, ties -> lower gallery index.  out_idx holds
+ * local row + idx_offset; exclude_idx (may be NULL) [B] removes one global index per query
+ * (CIRR reference removal, run/test/test_cirr.py:55-58).  Unfilled slots: score -inf, idx -1.
+ * 1 <= K <= 64. */
+FERN_API int fern_sim_topk(fern_ctx* ctx, const float* q /*[B,D]*/, const float* gallery /*[N,D]*/, int B,
+                  int64_t N, int D, int K, float* out_scores /*[B,K]*/, int32_t* out_idx /*[B,K]*/,
+                  int64_t idx_offset, const int32_t* exclude_idx, void* stream);
+/* scores of explicitly named gallery rows (CIRR subset ranking, run/test/test_cirr.py:64-66);
+ * idx < 0 -> -inf */
+FERN_API int fern_gather_scores(fern_ctx* ctx, const float* q /*[B,D]*/, const float* gallery /*[N,D]*/,
+                       const int32_t* idx /*[B,m]*/, float* out /*[B,m]*/, int B, int m, int D,
+                       void* stream);
+/* merge R per-shard top-K lists (gallery sharded over R GPUs; SURVEY.md 8e alternative) */
+FERN_API int fern_topk_merge(fern_ctx* ctx, const float* scores /*[R,B,K]*/, const int32_t* idx /*[R,B,K]*/,
+                    float* out_scores /*[B,K]*/, int32_t* out_idx /*[B,K]*/, int R, int B, int K,
+                    void* stream);
+
+/* building blocks (exported for kernel-level parity tests) -------------------------------- */
+/* C[M,N] = A[M,K] W[N,K]^T (+ epilogue); fp32 MFMA.  K % 32 == 0, lda/ldw % 4 == 0. */
+FERN_API int fern_gemm(fern_ctx* ctx, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+              const float* residual, float* C, int64_t ldc, int M, int N, int K, int epilogue,
+              void* stream);
+/* y = LayerNorm(x (+ residual)) * gamma + beta, rows of width d */
+FERN_API int fern_layernorm(fern_ctx* ctx, const float* x, const float* residual, const float* gamma,
+                   const float* beta, float* y, int64_t rows, int d, float eps, void* stream);
+/* softmax(scale * Q K^T (+causal)) V per (batch, head); q/k/v row strides in floats */
+FERN_API int fern_attention(fern_ctx* ctx, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                   int64_t ldv, float* out, int64_t ldo, int batch, int heads, int head_dim, int s_q,
+                   int s_k, int causal, float scale, void* stream);
+
+/* profiling ----------------------------------------------------------------------------- */
+FERN_API int fern_prof_enable(fern_ctx* ctx, int on);    /* wrap GEMM/attention/top-K launches in HIP events */
+FERN_API int fern_prof_collect(fern_ctx* ctx, fern_prof_stats* out);  /* synchronises, sums, resets */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FERN_H */

@@ -1,0 +1,82 @@
+"""Oracle: CLIP ViT image tower and text tower (torch CPU fp32).  TEST INFRASTRUCTURE.
+
+PARITY UNPINNED by the reference's own call path: ``clip_model.encode_image`` /
+``encode_text`` are called at /root/reference/utils/utils.py:64 and
+/root/reference/run/test/test_fiq.py:102-103 on an object built by third-party
+open-clip-torch==2.20.0 (environment.yml:114) plus the authors' unreleased text encoder
+(README.md:41); neither is in /root/reference.  The arithmetic restated here follows the one
+in-tree statement of CLIP, /root/reference/models/others/modeling_clip.py (cited per step), the
+open_clip "ViT-B-16" shape (exact-erf GELU), and open_clip's state-dict key names.
+``tools/make_goldens.py`` executes that in-tree file on the same weights to pin this module.
+
+Definition of the un-pinned ``encode_text(text, mode=, visual_emb=)``: one
+text-tower pass; ``seq = ln_final(h) @ text_projection`` [B,77,D]; ``global = seq[b, argmax(text[b])]``;
+default/"global" mode returns ``(global, seq)``, "seq" returns ``seq``; ``visual_emb`` is
+shape-checked and ignored ("vanilla CLIP single branch", README.md:41).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _ln(sd, prefix, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
+
+
+def _attention(sd, prefix, x, heads, causal):
+    """modeling_clip.py:272-336: q scaled by hd**-0.5 before QK^T, additive causal mask, softmax, PV."""
+    b, s, w = x.shape
+    hd = w // heads
+    qkv = F.linear(x, sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"])
+    q, k, v = qkv.split(w, dim=-1)
+    q = q.view(b, s, heads, hd).transpose(1, 2) * (hd ** -0.5)
+    k = k.view(b, s, heads, hd).transpose(1, 2)
+    v = v.view(b, s, heads, hd).transpose(1, 2)
+    att = q @ k.transpose(-1, -2)
+    if causal:                                            # modeling_clip.py:677-691
+        att = att + torch.full((s, s), float("-inf")).triu(1)
+    att = torch.softmax(att, dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(b, s, w)
+    return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
+
+
+def _block(sd, prefix, x, heads, causal):
+    """Pre-LN residual block, modeling_clip.py:354-401; MLP :339-351 with exact GELU."""
+    x = x + _attention(sd, prefix + ".attn", _ln(sd, prefix + ".ln_1", x), heads, causal)
+    h = F.gelu(F.linear(_ln(sd, prefix + ".ln_2", x), sd[prefix + ".mlp.c_fc.weight"], sd[prefix + ".mlp.c_fc.bias"]))
+    return x + F.linear(h, sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"])
+
+
+def encode_image(sd, cfg, images):
+    """[b,3,H,W] f32 -> [b,embed_dim] un-normalised (call site utils/utils.py:64)."""
+    w = sd["visual.conv1.weight"]
+    x = F.conv2d(images, w, stride=cfg.patch_size)                      # modeling_clip.py:180-196
+    x = x.flatten(2).transpose(1, 2)                                    # [b, g*g, width]
+    cls = sd["visual.class_embedding"].expand(x.shape[0], 1, -1)
+    x = torch.cat((cls, x), dim=1) + sd["visual.positional_embedding"]  # :197-200
+    x = _ln(sd, "visual.ln_pre", x)                                     # :839,866
+    for i in range(cfg.v_layers):
+        x = _block(sd, f"visual.transformer.resblocks.{i}", x, cfg.v_heads, causal=False)
+    pooled = _ln(sd, "visual.ln_post", x[:, 0])                         # :876-877
+    return pooled @ sd["visual.proj"]                                   # :977,1076 (bias-free)
+
+
+def text_hidden(sd, cfg, text):
+    x = sd["token_embedding.weight"][text] + sd["positional_embedding"][: text.shape[1]]   # :204-232
+    for i in range(cfg.t_layers):
+        x = _block(sd, f"transformer.resblocks.{i}", x, cfg.t_heads, causal=True)
+    return _ln(sd, "ln_final", x)                                       # :750
+
+
+def encode_text(sd, cfg, text, mode="global", visual_emb=None):
+    """int64 [B,77] -> (global [B,D], seq [B,77,D]) or seq (call sites run/test/test_fiq.py:102-103)."""
+    if visual_emb is not None and (visual_emb.dim() != 3 or visual_emb.shape[1] != text.shape[0]):
+        raise ValueError("visual_emb must be [patch_num, B, D]")
+    seq = text_hidden(sd, cfg, text) @ sd["text_projection"]            # :978,1027 (bias-free)
+    if mode == "seq":
+        return seq
+    pooled = seq[torch.arange(text.shape[0]), text.argmax(dim=-1)]      # :755-758 (EOT = largest id)
+    return pooled, seq

@@ -1,0 +1,137 @@
+"""Oracle: the fusion arithmetic of the reference, restated functionally (torch CPU fp32).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Every function cites the reference lines it
+follows.  Weights come in as a dict keyed by the reference's ``ERN.state_dict()`` names.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+PATCH_NUM = 13
+BERT_HEADS = 8
+MHA_HEADS = 8
+
+
+def as_torch(sd: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
+    return {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)
+            for k, v in sd.items()}
+
+
+def _lin(sd, prefix, x):
+    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+def _ln(sd, prefix, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def combiner_simple(sd, prefix, image_features, text_features):
+    """CombinerSimple.forward -- /root/reference/models/fusion_model.py:86-94 (eval: dropouts off)."""
+    tp = F.relu(_lin(sd, prefix + ".text_projection_layer.0", text_features))
+    ip = F.relu(_lin(sd, prefix + ".image_projection_layer.0", image_features))
+    raw = torch.cat((tp, ip), dim=-1)                       # :90 text first, image second
+    h = F.relu(_lin(sd, prefix + ".dynamic_scalar.0", raw))
+    s = torch.sigmoid(_lin(sd, prefix + ".dynamic_scalar.3", h))
+    out = s * text_features + (1 - s) * image_features      # :93
+    return F.normalize(out, dim=-1)                         # :94 (eps 1e-12 clamp)
+
+
+def _bn_eval(sd, prefix, x, channel_dim):
+    """BatchNorm1d in eval mode; channel axis = 1 for 3-D input, = last for 2-D (torch semantics)."""
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    shape = [1] * x.dim()
+    shape[channel_dim] = -1
+    return (x - rm.view(shape)) / torch.sqrt(rv.view(shape) + 1e-5) * w.view(shape) + b.view(shape)
+
+
+def visual_sr(sd, prefix, local):
+    """VisualSR.forward -- fusion_model.py:141-154; BatchNorm1d(13) normalises over the *patch* axis."""
+    assert local.shape[1] == PATCH_NUM
+    raw_global = local.mean(dim=1)                                                   # :142
+    l_emb = torch.tanh(_bn_eval(sd, prefix + ".embedding_local.1",
+                                _lin(sd, prefix + ".embedding_local.0", local), 1))  # :145 (:117-123)
+    g_emb = torch.tanh(_bn_eval(sd, prefix + ".embedding_global.1",
+                                _lin(sd, prefix + ".embedding_global.0", raw_global), 1))
+    common = l_emb * g_emb.unsqueeze(1)                                              # :149
+    logits = _lin(sd, prefix + ".embedding_common", common).squeeze(2)
+    w = torch.softmax(logits, dim=1)                                                 # :150
+    new_global = (w.unsqueeze(2) * local).sum(dim=1)                                 # :153
+    norm = torch.sqrt((new_global ** 2).sum(dim=-1, keepdim=True)) + 1e-8            # :136-139
+    return new_global / norm
+
+
+def bert_encode(sd, prefix, x0, n_type0):
+    """HF BertModel(inputs_embeds=x0, token_type_ids=[0]*n_type0+[1]*rest, mask=1) -> last_hidden_state.
+
+    Call site fusion_model.py:199-212; config fusion_model.py:162-170 (post-LN, eps 1e-12,
+    GELU(erf), absolute positions, intermediate 3072, 8 heads).  The arithmetic itself lives in
+    third-party ``transformers`` (pinned 4.30.2, environment.yml:156).
+    """
+    b, s, d = x0.shape
+    hd = d // BERT_HEADS
+    tok = torch.cat((torch.zeros(n_type0, dtype=torch.long), torch.ones(s - n_type0, dtype=torch.long)))
+    x = x0 + sd[prefix + ".embeddings.token_type_embeddings.weight"][tok]
+    x = x + sd[prefix + ".embeddings.position_embeddings.weight"][:s]
+    x = _ln(sd, prefix + ".embeddings.LayerNorm", x, 1e-12)
+    layer = 0
+    while f"{prefix}.encoder.layer.{layer}.attention.self.query.weight" in sd:
+        lp = f"{prefix}.encoder.layer.{layer}"
+        q = _lin(sd, lp + ".attention.self.query", x).view(b, s, BERT_HEADS, hd).transpose(1, 2)
+        k = _lin(sd, lp + ".attention.self.key", x).view(b, s, BERT_HEADS, hd).transpose(1, 2)
+        v = _lin(sd, lp + ".attention.self.value", x).view(b, s, BERT_HEADS, hd).transpose(1, 2)
+        p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1)
+        ctx = (p @ v).transpose(1, 2).reshape(b, s, d)
+        x = _ln(sd, lp + ".attention.output.LayerNorm", _lin(sd, lp + ".attention.output.dense", ctx) + x, 1e-12)
+        h = F.gelu(_lin(sd, lp + ".intermediate.dense", x))
+        x = _ln(sd, lp + ".output.LayerNorm", _lin(sd, lp + ".output.dense", h) + x, 1e-12)
+        layer += 1
+    return x
+
+
+def mha_forward(sd, prefix, query, key, value, heads=MHA_HEADS):
+    """nn.MultiheadAttention(batch_first=True) eval forward -- constructed fusion_model.py:18-20."""
+    d = query.shape[-1]
+    hd = d // heads
+    w, bias = sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"]
+    q = F.linear(query, w[:d], bias[:d])
+    k = F.linear(key, w[d:2 * d], bias[d:2 * d])
+    v = F.linear(value, w[2 * d:], bias[2 * d:])
+    b, sq, _ = q.shape
+    sk = k.shape[1]
+    q = q.view(b, sq, heads, hd).transpose(1, 2) * (1.0 / math.sqrt(hd))
+    k = k.view(b, sk, heads, hd).transpose(1, 2)
+    v = v.view(b, sk, heads, hd).transpose(1, 2)
+    p = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(b, sq, d)
+    return _lin(sd, prefix + ".out_proj", o)
+
+
+def dvr_fuse(sd, ref_patch, text_seq, ref_global, text_global, prefix="DVR"):
+    """DVR_module.forward -- fusion_model.py:26-55 (= ERN mode="test", models/model.py:68-69)."""
+    b, p, d = ref_patch.shape
+    tl = prefix + ".transformer_layer"
+    cls = sd.get(tl + ".cls_token")                  # absent in GPU-trained checkpoints -> zeros
+    if cls is None:
+        cls = torch.zeros(1, 1, d)
+    x0 = torch.cat((cls.expand(b, -1, -1), ref_patch, text_seq), dim=1)             # :199-201
+    hidden = bert_encode(sd, tl + ".bert_encoder.bert_model", x0, p + 1)            # :202-212
+    img = F.normalize(hidden[:, 1:p + 1], dim=2)                                    # :38,40
+    txt = F.normalize(hidden[:, p + 1:], dim=2)                                     # :39,41
+    cross = mha_forward(sd, prefix + ".MR_component", txt, img, img)[:, :p]         # :44-47
+    patch_vision_mean = visual_sr(sd, prefix + ".SR_module", cross)                 # :48
+    seq_text_mean = txt.mean(dim=1)                                                 # :49
+    g = combiner_simple(sd, prefix + ".combiner_global", ref_global, text_global)   # :52
+    l = combiner_simple(sd, prefix + ".combiner_local", patch_vision_mean, seq_text_mean)  # :53
+    return combiner_simple(sd, prefix + ".combiner", g, l)                          # :54
+
+
+def index_fuse(sd, tar_feats, tar_local):
+    """ERN mode="index" -- models/model.py:64-66 (caller normalises tar_feats first, test_fiq.py:45)."""
+    sr = visual_sr(sd, "SR_module", tar_local)
+    return combiner_simple(sd, "Combiner_module", tar_feats, sr)

@@ -1,0 +1,158 @@
+"""Model-level parity through the C ABI: fusion (ERN mode="test"/"index", CombinerSimple, VisualSR) and the
+CLIP towers against the CPU oracle on the same seeded weights and inputs.  Tolerances are absolute on
+unit-norm (fusion) or O(1) (CLIP) features; north_star asks for cosine scores within 1e-3."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fashionern_aaai2024_amd import synth
+from fashionern_aaai2024_amd.engine import (COMBINER_DVR_FINAL, COMBINER_DVR_GLOBAL, COMBINER_DVR_LOCAL, COMBINER_TARGET,
+                                             SR_DVR, SR_TARGET, FernEngine)
+from oracle import clip as oclip
+from oracle import fusion as ofusion
+
+pytestmark = pytest.mark.gpu
+
+FUSION_TOL = 2e-5
+_engines = {}
+
+
+def fusion_engine(d):
+    if d not in _engines:
+        eng = FernEngine("cuda:0")
+        sd = synth.fusion_state_dict(d, seed=11)
+        eng.load_tensors(sd)
+        eng.finalize_fusion(d)
+        _engines[d] = (eng, ofusion.as_torch(sd))
+    return _engines[d]
+
+
+def _t(a):
+    return torch.from_numpy(a)
+
+
+def _maxerr(got, ref):
+    return (got.detach().cpu().double() - ref.double()).abs().max().item()
+
+
+@pytest.mark.parametrize("d", [128, 512, 640])
+def test_combiner_and_sr(d):
+    eng, sd = fusion_engine(d)
+    n = 70
+    img, txt = _t(synth.global_feats(n, d, tag="ci")), _t(synth.global_feats(n, d, tag="ct"))
+    for which, prefix in ((COMBINER_TARGET, "Combiner_module"), (COMBINER_DVR_GLOBAL, "DVR.combiner_global"),
+                          (COMBINER_DVR_LOCAL, "DVR.combiner_local"), (COMBINER_DVR_FINAL, "DVR.combiner")):
+        ref = ofusion.combiner_simple(sd, prefix, img, txt)
+        assert _maxerr(eng.combiner(which, img, txt), ref) < FUSION_TOL
+    loc = _t(synth.local_feats(n, d, tag="sl"))
+    for which, prefix in ((SR_TARGET, "SR_module"), (SR_DVR, "DVR.SR_module")):
+        assert _maxerr(eng.visual_sr(which, loc), ofusion.visual_sr(sd, prefix, loc)) < FUSION_TOL
+
+
+@pytest.mark.parametrize("d,n", [(128, 1), (128, 300), (512, 129), (640, 65)])
+def test_index_fuse(d, n):
+    eng, sd = fusion_engine(d)
+    raw, loc = _t(synth.global_feats(n, d, tag="ir")), _t(synth.local_feats(n, d, tag="il"))
+    ref = ofusion.index_fuse(sd, F.normalize(raw, dim=-1), loc)
+    assert _maxerr(eng.index_fuse(raw, loc, normalize_input=True), ref) < FUSION_TOL
+    assert _maxerr(eng.index_fuse(F.normalize(raw, dim=-1), loc), ref) < FUSION_TOL
+
+
+def test_index_fuse_tiles_large_gallery():
+    """More rows than one internal tile (8192): results must not depend on the tiling."""
+    d, n = 128, 8192 + 777
+    eng, sd = fusion_engine(d)
+    raw, loc = _t(synth.global_feats(n, d, tag="big")), _t(synth.local_feats(n, d, tag="bigl"))
+    got = eng.index_fuse(raw, loc, normalize_input=True).cpu()
+    sel = torch.cat((torch.arange(0, 64), torch.arange(8160, 8260), torch.arange(n - 50, n)))
+    ref = ofusion.index_fuse(sd, F.normalize(raw[sel], dim=-1), loc[sel])
+    assert _maxerr(got[sel], ref) < FUSION_TOL
+    small = eng.index_fuse(raw[8192:], loc[8192:], normalize_input=True).cpu()
+    assert torch.equal(small, got[8192:])
+
+
+@pytest.mark.parametrize("d,b,t", [(128, 5, 77), (128, 1, 77), (512, 9, 77), (640, 6, 77), (128, 3, 40)])
+def test_dvr_fuse(d, b, t):
+    eng, sd = fusion_engine(d)
+    rg, rl = _t(synth.global_feats(b, d, tag="rg")), _t(synth.local_feats(b, d, tag="rl"))
+    tg = _t(synth.global_feats(b, d, tag="tg"))
+    ts = _t(synth._normal(42, f"tseq/{d}", (b, t, d)))
+    ref = ofusion.dvr_fuse(sd, rl, ts, rg, tg)
+    got = eng.dvr_fuse(rg, rl, tg, ts)
+    assert _maxerr(got, ref) < 5e-5
+    assert abs(got.norm(dim=1).cpu() - 1).max().item() < 1e-5
+
+
+def test_dvr_fuse_without_cls_token():
+    """GPU-trained checkpoints lack DVR.transformer_layer.cls_token (fusion_model.py:185): it defaults to zeros."""
+    d = 128
+    sd_np = synth.fusion_state_dict(d, seed=12, with_cls_token=False)
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(sd_np)
+    eng.finalize_fusion(d)
+    sd = ofusion.as_torch(sd_np)
+    b = 4
+    rg, rl = _t(synth.global_feats(b, d, tag="rg")), _t(synth.local_feats(b, d, tag="rl"))
+    tg, ts = _t(synth.global_feats(b, d, tag="tg")), _t(synth._normal(42, "tseq", (b, 77, d)))
+    assert _maxerr(eng.dvr_fuse(rg, rl, tg, ts), ofusion.dvr_fuse(sd, rl, ts, rg, tg)) < 5e-5
+    eng.close()
+
+
+def test_missing_weight_fails_loudly():
+    from fashionern_aaai2024_amd._lib import FernError
+    eng = FernEngine("cuda:0")
+    sd = synth.fusion_state_dict(128, seed=1)
+    del sd["SR_module.embedding_common.weight"]
+    eng.load_tensors(sd)
+    with pytest.raises(FernError, match="missing weight"):
+        eng.finalize_fusion(128)
+    with pytest.raises(FernError, match="not finalised"):
+        eng.lib  # noqa
+        eng.feature_dim = 128
+        eng.index_fuse(torch.zeros(2, 128), torch.zeros(2, 13, 128))
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny-hd64"])
+def test_clip_towers_tiny(name):
+    cfg = synth.CLIP_CONFIGS[name]
+    sd_np = synth.clip_state_dict(cfg, seed=5)
+    sd = ofusion.as_torch(sd_np)
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(sd_np)
+    eng.finalize_clip(cfg)
+    imgs = _t(synth.images(5, cfg))
+    ref = oclip.encode_image(sd, cfg, imgs)
+    got = eng.encode_image(imgs)
+    assert _maxerr(got, ref) < 2e-4 * max(1.0, ref.abs().max().item())
+    for full in (True, False):
+        toks = _t(synth.captions(6, cfg, full_length=full))
+        rg, rs = oclip.encode_text(sd, cfg, toks)
+        g, s = eng.encode_text(toks)
+        scale = max(1.0, rs.abs().max().item())
+        assert _maxerr(s, rs) < 2e-4 * scale and _maxerr(g, rg) < 2e-4 * scale
+        g2, _ = eng.encode_text(toks, want_seq=False)
+        assert _maxerr(g2, rg) < 2e-4 * scale
+    eng.close()
+
+
+def test_clip_vit_b16_full_size():
+    """The real ViT-B/16 shape (197 tokens, 12 x 64 heads, 12 layers) on 3 images / captions."""
+    cfg = synth.CLIP_CONFIGS["ViT-B-16"]
+    sd_np = synth.clip_state_dict(cfg, seed=6)
+    sd = ofusion.as_torch(sd_np)
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(sd_np)
+    eng.finalize_clip(cfg)
+    imgs = _t(synth.images(3, cfg))
+    ref = oclip.encode_image(sd, cfg, imgs)
+    got = eng.encode_image(imgs)
+    cos = F.cosine_similarity(got.cpu(), ref, dim=-1)
+    assert _maxerr(got, ref) < 1e-3 * max(1.0, ref.abs().max().item()) and (1 - cos).abs().max().item() < 1e-5
+    toks = _t(synth.captions(3, cfg))
+    rg, rs = oclip.encode_text(sd, cfg, toks)
+    g, s = eng.encode_text(toks)
+    assert _maxerr(s, rs) < 1e-3 * max(1.0, rs.abs().max().item())
+    assert (1 - F.cosine_similarity(g.cpu(), rg, dim=-1)).abs().max().item() < 1e-5
+    eng.close()
