@@ -228,9 +228,10 @@ class FernEngine:
         x = self._f32(x)
         rows, d = x.shape
         residual = None if residual is None else self._f32(residual, (rows, d))
+        gamma, beta = self._f32(gamma, (d,)), self._f32(beta, (d,))   # keep alive until the launch is queued
         out = torch.empty_like(x)
-        _lib.check(self.lib.fern_layernorm(self._h, _ptr(x), _ptr(residual), _ptr(self._f32(gamma, (d,))),
-                                           _ptr(self._f32(beta, (d,))), _ptr(out), rows, d, float(eps), _stream()), "fern_layernorm")
+        _lib.check(self.lib.fern_layernorm(self._h, _ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta), _ptr(out), rows, d,
+                                           float(eps), _stream()), "fern_layernorm")
         return out
 
     def attention(self, q, k, v, heads: int, causal=False, scale=None) -> torch.Tensor:
