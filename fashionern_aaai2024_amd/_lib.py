@@ -31,7 +31,7 @@ SIGNATURES = {
     "fern_ctx_destroy": (c_int, [c_void_p]),
     "fern_sync": (c_int, [c_void_p, c_void_p]),
     "fern_load_tensor": (c_int, [c_void_p, C.c_char_p, c_void_p, c_int, c_int, C.POINTER(c_i64)]),
-    "fern_finalize_fusion": (c_int, [c_void_p, c_int]),
+    "fern_finalize_fusion": (c_int, [c_void_p, c_int, c_int]),
     "fern_finalize_clip": (c_int, [c_void_p, C.POINTER(ClipConfigC)]),
     "fern_vit_encode_image": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fern_text_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

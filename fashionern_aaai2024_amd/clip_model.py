@@ -1,0 +1,128 @@
+"""CLIP encoder object and the ImageCLIP / TextCLIP wrappers, behind the reference's call surface.
+
+Reference interface: the external ``clip_model`` object the reference builds with
+``open_clip.create_model_and_transforms`` (/root/reference/run/test/test_fiq.py:141-146) and calls as
+``clip_model.encode_image(images)`` (/root/reference/utils/utils.py:64) and
+``clip_model.encode_text(text, mode=, visual_emb=)`` (/root/reference/run/test/test_fiq.py:102-103), plus the
+two thin wrappers of /root/reference/models/clip_model.py:5-31.
+
+``encode_text`` semantics are *defined* here because the reference's private text encoder is unreleased
+(SURVEY.md 8c): one text-tower pass; ``seq = ln_final(h) @ text_projection``; ``global = seq[EOT]``;
+default/"global" returns ``(global, seq)``; "seq" returns ``seq``; ``visual_emb`` [13,B,D] is shape-checked
+and ignored ("vanilla CLIP single branch", README.md:41).
+"""
+from __future__ import annotations
+
+from typing import Dict, Mapping, Optional, Union
+
+import numpy as np
+import torch
+
+from . import synth
+from .engine import PATCH_NUM, FernEngine
+from .synth import CLIP_CONFIGS, ClipConfig
+
+
+class FernCLIP:
+    """CLIP ViT image tower + text tower running as HIP kernels on one MI355X."""
+
+    def __init__(self, model_name: Union[str, ClipConfig] = "ViT-B-16", device="cuda:0", engine=None):
+        cfg = model_name if isinstance(model_name, ClipConfig) else CLIP_CONFIGS.get(model_name)
+        if cfg is None:
+            raise ValueError(f"unknown CLIP model {model_name!r}; known: {sorted(CLIP_CONFIGS)}")
+        self.cfg = cfg
+        self.engine = engine if engine is not None else FernEngine(device)
+        self.device = self.engine.device
+        self._state: Dict[str, np.ndarray] = {}
+        self._ready = False
+        self._text_cache = None
+
+    # -- nn.Module-like surface used by the reference scripts (test_fiq.py:142-145) ---------------
+    def load_state_dict(self, state_dict: Mapping[str, object], strict: bool = True):
+        sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in state_dict.items()}
+        self.engine.load_tensors(sd)
+        self.engine.finalize_clip(self.cfg)      # raises FernError naming the first missing/mis-shaped key
+        self._state = sd
+        self._ready = True
+        self._text_cache = None
+        return self
+
+    def init_random(self, seed: int = 0):
+        return self.load_state_dict(synth.clip_state_dict(self.cfg, seed))
+
+    def state_dict(self):
+        return {k: torch.from_numpy(np.array(v)) for k, v in self._state.items()}
+
+    def eval(self):
+        return self
+
+    def float(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    # -- encoders --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_image(self, images: torch.Tensor) -> torch.Tensor:
+        """[b,3,S,S] f32 -> [b,embed_dim] un-normalised (utils/utils.py:64)."""
+        return self.engine.encode_image(images)
+
+    @torch.no_grad()
+    def encode_text(self, text: torch.Tensor, mode: str = "global", visual_emb: Optional[torch.Tensor] = None):
+        if visual_emb is not None:
+            ve = tuple(visual_emb.shape)
+            if len(ve) != 3 or ve[0] != PATCH_NUM or ve[1] != text.shape[0] or ve[2] != self.cfg.embed_dim:
+                raise ValueError(f"visual_emb must be [{PATCH_NUM}, B, {self.cfg.embed_dim}], got {ve}")
+        t = text.to(device=self.device, dtype=torch.int64)
+        # the reference calls encode_text twice on the same tokens (global, then seq: test_fiq.py:102-103);
+        # one tower pass serves both
+        c = self._text_cache
+        if c is not None and c[0].shape == t.shape and torch.equal(c[0], t):
+            g, s = c[1], c[2]
+        else:
+            g, s = self.engine.encode_text(t)
+            self._text_cache = (t.clone(), g, s)
+        return s if mode == "seq" else (g, s)
+
+
+def create_model(model_name="ViT-B-16", device="cuda:0", seed: Optional[int] = None, engine=None) -> FernCLIP:
+    """Counterpart of ``open_clip.create_model_and_transforms(name, device=)`` (test_fiq.py:141): random-init when
+    ``seed`` is given, otherwise weights must follow through ``load_state_dict(saved["CLIP"])``."""
+    m = FernCLIP(model_name, device, engine=engine)
+    if seed is not None:
+        m.init_random(seed)
+    return m
+
+
+class ImageCLIP:
+    """models/clip_model.py:5-15."""
+
+    def __init__(self, clip_model):
+        self.clip_model = clip_model
+
+    def __call__(self, images, mode="eval"):
+        self.clip_model.eval()
+        with torch.no_grad():
+            return self.clip_model.encode_image(images)
+
+    forward = __call__
+
+
+class TextCLIP:
+    """models/clip_model.py:18-31."""
+
+    def __init__(self, clip_model):
+        self.clip_model = clip_model
+
+    def __call__(self, text, mode="global", visual_emb=None):
+        self.clip_model.eval()
+        with torch.no_grad():
+            if mode == "seq":
+                return self.clip_model.encode_text(text, mode="seq", visual_emb=visual_emb)
+            return self.clip_model.encode_text(text, visual_emb=visual_emb)
+
+    forward = __call__

@@ -57,7 +57,7 @@ struct SRW {
 };
 struct BertLayerW { LinearW qkv, attn_out, inter, out; LNW ln1, ln2; };
 struct FusionW {
-    bool ready = false;
+    int parts = 0;      // FERN_PART_* bits that are finalised
     int D = 0;
     const float *cls = nullptr, *pos = nullptr, *type = nullptr;
     LNW emb_ln;
@@ -264,10 +264,17 @@ static int up_sr(fern_ctx* c, const std::string& p, int D, SRW* W) {
     return up_key(c, p + ".embedding_common.bias", {1}, &W->bc);
 }
 static int up_combiner(fern_ctx* c, const std::string& p, int D, CombinerW* W) {
-    FERN_TRY(up_linear(c, p + ".text_projection_layer.0", 4 * D, D, &W->text));
-    FERN_TRY(up_linear(c, p + ".image_projection_layer.0", 4 * D, D, &W->image));
-    FERN_TRY(up_linear(c, p + ".dynamic_scalar.0", 8 * D, 8 * D, &W->hidden));
-    FERN_TRY(up_key(c, p + ".dynamic_scalar.3.weight", {1, 8 * D}, &W->w2));
+    // CombinerSimple(clip_feature_dim=D, projection_dim=Pj, hidden_dim=Hd) (fusion_model.py:63-84); ERN uses Pj=4D, Hd=8D
+    const HostTensor *tp, *hw;
+    FERN_TRY(need(c, p + ".text_projection_layer.0.weight", {}, &tp));
+    FERN_TRY(need(c, p + ".dynamic_scalar.0.weight", {}, &hw));
+    if (tp->shape.size() != 2 || hw->shape.size() != 2) return fail(FERN_ERR_STATE, "combiner weights must be 2-D: " + p);
+    const int Pj = (int)tp->shape[0], Hd = (int)hw->shape[0];
+    if (Pj % 4 || (2 * Pj) % 32 || Hd <= 0) return fail(FERN_ERR_ARG, "combiner: projection_dim must be a multiple of 16: " + p);
+    FERN_TRY(up_linear(c, p + ".text_projection_layer.0", Pj, D, &W->text));
+    FERN_TRY(up_linear(c, p + ".image_projection_layer.0", Pj, D, &W->image));
+    FERN_TRY(up_linear(c, p + ".dynamic_scalar.0", Hd, 2 * Pj, &W->hidden));
+    FERN_TRY(up_key(c, p + ".dynamic_scalar.3.weight", {1, Hd}, &W->w2));
     return up_key(c, p + ".dynamic_scalar.3.bias", {1}, &W->b2);
 }
 
@@ -324,54 +331,67 @@ extern "C" int fern_load_tensor(fern_ctx* c, const char* key, const void* host_p
     return FERN_OK;
 }
 
-extern "C" int fern_finalize_fusion(fern_ctx* c, int D) {
+extern "C" int fern_finalize_fusion(fern_ctx* c, int D, int parts) {
     if (!c) return fail(FERN_ERR_ARG, "fern_finalize_fusion: ctx is NULL");
     if (D <= 0 || D % 32 || D > 768) return fail(FERN_ERR_ARG, "fern_finalize_fusion: feature_dim must be a multiple of 32, <= 768");
+    if (parts <= 0 || (parts & ~FERN_PART_ALL)) return fail(FERN_ERR_ARG, "fern_finalize_fusion: bad parts mask");
     HIP_TRY(hipSetDevice(c->device));
     FusionW& F = c->fusion;
-    F = FusionW();
+    if (F.parts && F.D != D) return fail(FERN_ERR_ARG, "fern_finalize_fusion: feature_dim differs from the already finalised parts");
     F.D = D;
-    const std::string tl = "DVR.transformer_layer";
-    const std::string bm = tl + ".bert_encoder.bert_model";
-    if (c->host.count(tl + ".cls_token")) FERN_TRY(up_key(c, tl + ".cls_token", {1, 1, D}, &F.cls));
-    else {   // absent in GPU-trained checkpoints: `nn.Parameter(...).to(device)` is not registered (fusion_model.py:185)
-        std::vector<float> z(D, 0.f);
-        FERN_TRY(upload(c, z.data(), D, &F.cls));
+    if (parts & FERN_PART_DVR) {
+        F.parts &= ~FERN_PART_DVR;
+        const std::string tl = "DVR.transformer_layer";
+        const std::string bm = tl + ".bert_encoder.bert_model";
+        if (c->host.count(tl + ".cls_token")) FERN_TRY(up_key(c, tl + ".cls_token", {1, 1, D}, &F.cls));
+        else {   // absent in GPU-trained checkpoints: `nn.Parameter(...).to(device)` is not registered (fusion_model.py:185)
+            std::vector<float> z(D, 0.f);
+            FERN_TRY(upload(c, z.data(), D, &F.cls));
+        }
+        const HostTensor* pos;
+        FERN_TRY(need(c, bm + ".embeddings.position_embeddings.weight", {}, &pos));
+        if (pos->shape.size() != 2 || pos->shape[1] != D || pos->shape[0] < 96) return fail(FERN_ERR_STATE, "position_embeddings has the wrong shape");
+        FERN_TRY(upload(c, pos->f.data(), pos->f.size(), &F.pos));
+        FERN_TRY(up_key(c, bm + ".embeddings.token_type_embeddings.weight", {2, D}, &F.type));
+        FERN_TRY(up_ln(c, bm + ".embeddings.LayerNorm", D, &F.emb_ln));
+        for (int i = 0; i < 2; ++i) {
+            const std::string lp = bm + ".encoder.layer." + std::to_string(i);
+            BertLayerW& L = F.layer[i];
+            FERN_TRY(up_packed(c, {lp + ".attention.self.query", lp + ".attention.self.key", lp + ".attention.self.value"}, D, D, &L.qkv));
+            FERN_TRY(up_linear(c, lp + ".attention.output.dense", D, D, &L.attn_out));
+            FERN_TRY(up_ln(c, lp + ".attention.output.LayerNorm", D, &L.ln1));
+            const HostTensor* iw;
+            FERN_TRY(need(c, lp + ".intermediate.dense.weight", {}, &iw));
+            const int inter = (int)iw->shape[0];
+            if (inter % 32) return fail(FERN_ERR_ARG, "BERT intermediate size must be a multiple of 32");
+            FERN_TRY(up_linear(c, lp + ".intermediate.dense", inter, D, &L.inter));
+            FERN_TRY(up_linear(c, lp + ".output.dense", D, inter, &L.out));
+            FERN_TRY(up_ln(c, lp + ".output.LayerNorm", D, &L.ln2));
+        }
+        {   // nn.MultiheadAttention packed in-proj: rows [0,D) = q, [D,3D) = k,v
+            const float *w, *b;
+            FERN_TRY(up_key(c, "DVR.MR_component.in_proj_weight", {3 * D, D}, &w));
+            FERN_TRY(up_key(c, "DVR.MR_component.in_proj_bias", {3 * D}, &b));
+            F.mha_q = {w, b, D, D};
+            F.mha_kv = {w + (size_t)D * D, b + D, 2 * D, D};
+            FERN_TRY(up_linear(c, "DVR.MR_component.out_proj", D, D, &F.mha_out));
+        }
+        FERN_TRY(up_sr(c, "DVR.SR_module", D, &F.sr[FERN_SR_DVR]));
+        FERN_TRY(up_combiner(c, "DVR.combiner_global", D, &F.comb[FERN_COMBINER_DVR_GLOBAL]));
+        FERN_TRY(up_combiner(c, "DVR.combiner_local", D, &F.comb[FERN_COMBINER_DVR_LOCAL]));
+        FERN_TRY(up_combiner(c, "DVR.combiner", D, &F.comb[FERN_COMBINER_DVR_FINAL]));
+        F.parts |= FERN_PART_DVR;
     }
-    const HostTensor* pos;
-    FERN_TRY(need(c, bm + ".embeddings.position_embeddings.weight", {}, &pos));
-    if (pos->shape.size() != 2 || pos->shape[1] != D) return fail(FERN_ERR_STATE, "position_embeddings has the wrong width");
-    FERN_TRY(upload(c, pos->f.data(), pos->f.size(), &F.pos));
-    FERN_TRY(up_key(c, bm + ".embeddings.token_type_embeddings.weight", {2, D}, &F.type));
-    FERN_TRY(up_ln(c, bm + ".embeddings.LayerNorm", D, &F.emb_ln));
-    for (int i = 0; i < 2; ++i) {
-        const std::string lp = bm + ".encoder.layer." + std::to_string(i);
-        BertLayerW& L = F.layer[i];
-        FERN_TRY(up_packed(c, {lp + ".attention.self.query", lp + ".attention.self.key", lp + ".attention.self.value"}, D, D, &L.qkv));
-        FERN_TRY(up_linear(c, lp + ".attention.output.dense", D, D, &L.attn_out));
-        FERN_TRY(up_ln(c, lp + ".attention.output.LayerNorm", D, &L.ln1));
-        const HostTensor* iw;
-        FERN_TRY(need(c, lp + ".intermediate.dense.weight", {}, &iw));
-        const int inter = (int)iw->shape[0];
-        FERN_TRY(up_linear(c, lp + ".intermediate.dense", inter, D, &L.inter));
-        FERN_TRY(up_linear(c, lp + ".output.dense", D, inter, &L.out));
-        FERN_TRY(up_ln(c, lp + ".output.LayerNorm", D, &L.ln2));
+    if (parts & FERN_PART_TARGET_SR) {
+        F.parts &= ~FERN_PART_TARGET_SR;
+        FERN_TRY(up_sr(c, "SR_module", D, &F.sr[FERN_SR_TARGET]));
+        F.parts |= FERN_PART_TARGET_SR;
     }
-    {   // nn.MultiheadAttention packed in-proj: rows [0,D) = q, [D,3D) = k,v
-        const float *w, *b;
-        FERN_TRY(up_key(c, "DVR.MR_component.in_proj_weight", {3 * D, D}, &w));
-        FERN_TRY(up_key(c, "DVR.MR_component.in_proj_bias", {3 * D}, &b));
-        F.mha_q = {w, b, D, D};
-        F.mha_kv = {w + (size_t)D * D, b + D, 2 * D, D};
-        FERN_TRY(up_linear(c, "DVR.MR_component.out_proj", D, D, &F.mha_out));
+    if (parts & FERN_PART_TARGET_COMBINER) {
+        F.parts &= ~FERN_PART_TARGET_COMBINER;
+        FERN_TRY(up_combiner(c, "Combiner_module", D, &F.comb[FERN_COMBINER_TARGET]));
+        F.parts |= FERN_PART_TARGET_COMBINER;
     }
-    FERN_TRY(up_sr(c, "SR_module", D, &F.sr[FERN_SR_TARGET]));
-    FERN_TRY(up_sr(c, "DVR.SR_module", D, &F.sr[FERN_SR_DVR]));
-    FERN_TRY(up_combiner(c, "Combiner_module", D, &F.comb[FERN_COMBINER_TARGET]));
-    FERN_TRY(up_combiner(c, "DVR.combiner_global", D, &F.comb[FERN_COMBINER_DVR_GLOBAL]));
-    FERN_TRY(up_combiner(c, "DVR.combiner_local", D, &F.comb[FERN_COMBINER_DVR_LOCAL]));
-    FERN_TRY(up_combiner(c, "DVR.combiner", D, &F.comb[FERN_COMBINER_DVR_FINAL]));
-    F.ready = true;
     return FERN_OK;
 }
 
@@ -454,11 +474,11 @@ static int run_visual_sr(fern_ctx* c, const SRW& W, const float* local, float* o
 // epilogue, which reduces it against dynamic_scalar.3.weight on the fly.
 static int run_combiner(fern_ctx* c, const CombinerW& W, const float* image, const float* text, float* out, long n, int D, hipStream_t s) {
     float *cat, *partial;
-    const int H = 8 * D;
+    const int Pj = W.text.out, H = 2 * Pj;      // cat(text_proj, image_proj) width; ERN: 8D
     FERN_TRY(ws_get(c, (size_t)n * H, &cat));
-    FERN_TRY(run_gemm(c, gemm_desc(text, D, W.text, cat, H, (int)n, EPI_BIAS_RELU), s));            // :87,:90 text first
-    FERN_TRY(run_gemm(c, gemm_desc(image, D, W.image, cat + 4 * D, H, (int)n, EPI_BIAS_RELU), s));  // :88
-    const int nb = gemm_num_col_blocks((int)n, H);
+    FERN_TRY(run_gemm(c, gemm_desc(text, D, W.text, cat, H, (int)n, EPI_BIAS_RELU), s));          // :87,:90 text first
+    FERN_TRY(run_gemm(c, gemm_desc(image, D, W.image, cat + Pj, H, (int)n, EPI_BIAS_RELU), s));   // :88
+    const int nb = gemm_num_col_blocks((int)n, W.hidden.out);
     FERN_TRY(ws_get(c, (size_t)n * nb, &partial));
     GemmParams ph = gemm_desc(cat, H, W.hidden, nullptr, H, (int)n, EPI_RELU_DOT);
     ph.aux0 = W.w2; ph.partial = partial;
@@ -467,16 +487,17 @@ static int run_combiner(fern_ctx* c, const CombinerW& W, const float* image, con
     return FERN_OK;
 }
 
-static int check_fusion(fern_ctx* c, const char* fn) {
+static int check_fusion(fern_ctx* c, const char* fn, int parts) {
     if (!c) return fail(FERN_ERR_ARG, std::string(fn) + ": ctx is NULL");
-    if (!c->fusion.ready) return fail(FERN_ERR_STATE, std::string(fn) + ": fusion weights not finalised (fern_finalize_fusion)");
+    if ((c->fusion.parts & parts) != parts) return fail(FERN_ERR_STATE, std::string(fn) + ": fusion weights not finalised (fern_finalize_fusion)");
     HIP_TRY(hipSetDevice(c->device));
     return FERN_OK;
 }
 
 extern "C" int fern_combiner(fern_ctx* c, int which, const float* image, const float* text, float* out, int64_t n, void* stream) {
-    FERN_TRY(check_fusion(c, "fern_combiner"));
-    if (which < 0 || which > 3 || n < 0 || (n && (!image || !text || !out))) return fail(FERN_ERR_ARG, "fern_combiner: bad argument");
+    if (which < 0 || which > 3) return fail(FERN_ERR_ARG, "fern_combiner: bad combiner id");
+    FERN_TRY(check_fusion(c, "fern_combiner", which == FERN_COMBINER_TARGET ? FERN_PART_TARGET_COMBINER : FERN_PART_DVR));
+    if ( n < 0 || (n && (!image || !text || !out))) return fail(FERN_ERR_ARG, "fern_combiner: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int D = c->fusion.D;
     const long CH = 8192;
@@ -489,8 +510,9 @@ extern "C" int fern_combiner(fern_ctx* c, int which, const float* image, const f
 }
 
 extern "C" int fern_visual_sr(fern_ctx* c, int which, const float* local, float* out, int64_t n, void* stream) {
-    FERN_TRY(check_fusion(c, "fern_visual_sr"));
-    if (which < 0 || which > 1 || n < 0 || (n && (!local || !out))) return fail(FERN_ERR_ARG, "fern_visual_sr: bad argument");
+    if (which < 0 || which > 1) return fail(FERN_ERR_ARG, "fern_visual_sr: bad VisualSR id");
+    FERN_TRY(check_fusion(c, "fern_visual_sr", which == FERN_SR_TARGET ? FERN_PART_TARGET_SR : FERN_PART_DVR));
+    if ( n < 0 || (n && (!local || !out))) return fail(FERN_ERR_ARG, "fern_visual_sr: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int D = c->fusion.D;
     const long CH = 8192;
@@ -511,7 +533,7 @@ extern "C" int fern_l2_normalize(fern_ctx* c, const float* x, float* out, int64_
 
 extern "C" int fern_index_fuse(fern_ctx* c, const float* tar_feats, const float* tar_local, float* out, int64_t n, int normalize_input,
                                void* stream) {
-    FERN_TRY(check_fusion(c, "fern_index_fuse"));
+    FERN_TRY(check_fusion(c, "fern_index_fuse", FERN_PART_TARGET_SR | FERN_PART_TARGET_COMBINER));
     if (n < 0 || (n && (!tar_feats || !tar_local || !out))) return fail(FERN_ERR_ARG, "fern_index_fuse: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int D = c->fusion.D;
@@ -596,7 +618,7 @@ static int dvr_chunk(fern_ctx* c, const float* ref_global, const float* ref_loca
 
 extern "C" int fern_dvr_fuse(fern_ctx* c, const float* ref_global, const float* ref_local, const float* text_global, const float* text_seq,
                              float* out, int B, int seq_len, void* stream) {
-    FERN_TRY(check_fusion(c, "fern_dvr_fuse"));
+    FERN_TRY(check_fusion(c, "fern_dvr_fuse", FERN_PART_DVR));
     if (B < 0 || (B && (!ref_global || !ref_local || !text_global || !text_seq || !out))) return fail(FERN_ERR_ARG, "fern_dvr_fuse: bad argument");
     if (seq_len < 1 || 1 + 13 + seq_len > 96) return fail(FERN_ERR_ARG, "fern_dvr_fuse: 1 + 13 + seq_len must be <= 96");
     hipStream_t s = (hipStream_t)stream;

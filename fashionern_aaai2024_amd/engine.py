@@ -19,6 +19,7 @@ from .synth import ClipConfig
 COMBINER_TARGET, COMBINER_DVR_GLOBAL, COMBINER_DVR_LOCAL, COMBINER_DVR_FINAL = 0, 1, 2, 3
 SR_TARGET, SR_DVR = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
+PART_DVR, PART_TARGET_SR, PART_TARGET_COMBINER, PART_ALL = 1, 2, 4, 7
 PATCH_NUM = 13
 
 
@@ -86,8 +87,8 @@ class FernEngine:
             _lib.check(self.lib.fern_load_tensor(self._h, (prefix + key).encode(), arr.ctypes.data_as(C.c_void_p), dt,
                                                  arr.ndim, shape), f"fern_load_tensor({key})")
 
-    def finalize_fusion(self, feature_dim: int) -> None:
-        _lib.check(self.lib.fern_finalize_fusion(self._h, int(feature_dim)), "fern_finalize_fusion")
+    def finalize_fusion(self, feature_dim: int, parts: int = PART_ALL) -> None:
+        _lib.check(self.lib.fern_finalize_fusion(self._h, int(feature_dim), int(parts)), "fern_finalize_fusion")
         self.feature_dim = int(feature_dim)
 
     def finalize_clip(self, cfg: ClipConfig) -> None:

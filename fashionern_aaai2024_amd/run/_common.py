@@ -1,0 +1,151 @@
+"""Shared body of the per-dataset harness modules.
+
+The reference repeats the same ~100 lines per dataset (run/test/test_*.py, run/valid/validate_*.py); the
+arithmetic that matters is identical and lives here once:
+
+* query loop  (test_fiq.py:67-122): caption formatting, tokenise, encode_text x2, RAW reference-feature lookup,
+  ``model(..., mode="test")``;
+* rank step   (test_fiq.py:45-50): normalise gallery -> ``mode="index"`` -> cosine ranking.  The reference
+  materialises ``1 - Q @ G.T`` and fully argsorts it; only ranks < 50 (51 with the CIRR reference removed) and the
+  scores of <= 6 named members are consumed, so this asks the engine for top-K (+ gathered member scores) instead;
+* recall      (test_fiq.py:54-60, test_cirr.py:55-80, test_200k.py:53-60): name compares on the host, percentages
+  computed exactly as the reference does (float32 ``sum / len`` then ``* 100``).
+"""
+from __future__ import annotations
+
+from collections import Counter
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.utils.data import DataLoader
+
+from ..tokenizer import get_tokenizer
+from ..utils import collate_fn
+
+TOPK = 50
+
+
+def _engine_of(model):
+    eng = getattr(model, "engine", None)
+    if eng is None:
+        raise RuntimeError("the ranking step needs model.engine (a FernEngine): no CPU ranking fallback exists")
+    return eng
+
+
+def format_fiq_captions(captions) -> List[str]:
+    """test_fiq.py:93-97: collated [2][B] caption lists -> 'Cap1 and cap2' per item."""
+    flat = np.array(captions).T.flatten().tolist()
+    return [f"{flat[i].strip('.?, ').capitalize()} and {flat[i + 1].strip('.?, ')}" for i in range(0, len(flat), 2)]
+
+
+def generate_predictions(kind: str, clip_model, relative_val_dataset, model, index_names, index_features, device,
+                         feature_dim, batch_size, num_workers, clip_model_name) -> Dict[str, object]:
+    tokenizer = get_tokenizer(clip_model_name)
+    device = torch.device(device)
+    loader = DataLoader(dataset=relative_val_dataset, batch_size=batch_size, num_workers=num_workers,
+                        pin_memory=(device.type == "cuda"), collate_fn=collate_fn, shuffle=False)
+    name_to_row = {n: i for i, n in enumerate(index_names)}      # duplicates: last row wins, like dict(zip(...)) (:88)
+    predicted: List[torch.Tensor] = []
+    target_names: List[str] = []
+    reference_names: List[str] = []
+    group_members: List[List[str]] = []
+    for batch in loader:
+        members = None
+        if kind in ("fiq", "val"):
+            ref_names, batch_targets, captions, ref_patch = batch
+            captions = format_fiq_captions(captions)
+        elif kind == "cirr":
+            ref_names, batch_targets, captions, ref_patch, members = batch
+            members = np.array(members).T.tolist()                                   # test_cirr.py:113
+        elif kind == "shoes":
+            ref_names, batch_targets, captions, ref_patch, _ = batch
+        elif kind == "200k":
+            _, ref_names, captions, batch_targets, _, ref_patch = batch              # test_200k.py:89
+        else:
+            raise ValueError(kind)
+        text_inputs = tokenizer(list(captions), context_length=77)
+        ref_patch = ref_patch.to(device)
+        with torch.no_grad():
+            visual_emb = ref_patch.transpose(0, 1)                                   # [13,B,D]  (:101)
+            text_features, _ = clip_model.encode_text(text_inputs, visual_emb=visual_emb)              # :102
+            text_seq = clip_model.encode_text(text_inputs, mode="seq", visual_emb=visual_emb)          # :103
+            rows = torch.as_tensor([name_to_row[n] for n in ref_names], device=index_features.device)
+            ref_feats = index_features[rows]                                         # RAW gallery features (:104-107)
+            fused = model(ref_feats=ref_feats.to(device), ref_local_feats=ref_patch, text_feats=text_features.to(device),
+                          text_seq_feats=text_seq.to(device), mode="test")           # :112-118
+        predicted.append(fused)
+        target_names.extend(batch_targets)
+        reference_names.extend(ref_names)
+        if members is not None:
+            group_members.extend(members)
+    pred = torch.cat(predicted, dim=0) if predicted else torch.empty((0, feature_dim), device=device)
+    return {"predicted": pred, "targets": target_names, "references": reference_names, "members": group_members}
+
+
+def fuse_index(model, index_features, index_local_features):
+    """test_fiq.py:45-46."""
+    eng = getattr(model, "engine", None)
+    if eng is not None and hasattr(eng, "index_fuse"):
+        return eng.index_fuse(index_features, index_local_features, normalize_input=True)
+    idx = F.normalize(index_features, dim=-1).float()
+    return model(tar_feats=idx, tar_local_feats=index_local_features, mode="index").float()
+
+
+def _pct(count: int, total: int) -> float:
+    return (torch.tensor(int(count)) / total).item() * 100          # float32 tensor, like test_fiq.py:59
+
+
+def _unique_rows(index_names: Sequence[str], wanted: Sequence[str], what: str) -> np.ndarray:
+    counts = Counter(index_names)
+    row = {n: i for i, n in enumerate(index_names)}
+    for n in wanted:
+        # the reference asserts exactly one ground-truth hit per ranking (test_fiq.py:56)
+        assert counts.get(n, 0) == 1, f"{what} {n!r} occurs {counts.get(n, 0)} times in the index (expected exactly once)"
+    return np.array([row[n] for n in wanted], dtype=np.int64)
+
+
+def recalls_unique(model, predicted, index_fused, index_names, target_names, ks):
+    """FashionIQ / Shoes / VAL: R@k = % of queries whose (unique) target is ranked < k."""
+    q = len(target_names)
+    tgt = _unique_rows(index_names, target_names, "target")
+    _, idx = _engine_of(model).sim_topk(predicted, index_fused, max(ks))
+    hit = idx.cpu().numpy() == tgt[:, None]
+    return tuple(_pct(hit[:, :k].sum(), q) for k in ks)
+
+
+def recalls_anyhit(model, predicted, index_fused, index_names, target_names, ks):
+    """Fashion200k: gallery names are caption ids with duplicates; a hit is ANY of the top-k rows (test_200k.py:59-60)."""
+    q = len(target_names)
+    _, idx = _engine_of(model).sim_topk(predicted, index_fused, max(ks))
+    names = np.array(index_names)[idx.cpu().numpy().clip(min=0)]
+    hit = (names == np.array(target_names)[:, None]) & (idx.cpu().numpy() >= 0)
+    return tuple(_pct((hit[:, :k].sum(1) > 0).sum(), q) for k in ks)
+
+
+def recalls_cirr(model, predicted, index_fused, index_names, reference_names, target_names, group_members):
+    """CIRR: reference image removed from each ranking; global R@1/5/10/50 + subset R@1/2/3 (test_cirr.py:55-80)."""
+    q = len(target_names)
+    eng = _engine_of(model)
+    tgt = _unique_rows(index_names, target_names, "target")
+    ref = _unique_rows(index_names, reference_names, "reference")
+    _, idx = eng.sim_topk(predicted, index_fused, TOPK, exclude_idx=torch.as_tensor(ref, dtype=torch.int32))
+    hit = idx.cpu().numpy() == tgt[:, None]
+    glob = tuple(_pct(hit[:, :k].sum(), q) for k in (1, 5, 10, 50))
+    # subset: rank the target among the query's img_set members (reference excluded) by the same scores
+    row = {n: i for i, n in enumerate(index_names)}
+    width = max(len(m) for m in group_members)
+    member_rows = np.full((q, width), -1, dtype=np.int64)
+    for i, mem in enumerate(group_members):
+        rows = [row[m] for m in mem if m in row and m != reference_names[i]]
+        assert rows.count(tgt[i]) == 1, "target must appear exactly once among the group members (test_cirr.py:69)"
+        member_rows[i, :len(rows)] = rows
+    sc = eng.gather_scores(predicted, index_fused, torch.as_tensor(member_rows, dtype=torch.int32)).cpu().numpy().astype(np.float64)
+    ranks = np.empty(q, dtype=np.int64)
+    for i in range(q):
+        rows_i = np.where(member_rows[i] >= 0, member_rows[i], np.iinfo(np.int64).max)
+        order = np.lexsort((rows_i, -sc[i]))                   # score desc, gallery index asc
+        ranks[i] = int(np.where(member_rows[i][order] == tgt[i])[0][0])
+    grp = tuple(_pct((ranks < k).sum(), q) for k in (1, 2, 3))
+    return grp + glob                                          # (G@1,G@2,G@3,R@1,R@5,R@10,R@50) test_cirr.py:80

@@ -54,6 +54,15 @@ typedef enum {
     FERN_COMBINER_DVR_FINAL = 3    /* DVR.combiner             (fusion_model.py:24) */
 } fern_combiner_id;
 
+/* groups of fusion weights that can be finalised independently (a stand-alone CombinerSimple / VisualSR /
+ * DVR_module loads its weights under the ERN prefix of the slot it occupies) */
+typedef enum {
+    FERN_PART_DVR = 1,              /* "DVR.*"              -> fern_dvr_fuse, DVR combiners / SR */
+    FERN_PART_TARGET_SR = 2,        /* "SR_module.*"        -> fern_visual_sr(FERN_SR_TARGET) */
+    FERN_PART_TARGET_COMBINER = 4,  /* "Combiner_module.*"  -> fern_combiner(FERN_COMBINER_TARGET) */
+    FERN_PART_ALL = 7               /* everything ERN owns  -> + fern_index_fuse */
+} fern_fusion_part;
+
 typedef enum {
     FERN_SR_TARGET = 0,            /* ERN.SR_module            (model.py:19) */
     FERN_SR_DVR = 1                /* DVR.SR_module            (fusion_model.py:17) */
@@ -104,7 +113,7 @@ FERN_API int fern_sync(fern_ctx* ctx, void* stream);
 FERN_API int fern_load_tensor(fern_ctx* ctx, const char* key, const void* host_ptr, int dtype, int ndim,
                      const int64_t* shape);
 /* repack for the kernels (packed QKV, folded BatchNorm, transposed projections) and upload */
-FERN_API int fern_finalize_fusion(fern_ctx* ctx, int feature_dim);          /* ERN(clip, feature_dim, device) model.py:8 */
+FERN_API int fern_finalize_fusion(fern_ctx* ctx, int feature_dim, int parts); /* ERN(clip, feature_dim, device) model.py:8; parts = FERN_PART_* mask */
 FERN_API int fern_finalize_clip(fern_ctx* ctx, const fern_clip_config* cfg); /* open_clip.create_model_and_transforms test_fiq.py:141 */
 
 /* encoders ------------------------------------------------------------------------------ */

@@ -1,0 +1,68 @@
+"""TEST-ONLY engine: the FernEngine protocol implemented with the CPU oracle, so host-side logic (ERN dispatch,
+harness, sharding) can be exercised without a GPU.  Lives under tests/ -- the product never imports it."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import clip as oclip
+from oracle import fusion as ofusion
+from oracle import rank as orank
+
+_SLOT = {0: "Combiner_module", 1: "DVR.combiner_global", 2: "DVR.combiner_local", 3: "DVR.combiner"}
+_SR = {0: "SR_module", 1: "DVR.SR_module"}
+
+
+class OracleEngine:
+    def __init__(self, device="cpu"):
+        self.device = torch.device("cpu")
+        self.sd = {}
+        self.feature_dim = None
+        self.clip_cfg = None
+
+    def close(self):
+        pass
+
+    def load_tensors(self, state_dict, prefix=""):
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            self.sd[prefix + k] = torch.from_numpy(np.ascontiguousarray(a))
+
+    def finalize_fusion(self, feature_dim, parts=7):
+        self.feature_dim = int(feature_dim)
+
+    def finalize_clip(self, cfg):
+        self.clip_cfg = cfg
+
+    def encode_image(self, images):
+        return oclip.encode_image(self.sd, self.clip_cfg, images.float().cpu())
+
+    def encode_text(self, tokens, want_global=True, want_seq=True):
+        g, s = oclip.encode_text(self.sd, self.clip_cfg, tokens.cpu())
+        return (g if want_global else None), (s if want_seq else None)
+
+    def dvr_fuse(self, ref_global, ref_local, text_global, text_seq):
+        return ofusion.dvr_fuse(self.sd, ref_local.float().cpu(), text_seq.float().cpu(), ref_global.float().cpu(), text_global.float().cpu())
+
+    def index_fuse(self, tar_feats, tar_local, normalize_input=False):
+        tf = tar_feats.float().cpu()
+        if normalize_input:
+            tf = F.normalize(tf, dim=-1)
+        return ofusion.index_fuse(self.sd, tf, tar_local.float().cpu())
+
+    def combiner(self, which, image, text):
+        return ofusion.combiner_simple(self.sd, _SLOT[which], image.float().cpu(), text.float().cpu())
+
+    def visual_sr(self, which, local):
+        return ofusion.visual_sr(self.sd, _SR[which], local.float().cpu())
+
+    def l2_normalize(self, x):
+        return F.normalize(x.float().cpu(), dim=-1)
+
+    def sim_topk(self, q, gallery, k, idx_offset=0, exclude_idx=None):
+        return orank.cosine_topk(q.float().cpu(), gallery.float().cpu(), k, idx_offset, exclude_idx)
+
+    def gather_scores(self, q, gallery, idx):
+        return orank.gather_scores(q.float().cpu(), gallery.float().cpu(), torch.as_tensor(idx))
+
+    def topk_merge(self, scores, idx):
+        return orank.topk_merge(scores.float().cpu(), torch.as_tensor(idx).cpu())

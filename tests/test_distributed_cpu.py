@@ -1,0 +1,84 @@
+"""CPU, world_size 2 over gloo: the multi-GPU layout (gallery shard + all_gather, query DP, sharded top-K merge)
+is placement-independent and reproduces the single-process ordering exactly.  Compute = TEST-ONLY OracleEngine."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from oracle_engine import OracleEngine
+    from fashionern_aaai2024_amd import distributed as fd
+    from fashionern_aaai2024_amd import synth
+    r, w, _ = fd.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    d = 128
+    eng = OracleEngine()
+    eng.load_tensors(synth.fusion_state_dict(d, seed=3))
+    eng.finalize_fusion(d)
+    raw, loc = torch.from_numpy(synth.global_feats(n, d, tag="g")), torch.from_numpy(synth.local_feats(n, d, tag="gl"))
+    gallery = fd.build_gallery(eng, raw, loc)                                    # shard -> fuse -> all_gather
+    q_all = torch.from_numpy(synth.unit_rows(10, d, tag="q"))
+    q_mine = q_all[rank * 5:(rank + 1) * 5]                                      # query data parallel
+    s, i = fd.rank_replicated(eng, q_mine, gallery, 7)
+    s_all, i_all = fd.gather_rows(s), fd.gather_rows(i)
+    start, stop, _ = fd.shard_rows(n, rank, world)
+    ex = torch.tensor([3, -1, n - 1, 0, 5, -1, 7, 8, 9, 1], dtype=torch.int32)
+    s_sh, i_sh = fd.rank_sharded(eng, q_all, gallery[start:stop], start, 7, exclude_idx=ex)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "r0.npz"), gallery=gallery.numpy(), s=s_all.numpy(), i=i_all.numpy(), s_sh=s_sh.numpy(), i_sh=i_sh.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [101, 64, 1])
+def test_two_rank_layout_matches_single_process(tmp_path, n):
+    sys.path.insert(0, HERE)
+    from oracle_engine import OracleEngine
+    from fashionern_aaai2024_amd import synth
+    from oracle import rank as orank
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "r0.npz")
+    d = 128
+    eng = OracleEngine()
+    eng.load_tensors(synth.fusion_state_dict(d, seed=3))
+    raw, loc = torch.from_numpy(synth.global_feats(n, d, tag="g")), torch.from_numpy(synth.local_feats(n, d, tag="gl"))
+    gallery = eng.index_fuse(raw, loc, normalize_input=True)
+    assert np.abs(got["gallery"] - gallery.numpy()).max() < 1e-6       # CPU BLAS blocking differs with the shard size
+    gallery = torch.from_numpy(got["gallery"])                         # ranking is checked bit-exactly on the gathered gallery
+    q = torch.from_numpy(synth.unit_rows(10, d, tag="q"))
+    s, i = orank.cosine_topk(q, gallery, 7)
+    assert np.array_equal(got["i"], i.numpy()) and np.allclose(got["s"], s.numpy(), atol=1e-6)
+    ex = torch.tensor([3, -1, n - 1, 0, 5, -1, 7, 8, 9, 1], dtype=torch.int32)
+    s2, i2 = orank.cosine_topk(q, gallery, 7, exclude_idx=ex)
+    assert np.array_equal(got["i_sh"], i2.numpy()) and np.allclose(got["s_sh"], s2.numpy(), atol=1e-6)
+
+
+def test_shard_rows_cover_everything_once():
+    from fashionern_aaai2024_amd.distributed import shard_rows
+    for n in (0, 1, 7, 8, 46000, 200001):
+        for w in (1, 2, 3, 8):
+            spans = [shard_rows(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(stop - start <= per for start, stop, per in spans)

@@ -1,0 +1,140 @@
+"""GPU: the drop-in surface end to end on the HIP engine -- ERN / FernCLIP / harness -- against (a) the recall tuples,
+query features and top-50 lists captured from the imported reference harness (tests/golden/harness.*) and (b) the
+oracle-backed run of the same host code."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synthetic_data as sdata
+from oracle_engine import OracleEngine
+
+from fashionern_aaai2024_amd import synth
+from fashionern_aaai2024_amd.clip_model import FernCLIP, create_model
+from fashionern_aaai2024_amd.fusion_model import CombinerSimple, DVR_module, VisualSR
+from fashionern_aaai2024_amd.model import ERN
+from fashionern_aaai2024_amd.run import _common, test_200k, test_cirr, test_fiq, test_shoes, test_val
+from fashionern_aaai2024_amd.tokenizer import register_tokenizer
+from fashionern_aaai2024_amd.utils import extract_index_features
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+META = json.load(open(os.path.join(GOLD, "harness.json")))
+ARR = np.load(os.path.join(GOLD, "harness.npz"))
+register_tokenizer("stub", sdata.stub_tokenizer)
+DEV = "cuda:0"
+
+
+def build(kind, engine=None, device=DEV):
+    d, n, q = META["d"], META["n"], META["q"]
+    clip = sdata.StubCLIP(d).eval().to(device)
+    model = ERN(clip, d, device, engine=engine)
+    model.load_state_dict(synth.fusion_state_dict(d, seed=META["fusion_seed"]))
+    gal = sdata.Gallery(n, d, seed=META["gallery_seed"], dup_names=(kind == "200k"))
+    rel = sdata.RelativeDataset(gal, q, "fiq" if kind == "val" else kind, seed=META["relative_seed"])
+    feats, names, local = extract_index_features(sdata.ClassicDataset(gal), clip, 13, device, d, num_workers=0)
+    return clip, model, rel, feats, names, local, d
+
+
+@pytest.mark.parametrize("kind,fn", [("fiq", test_fiq.compute_fiq_val_metrics), ("cirr", test_cirr.compute_cirr_val_metrics),
+                                     ("200k", test_200k.compute_200k_val_metrics), ("shoes", test_shoes.compute_shoes_val_metrics),
+                                     ("val", test_val.compute_fiq_val_metrics)])
+def test_harness_on_hip_reproduces_reference_recalls(kind, fn):
+    clip, model, rel, feats, names, local, d = build(kind)
+    res = fn(rel, clip, feats, local, names, model, DEV, d, META["batch_size"], 0, "stub")
+    assert list(res) == META["recalls"][kind], (res, META["recalls"][kind])
+
+
+def test_query_features_scores_and_top50_match_reference_run():
+    clip, model, rel, feats, names, local, d = build("fiq")
+    pred, _ = test_fiq.generate_fiq_val_predictions(clip, rel, model, names, feats, DEV, d, META["batch_size"], 0, "stub")
+    assert np.abs(pred.cpu().numpy() - ARR["fiq_predicted"]).max() < 5e-5
+    fused = _common.fuse_index(model, feats, local)
+    assert np.abs(fused.cpu().numpy() - ARR["fiq_index_fused"]).max() < 5e-5
+    scores, idx = model.engine.sim_topk(pred, fused, 50)
+    ref_scores = np.take_along_axis(ARR["fiq_predicted"] @ ARR["fiq_index_fused"].T, ARR["fiq_top50"].astype(np.int64), axis=1)
+    assert np.abs(scores.cpu().numpy() - ref_scores).max() < 1e-3          # north_star: cosine scores within 1e-3
+    same = idx.cpu().numpy() == ARR["fiq_top50"]
+    # identical ordering; a swap is only tolerated between neighbours the reference itself separates by < 1e-5
+    for r, c in zip(*np.nonzero(~same)):
+        full = ARR["fiq_predicted"][r] @ ARR["fiq_index_fused"].T
+        assert abs(full[idx[r, c].item()] - full[ARR["fiq_top50"][r, c]]) < 1e-5
+
+
+def test_full_pipeline_with_hip_clip_matches_oracle_pipeline():
+    """FernCLIP (tiny shape) + ERN + FIQ harness on the GPU vs the same host code on the oracle engine."""
+    cfg = synth.CLIP_CONFIGS["tiny"]
+    d = cfg.embed_dim
+    register_tokenizer("tiny", sdata.stub_tokenizer)
+    r = np.random.default_rng(5)
+    n, q = 300, 40
+    gal = sdata.Gallery(n, d, seed=21, image_size=cfg.image_size)
+    rel = sdata.RelativeDataset(gal, q, "fiq", seed=22)
+    outs = []
+    for engine, device in ((None, DEV), (OracleEngine(), "cpu")):
+        clip = create_model(cfg, device=device, seed=9, engine=engine)
+        model = ERN(clip, d, device, engine=clip.engine).init_random(4)
+        feats, names, local = extract_index_features(sdata.ClassicDataset(gal), clip, 13, device, d, num_workers=0)
+        pred, targets = test_fiq.generate_fiq_val_predictions(clip, rel, model, names, feats, device, d, 16, 0, "tiny")
+        fused = _common.fuse_index(model, feats, local)
+        s, i = model.engine.sim_topk(pred, fused, 50)
+        rec = test_fiq.compute_fiq_val_metrics(rel, clip, feats, local, names, model, device, d, 16, 0, "tiny")
+        outs.append((feats.cpu(), pred.cpu(), fused.cpu(), s.cpu(), i.cpu(), rec))
+    (f0, p0, g0, s0, i0, r0), (f1, p1, g1, s1, i1, r1) = outs
+    assert (f0 - f1).abs().max() < 2e-4 * max(1.0, f1.abs().max().item())
+    assert (p0 - p1).abs().max() < 1e-4 and (g0 - g1).abs().max() < 1e-4
+    assert (s0 - s1).abs().max() < 1e-3 and r0 == r1
+    full = p1 @ g1.T
+    for row, col in zip(*np.nonzero((i0 != i1).numpy())):
+        assert abs(full[row, i0[row, col]].item() - full[row, i1[row, col]].item()) < 1e-4
+
+
+def test_standalone_modules_on_hip():
+    d = 128
+    gold = np.load(os.path.join(GOLD, "fusion.npz"))
+    sub = lambda p: {k[len(p):]: v for k, v in synth.fusion_state_dict(d, seed=11).items() if k.startswith(p)}  # noqa: E731
+    raw, loc = torch.from_numpy(synth.global_feats(6, d, 42, "ir")), torch.from_numpy(synth.local_feats(6, d, 42, "il"))
+    txt = torch.from_numpy(synth.global_feats(4, d, 42, "rg")).repeat(2, 1)[:6]
+    comb = CombinerSimple(d, 4 * d, 8 * d, device=DEV).load_state_dict(sub("Combiner_module."))
+    assert np.abs(comb(raw, txt).cpu().numpy() - gold["d128_combiner_target"]).max() < 2e-5
+    sr = VisualSR(d, device=DEV).load_state_dict(sub("SR_module."))
+    assert np.abs(sr(loc).cpu().numpy() - gold["d128_sr_target"]).max() < 2e-5
+    dvr = DVR_module(d, device=DEV).load_state_dict(sub("DVR."))
+    rl, ts = torch.from_numpy(synth.local_feats(4, d, 42, "rl")), torch.from_numpy(synth._normal(42, f"tseq/{d}", (4, 77, d)))
+    rg, tg = torch.from_numpy(synth.global_feats(4, d, 42, "rg")), torch.from_numpy(synth.global_feats(4, d, 42, "tg"))
+    assert np.abs(dvr(rl, ts, rg, tg).cpu().numpy() - gold["d128_dvr_module"]).max() < 5e-5
+    from fashionern_aaai2024_amd._lib import FernError
+    with pytest.raises(FernError, match="not finalised"):
+        comb.engine.visual_sr(0, loc)          # only the Combiner part was finalised on that context
+
+
+@pytest.mark.parametrize("d", [128, 512, 640])
+def test_ern_matches_reference_goldens(d):
+    gold = np.load(os.path.join(GOLD, "fusion.npz"))
+    model = ERN(None, d, DEV).load_state_dict(synth.fusion_state_dict(d, seed=11))
+    t = lambda a: torch.from_numpy(a)  # noqa: E731
+    rg, rl = t(synth.global_feats(4, d, 42, "rg")), t(synth.local_feats(4, d, 42, "rl"))
+    tg, ts = t(synth.global_feats(4, d, 42, "tg")), t(synth._normal(42, f"tseq/{d}", (4, 77, d)))
+    raw, loc = t(synth.global_feats(6, d, 42, "ir")), t(synth.local_feats(6, d, 42, "il"))
+    out = model(ref_feats=rg, ref_local_feats=rl, text_feats=tg, text_seq_feats=ts, mode="test")
+    assert np.abs(out.cpu().numpy() - gold[f"d{d}_test"]).max() < 5e-5
+    idx = model(tar_feats=torch.nn.functional.normalize(raw, dim=-1), tar_local_feats=loc, mode="index")
+    assert np.abs(idx.cpu().numpy() - gold[f"d{d}_index"]).max() < 2e-5
+
+
+def test_clip_matches_in_tree_reference_statement():
+    gold = np.load(os.path.join(GOLD, "clip.npz"))
+    for name, n_img, n_txt, tol in (("tiny", 5, 6, 2e-4), ("tiny-hd64", 5, 6, 2e-4), ("ViT-B-16", 2, 2, 1e-3)):
+        cfg = synth.CLIP_CONFIGS[name]
+        clip = create_model(cfg, device=DEV, seed=5)
+        img = clip.encode_image(torch.from_numpy(synth.images(n_img, cfg, 42)))
+        assert np.abs(img.cpu().numpy() - gold[f"{name}_image"]).max() < tol
+        for tag, full in (("full", True), ("ragged", False)):
+            toks = torch.from_numpy(synth.captions(n_txt, cfg, 42, full_length=full))
+            g, s = clip.encode_text(toks)
+            assert np.abs(s.cpu().numpy() - gold[f"{name}_text_{tag}_seq"]).max() < tol
+            assert np.abs(g.cpu().numpy() - gold[f"{name}_text_{tag}_global"]).max() < tol
+            assert torch.equal(clip.encode_text(toks, mode="seq"), s)
+        clip.engine.close()

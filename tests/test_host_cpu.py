@@ -1,0 +1,153 @@
+"""CPU: host-side logic of the drop-in surface (ERN dispatch, harness, caption formatting, recall arithmetic)
+against the fixtures captured from the imported reference harness.  The compute engine is the TEST-ONLY
+OracleEngine; on the GPU box tests/test_gpu_harness.py repeats this with the HIP engine."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import synthetic_data as sdata
+from oracle_engine import OracleEngine
+
+from fashionern_aaai2024_amd import synth
+from fashionern_aaai2024_amd.clip_model import FernCLIP, ImageCLIP, TextCLIP
+from fashionern_aaai2024_amd.fusion_model import CombinerSimple, DVR_module, VisualSR
+from fashionern_aaai2024_amd.model import ERN
+from fashionern_aaai2024_amd.run import _common, test_200k, test_cirr, test_fiq, test_shoes, test_val, validate
+from fashionern_aaai2024_amd.tokenizer import get_tokenizer, register_tokenizer
+from fashionern_aaai2024_amd.utils import collate_fn, extract_index_features
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+META = json.load(open(os.path.join(GOLD, "harness.json")))
+ARR = np.load(os.path.join(GOLD, "harness.npz"))
+register_tokenizer("stub", sdata.stub_tokenizer)
+register_tokenizer("RN50x4", sdata.stub_tokenizer)
+
+
+def build(kind):
+    d, n, q = META["d"], META["n"], META["q"]
+    clip = sdata.StubCLIP(d).eval()
+    model = ERN(clip, d, "cpu", engine=OracleEngine())
+    model.load_state_dict(synth.fusion_state_dict(d, seed=META["fusion_seed"]))
+    gal = sdata.Gallery(n, d, seed=META["gallery_seed"], dup_names=(kind == "200k"))
+    rel = sdata.RelativeDataset(gal, q, "fiq" if kind == "val" else kind, seed=META["relative_seed"])
+    feats, names, local = extract_index_features(sdata.ClassicDataset(gal), clip, 13, "cpu", d, num_workers=0)
+    return clip, model, rel, feats, names, local, d
+
+
+@pytest.mark.parametrize("kind,fn", [("fiq", test_fiq.compute_fiq_val_metrics), ("cirr", test_cirr.compute_cirr_val_metrics),
+                                     ("200k", test_200k.compute_200k_val_metrics), ("shoes", test_shoes.compute_shoes_val_metrics),
+                                     ("val", test_val.compute_fiq_val_metrics)])
+def test_harness_reproduces_reference_recalls(kind, fn):
+    clip, model, rel, feats, names, local, d = build(kind)
+    assert np.abs(feats.numpy() - ARR[f"{kind}_index_features"]).max() < 1e-6      # extract_index_features == reference's
+    res = fn(rel, clip, feats, local, names, model, "cpu", d, META["batch_size"], 0, "stub")
+    assert list(res) == META["recalls"][kind], (res, META["recalls"][kind])
+
+
+def test_generate_predictions_match_reference_query_features():
+    clip, model, rel, feats, names, local, d = build("fiq")
+    pred, targets = test_fiq.generate_fiq_val_predictions(clip, rel, model, names, feats, "cpu", d, META["batch_size"], 0, "stub")
+    assert np.abs(pred.numpy() - ARR["fiq_predicted"]).max() < 1e-6
+    assert targets == [it[1] for it in rel.items]
+    fused = _common.fuse_index(model, feats, local)
+    assert np.abs(fused.numpy() - ARR["fiq_index_fused"]).max() < 1e-6
+    _, idx = model.engine.sim_topk(pred, fused, 50)
+    assert np.array_equal(idx.numpy(), ARR["fiq_top50"])
+
+
+def test_validate_entry_points_and_batch_of_one():
+    clip, model, rel, feats, names, local, d = build("fiq")
+    assert list(validate.compute_fiq_val_metrics(rel, clip, feats, local, names, model, "cpu", d)) == META["recalls"]["fiq"]
+    res = test_fiq.compute_fiq_val_metrics(rel, clip, feats, local, names, model, "cpu", d, 1, 0, "stub")   # B == 1 path (test_fiq.py:104-105)
+    assert list(res) == META["recalls"]["fiq"]
+    clip, model, rel, feats, names, local, d = build("cirr")
+    assert list(validate.compute_cirr_val_metrics(rel, clip, feats, local, names, model, "cpu", d)) == META["recalls"]["cirr"]
+
+
+def test_caption_formatting_matches_reference_rule():
+    caps = [("is red.", "has Longer sleeves"), (" and blue?", "is darker,")]     # collated layout: [2][B]
+    assert _common.format_fiq_captions(caps) == ["Is red and and blue", "Has longer sleeves and is darker"]
+
+
+def test_unique_target_assertion_mirrors_reference():
+    clip, model, rel, feats, names, local, d = build("fiq")
+    names = list(names)
+    used = {it[0] for it in rel.items} | {it[1] for it in rel.items}
+    spare = next(i for i, n in enumerate(names) if n not in used)
+    names[spare] = rel.items[0][1]   # the first query's target now occurs twice: the reference's `exactly one hit` assert fires
+    with pytest.raises(AssertionError):
+        test_fiq.compute_fiq_val_metrics(rel, clip, feats, local, names, model, "cpu", d, 16, 0, "stub")
+
+
+def test_ern_modes_and_state_dict_surface():
+    d = 128
+    cfg = synth.CLIP_CONFIGS["tiny"]
+    eng = OracleEngine()
+    clip = FernCLIP(cfg, engine=eng).init_random(3)
+    model = ERN(clip, d, "cpu", engine=eng)
+    sd = synth.fusion_state_dict(d, seed=1)
+    full = dict(sd)
+    full.update({"image_clip.clip_model." + k: v for k, v in synth.clip_state_dict(cfg, 3).items()})
+    full["DVR.transformer_layer.bert_encoder.bert_model.embeddings.position_ids"] = np.arange(512)[None]   # transformers 4.30 buffer
+    model.load_state_dict(full)
+    assert set(model.state_dict()) >= set(sd)
+    imgs, toks = torch.from_numpy(synth.images(3, cfg)), torch.from_numpy(synth.captions(3, cfg))
+    loc = torch.from_numpy(synth.local_feats(3, d))
+    assert model(image=imgs, mode="image").shape == (3, d)
+    g = model(text=toks, ref_local_feats=loc.transpose(0, 1), mode="text_global")
+    s = model(text=toks, ref_local_feats=loc.transpose(0, 1), mode="text_seq")
+    assert g.shape == (3, d) and s.shape == (3, 77, d)
+    assert torch.equal(g, s[torch.arange(3), toks.argmax(-1)])            # global == seq[EOT]
+    out = model(ref_feats=g, ref_local_feats=loc, text_feats=g, text_seq_feats=s, mode="test")
+    idx = model(tar_feats=torch.nn.functional.normalize(g, dim=-1), tar_local_feats=loc, mode="index")
+    both = model(ref_feats=g, ref_local_feats=loc, text_feats=g, text_seq_feats=s, tar_feats=torch.nn.functional.normalize(g, dim=-1),
+                 tar_local_feats=loc)
+    assert torch.equal(both[0], out) and torch.equal(both[1], idx)
+    with pytest.raises(ValueError):
+        clip.encode_text(toks, visual_emb=torch.zeros(13, 4, d))
+    assert ImageCLIP(clip)(imgs).shape == (3, d) and TextCLIP(clip)(toks, mode="seq").shape == (3, 77, d)
+
+
+def test_standalone_modules_take_unprefixed_reference_keys():
+    d = 128
+    sd = synth.fusion_state_dict(d, seed=2)
+    gold = np.load(os.path.join(GOLD, "fusion.npz"))
+    sub = lambda p: {k[len(p):]: v for k, v in synth.fusion_state_dict(d, seed=11).items() if k.startswith(p)}  # noqa: E731
+    raw, loc = torch.from_numpy(synth.global_feats(6, d, 42, "ir")), torch.from_numpy(synth.local_feats(6, d, 42, "il"))
+    txt = torch.from_numpy(synth.global_feats(4, d, 42, "rg")).repeat(2, 1)[:6]
+    comb = CombinerSimple(d, 4 * d, 8 * d, engine=OracleEngine()).load_state_dict(sub("Combiner_module."))
+    assert np.abs(comb(raw, txt).numpy() - gold["d128_combiner_target"]).max() < 1e-6
+    sr = VisualSR(d, engine=OracleEngine()).load_state_dict(sub("SR_module."))
+    assert np.abs(sr(loc).numpy() - gold["d128_sr_target"]).max() < 1e-6
+    dvr = DVR_module(d, engine=OracleEngine()).load_state_dict(sub("DVR."))
+    rl, ts = torch.from_numpy(synth.local_feats(4, d, 42, "rl")), torch.from_numpy(synth._normal(42, f"tseq/{d}", (4, 77, d)))
+    rg, tg = torch.from_numpy(synth.global_feats(4, d, 42, "rg")), torch.from_numpy(synth.global_feats(4, d, 42, "tg"))
+    assert np.abs(dvr(rl, ts, rg, tg).numpy() - gold["d128_dvr_module"]).max() < 1e-6
+    with pytest.raises(ValueError):
+        VisualSR(d, num_region=9, engine=OracleEngine())
+
+
+def test_collate_fn_drops_none_and_tokenizer_registry():
+    batch = [("a", torch.zeros(2)), None, ("b", torch.ones(2))]
+    names, t = collate_fn(batch)
+    assert list(names) == ["a", "b"] and t.shape == (2, 2)
+    assert get_tokenizer("stub") is sdata.stub_tokenizer
+    with pytest.raises(RuntimeError, match="no tokenizer registered"):
+        get_tokenizer("no-such-model")
+
+
+def test_product_has_no_cpu_fallback_and_never_imports_oracle():
+    from fashionern_aaai2024_amd.engine import FernEngine
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            FernEngine("cuda:0")
+    root = os.path.join(os.path.dirname(os.path.dirname(__file__)), "fashionern_aaai2024_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
