@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -77,7 +78,7 @@ struct ClipW {
 };
 
 enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_TOPK = 2, PROF_SWEEP = 3 };
-struct ProfRec { hipEvent_t a, b; int kind; double work; };
+struct ProfRec { hipEvent_t a, b; int kind; double work; int m, n, k, tag; };
 
 struct fern_ctx {
     int device = 0;
@@ -134,7 +135,7 @@ static int ws_get(fern_ctx* c, size_t count, T** out) {
 }
 
 // ---- profiling hooks ----------------------------------------------------------------------------
-static int prof_open(fern_ctx* c, int kind, double work, hipStream_t s, int* slot) {
+static int prof_open(fern_ctx* c, int kind, double work, hipStream_t s, int* slot, int m = 0, int n = 0, int k = 0, int tag = 0) {
     *slot = -1;
     if (!c->prof_on) return FERN_OK;
     hipEvent_t ev[2];
@@ -143,7 +144,7 @@ static int prof_open(fern_ctx* c, int kind, double work, hipStream_t s, int* slo
         else HIP_TRY(hipEventCreate(&ev[i]));
     }
     HIP_TRY(hipEventRecord(ev[0], s));
-    c->recs.push_back({ev[0], ev[1], kind, work});
+    c->recs.push_back({ev[0], ev[1], kind, work, m, n, k, tag});
     *slot = (int)c->recs.size() - 1;
     return FERN_OK;
 }
@@ -155,7 +156,7 @@ static int prof_close(fern_ctx* c, int slot, hipStream_t s) {
 
 static int run_gemm(fern_ctx* c, const GemmParams& p, hipStream_t s, int kind = PROF_GEMM, double work = -1.0) {
     int slot;
-    FERN_TRY(prof_open(c, kind, work >= 0 ? work : 2.0 * p.M * (double)p.N * p.K, s, &slot));
+    FERN_TRY(prof_open(c, kind, work >= 0 ? work : 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, p.epi));
     HIP_TRY(launch_gemm(p, s));
     return prof_close(c, slot, s);
 }
@@ -167,7 +168,7 @@ static GemmParams gemm_desc(const float* A, long lda, const LinearW& L, float* C
 }
 static int run_attention(fern_ctx* c, const AttnParams& a, hipStream_t s) {
     int slot;
-    FERN_TRY(prof_open(c, PROF_ATTN, 4.0 * a.batch * a.heads * (double)a.s_q * a.s_k * a.hd, s, &slot));
+    FERN_TRY(prof_open(c, PROF_ATTN, 4.0 * a.batch * a.heads * (double)a.s_q * a.s_k * a.hd, s, &slot, a.batch * a.heads, a.s_q, a.hd, a.causal));
     HIP_TRY(launch_attention(a, s));
     return prof_close(c, slot, s);
 }
@@ -460,7 +461,7 @@ static int run_visual_sr(fern_ctx* c, const SRW& W, const float* local, float* o
     pg.aux0 = W.bnd_scale; pg.aux1 = W.bnd_shift;
     FERN_TRY(run_gemm(c, pg, s));
     const int M = (int)(n * 13);
-    const int nb = gemm_num_col_blocks(M, D);
+    const int nb = gemm_num_col_blocks(M, D, D);
     FERN_TRY(ws_get(c, (size_t)M * nb, &partial));
     GemmParams pl = gemm_desc(local, D, W.local, nullptr, D, M, EPI_SR_LOCAL);
     pl.aux0 = W.wc; pl.aux1 = W.bn13_mean; pl.aux2 = W.bn13_inv; pl.aux3 = W.bn13_beta;
@@ -478,7 +479,7 @@ static int run_combiner(fern_ctx* c, const CombinerW& W, const float* image, con
     FERN_TRY(ws_get(c, (size_t)n * H, &cat));
     FERN_TRY(run_gemm(c, gemm_desc(text, D, W.text, cat, H, (int)n, EPI_BIAS_RELU), s));          // :87,:90 text first
     FERN_TRY(run_gemm(c, gemm_desc(image, D, W.image, cat + Pj, H, (int)n, EPI_BIAS_RELU), s));   // :88
-    const int nb = gemm_num_col_blocks((int)n, W.hidden.out);
+    const int nb = gemm_num_col_blocks((int)n, W.hidden.out, H);
     FERN_TRY(ws_get(c, (size_t)n * nb, &partial));
     GemmParams ph = gemm_desc(cat, H, W.hidden, nullptr, H, (int)n, EPI_RELU_DOT);
     ph.aux0 = W.w2; ph.partial = partial;
@@ -846,9 +847,13 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
     std::memset(out, 0, sizeof(*out));
+    // FERN_PROF_DUMP=<path>: append one CSV line per instrumented launch (kind,m,n,k,tag,ms,work) for shape-level analysis
+    const char* dump_path = std::getenv("FERN_PROF_DUMP");
+    FILE* dump = dump_path ? std::fopen(dump_path, "a") : nullptr;
     for (auto& r : c->recs) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        if (dump) std::fprintf(dump, "%d,%d,%d,%d,%d,%.6f,%.0f\n", r.kind, r.m, r.n, r.k, r.tag, ms, r.work);
         switch (r.kind) {
             case PROF_GEMM: out->gemm_ms += ms; out->gemm_flops += r.work; out->gemm_launches++; break;
             case PROF_ATTN: out->attn_ms += ms; out->attn_flops += r.work; out->attn_launches++; break;
@@ -859,5 +864,6 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
         c->ev_pool.push_back(r.b);
     }
     c->recs.clear();
+    if (dump) std::fclose(dump);
     return FERN_OK;
 }

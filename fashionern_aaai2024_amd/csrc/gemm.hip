@@ -16,129 +16,36 @@
 //   * workgroup ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
 #include "kernels.h"
 
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
 namespace fern {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;
-constexpr int LDS_S = BK + 4;   // padded row stride (floats)
+// Exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at
+// fp32 rounding level) evaluated branch-free: 1 + erf(z) = 2 - P(t) e^{-z^2} for z >= 0 and P(t) e^{-z^2} for z < 0
+// (t = 1 / (1 + p |z|)), which also avoids the cancellation of 1 + erf(z) in the negative tail.  ~15 VALU ops per
+// element instead of the ~45 of libm's erff: the GELU epilogue of the 3072-wide MLP GEMMs was VALU-bound.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float az = fabsf(z);
+    const float t = __frcp_rn(fmaf(0.3275911f, az, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float pe = poly * t * __expf(-az * az);
+    const float cdf2 = z >= 0.0f ? 2.0f - pe : pe;
+    return 0.5f * x * cdf2;
+}
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
-    constexpr int WAVES_N = BN / WN;
-    constexpr int WAVES_M = BM / WM;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int AJ = BM / 32, WJ = BN / 32;   // float4 loads per thread per tile
-
-    __shared__ __attribute__((aligned(16))) float As[BM * LDS_S];
-    __shared__ __attribute__((aligned(16))) float Ws[BN * LDS_S];
-    __shared__ float red[WAVES_N][BM];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    // ---- XCD-aware, bijective workgroup -> tile map (n fastest inside an XCD's contiguous run) ----
-    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    const int nwg = nbm * nbn;
-    const int bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int bm = swz / nbn, bn = swz % nbn;
-
-    // ---- per-thread staging coordinates ----
-    const int c4 = tid & 7;      // float4 column inside the 32-wide k tile
-    const int r0 = tid >> 3;     // 0..31
-    const float* a_base[AJ];
-    const float* w_base[WJ];
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-        int row = bm * BM + r0 + 32 * j;
-        row = row < p.M ? row : p.M - 1;
-        if (p.aload == ALOAD_IM2COL) {
-            const int g2 = p.grid * p.grid;
-            const int b = row / g2, pr = row % g2;
-            const int py = pr / p.grid, px = pr % p.grid;
-            a_base[j] = p.A + ((long)b * 3 * p.img + (long)py * p.patch) * p.img + (long)px * p.patch;
-        } else {
-            a_base[j] = p.A + (long)row * p.lda;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-        int row = bn * BN + r0 + 32 * j;
-        row = row < p.N ? row : p.N - 1;
-        w_base[j] = p.W + (long)row * p.ldw;
-    }
-
-    f32x4 a_stage[AJ], w_stage[WJ];
-    auto stage_load = [&](int k0) {
-        const int k = k0 + c4 * 4;
-        long a_off = k;
-        if (p.aload == ALOAD_IM2COL) {
-            const int pp = p.patch * p.patch;
-            const int c = k / pp, rem = k % pp;
-            const int ky = rem / p.patch, kx = rem % p.patch;
-            a_off = ((long)c * p.img + ky) * p.img + kx;
-        }
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) a_stage[j] = *reinterpret_cast<const f32x4*>(a_base[j] + a_off);
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) w_stage[j] = *reinterpret_cast<const f32x4*>(w_base[j] + k);
-    };
-    auto stage_write = [&]() {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * j) * LDS_S + c4 * 4]) = a_stage[j];
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) *reinterpret_cast<f32x4*>(&Ws[(r0 + 32 * j) * LDS_S + c4 * 4]) = w_stage[j];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int nk = p.K / BK;
-    stage_load(0);
-    stage_write();
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage_load((kt + 1) * BK);   // in flight during the MFMA phase below
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(&As[(wm * WM + i * 32 + l31) * LDS_S + kk * 8 + 4 * lh]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(&Ws[(wn * WN + j * 32 + l31) * LDS_S + kk * 8 + 4 * lh]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            stage_write();
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+// Shared epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+template <int BM, int BN, int WM, int WN, int TM, int TN, int WAVES_N>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], float (*red)[BM], int bm, int bn, int nbn,
+                                              int wm, int wn, int l31, int lh, int tid) {
     const int row_w = bm * BM + wm * WM;
     const int col_w = bn * BN + wn * WN;
     if (p.epi < EPI_RELU_DOT) {
@@ -220,40 +127,391 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
-struct TileCfg { int bm, bn; float eff; };
-static const TileCfg kCfgs[4] = {{128, 128, 1.00f}, {64, 128, 0.93f}, {128, 64, 0.93f}, {64, 64, 0.86f}};
+// BM x BN block tile, WM x WN per wave (multiples of 32), BKT-wide k tiles, optional LDS double buffering.
+template <int BM, int BN, int WM, int WN, int BKT, bool DBUF>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(GemmParams p) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int WAVES_M = BM / WM;
+    constexpr int NT = WAVES_M * WAVES_N * 64;          // threads per workgroup
+    constexpr int LDS_S = BKT + 4;                      // padded row stride (floats): conflict-free ds_read_b128, 16-B aligned
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int C4 = BKT / 4;                         // float4 columns per k tile
+    constexpr int RSTEP = NT / C4;                      // rows covered by one pass of all threads
+    constexpr int AJ = BM / RSTEP, WJ = BN / RSTEP;     // float4 loads per thread per tile
+    static_assert(BM % RSTEP == 0 && BN % RSTEP == 0, "tile rows must divide evenly over the threads");
+    constexpr int NBUF = DBUF ? 2 : 1;
 
-static int choose_cfg(int M, int N) {
-    int best = 0;
+    __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDS_S];
+    __shared__ __attribute__((aligned(16))) float Ws[NBUF][BN * LDS_S];
+    __shared__ float red[WAVES_N][BM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- XCD-aware, bijective workgroup -> tile map (n fastest inside an XCD's contiguous run) ----
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nwg = nbm * nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int bm = swz / nbn, bn = swz % nbn;
+
+    // ---- per-thread staging coordinates ----
+    const int c4 = tid % C4;     // float4 column inside the k tile
+    const int r0 = tid / C4;
+    const float* a_base[AJ];
+    const float* w_base[WJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        int row = bm * BM + r0 + RSTEP * j;
+        row = row < p.M ? row : p.M - 1;
+        if (p.aload == ALOAD_IM2COL) {
+            const int g2 = p.grid * p.grid;
+            const int b = row / g2, pr = row % g2;
+            const int py = pr / p.grid, px = pr % p.grid;
+            a_base[j] = p.A + ((long)b * 3 * p.img + (long)py * p.patch) * p.img + (long)px * p.patch;
+        } else {
+            a_base[j] = p.A + (long)row * p.lda;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        int row = bn * BN + r0 + RSTEP * j;
+        row = row < p.N ? row : p.N - 1;
+        w_base[j] = p.W + (long)row * p.ldw;
+    }
+
+    f32x4 a_stage[AJ], w_stage[WJ];
+    auto stage_load = [&](int k0) {
+        const int k = k0 + c4 * 4;
+        long a_off = k;
+        if (p.aload == ALOAD_IM2COL) {
+            const int pp = p.patch * p.patch;
+            const int c = k / pp, rem = k % pp;
+            const int ky = rem / p.patch, kx = rem % p.patch;
+            a_off = ((long)c * p.img + ky) * p.img + kx;
+        }
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) a_stage[j] = *reinterpret_cast<const f32x4*>(a_base[j] + a_off);
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) w_stage[j] = *reinterpret_cast<const f32x4*>(w_base[j] + k);
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(&As[buf][(r0 + RSTEP * j) * LDS_S + c4 * 4]) = a_stage[j];
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) *reinterpret_cast<f32x4*>(&Ws[buf][(r0 + RSTEP * j) * LDS_S + c4 * 4]) = w_stage[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < BKT / 8; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&As[buf][(wm * WM + i * 32 + l31) * LDS_S + kk * 8 + 4 * lh]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(&Ws[buf][(wn * WN + j * 32 + l31) * LDS_S + kk * 8 + 4 * lh]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = p.K / BKT;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    if (DBUF) {
+        // one barrier per k tile: tile kt+1 is written into the other buffer while other waves still compute on tile kt
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) stage_load((kt + 1) * BKT);
+            compute(kt & 1);
+            if (kt + 1 < nk) stage_write((kt + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) stage_load((kt + 1) * BKT);   // in flight during the MFMA phase below
+            compute(0);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                stage_write(0);
+                __syncthreads();
+            }
+        }
+    }
+
+    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, red, bm, bn, nbn, wm, wn, l31, lh, tid);
+}
+
+// ---- LDS-DMA variant --------------------------------------------------------------------------------------------
+// Same tiling, but A / W tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write pass):
+// 16-wide k tiles, double buffered, one barrier per tile.  One wave-instruction writes 64 lanes x 16 B = 1 KiB =
+// 16 consecutive 64-byte tile rows, lane-linear, so the bank-conflict swizzle is applied on the per-lane SOURCE
+// address: the 16-byte chunk c of tile row r is stored at chunk position c ^ ((r >> 2) & 3), and the fragment reads
+// XOR the same value (conflict-free for the 16-lane groups of ds_read_b128).
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 4) void gemm_f32_glds_kernel(GemmParams p) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int WAVES_M = BM / WM;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int BKT = 16;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int ROWS = BM + BN;                        // A rows then W rows
+    constexpr int PIECES = ROWS / 16;                    // 1 KiB pieces per tile
+    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+    constexpr int PPW = PIECES / NW;                     // pieces per wave per tile
+
+    __shared__ __attribute__((aligned(1024))) float lds[2][ROWS * BKT];
+    __shared__ float red[WAVES_N][BM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nwg = nbm * nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int bm = swz / nbn, bn = swz % nbn;
+
+    // per-lane source row pointers (already offset by the swizzled 16-byte chunk) for this wave's pieces
+    const float* src[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave + NW * j;                       // wave-uniform
+        const int trow = piece * 16 + (lane >> 2);             // row in the [A; W] tile-row space
+        const int chunk = (lane & 3) ^ ((lane >> 4) & 3);      // logical chunk stored at position lane & 3 ((trow >> 2) & 3 == (lane >> 4) & 3)
+        if (trow < BM) {
+            int row = bm * BM + trow;
+            row = row < p.M ? row : p.M - 1;
+            src[j] = p.A + (long)row * p.lda + chunk * 4;
+        } else {
+            int row = bn * BN + (trow - BM);
+            row = row < p.N ? row : p.N - 1;
+            src[j] = p.W + (long)row * p.ldw + chunk * 4;
+        }
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int piece = wave + NW * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(&lds[buf][piece * 16 * BKT]), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int sw = (l31 >> 2) & 3;                              // read-side swizzle of this lane's rows
+    auto compute = [&](int buf) {
+        const float* As = &lds[buf][0];
+        const float* Ws = &lds[buf][BM * BKT];
+#pragma unroll
+        for (int kk = 0; kk < BKT / 8; ++kk) {
+            const int pc = ((2 * kk + lh) ^ sw) * 4;            // physical position of logical chunk 2kk + half
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[(wm * WM + i * 32 + l31) * BKT + pc]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Ws[(wn * WN + j * 32 + l31) * BKT + pc]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = p.K / BKT;
+    stage(0, 0);
+    __syncthreads();                                            // vmcnt(0) + barrier: tile 0 has landed for every wave
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BKT);   // the other buffer is free: every wave passed the last barrier
+        compute(kt & 1);
+        __syncthreads();                                        // drains this wave's DMA (vmcnt 0), then the barrier publishes it
+    }
+    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, red, bm, bn, nbn, wm, wn, l31, lh, tid);
+}
+
+struct TileCfg { int bm, bn, bk; float eff; };
+// order matters only for ties; eff = relative main-loop efficiency used by the shape heuristic
+static const TileCfg kCfgs[] = {
+    {128, 128, 32, 1.00f},   // 0: 4 waves of 64x64
+    {64, 128, 32, 0.93f},    // 1
+    {128, 64, 32, 0.93f},    // 2
+    {64, 64, 32, 0.86f},     // 3
+    {128, 128, 32, 1.00f},   // 4: as 0, LDS double-buffered (experimental)
+    {128, 128, 64, 1.00f},   // 5: as 0, 64-wide k tiles (experimental)
+    {256, 128, 32, 1.00f},   // 6: 8 waves of 64x64 (experimental)
+    {256, 128, 32, 1.00f},   // 7: as 6, double-buffered (experimental)
+    {128, 128, 16, 1.00f},   // 8: LDS-DMA staging, 16-wide k tiles, double buffered
+    {64, 128, 16, 0.93f},    // 9
+    {128, 64, 16, 0.93f},    // 10
+    {64, 64, 16, 0.86f},     // 11
+};
+constexpr int kNumAuto = 4;      // configs the heuristic may pick
+constexpr int kNumCfgs = 12;
+
+static int forced_cfg() {
+    static int v = [] {
+        const char* e = getenv("FERN_GEMM_CFG");
+        return e ? atoi(e) : -1;
+    }();
+    return v;
+}
+
+static int best_of(int M, int N, int first, int last) {
+    int best = first;
     double best_cost = 1e300;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = first; c < last; ++c) {
         const long nb = (long)((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((N + kCfgs[c].bn - 1) / kCfgs[c].bn);
-        const long rounds = (nb + 255) / 256;
-        const double cost = (double)rounds * kCfgs[c].bm * kCfgs[c].bn / kCfgs[c].eff;
+        const double cost = (double)((nb + 255) / 256) * kCfgs[c].bm * kCfgs[c].bn / kCfgs[c].eff;
         if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
     }
     return best;
 }
 
-int gemm_num_col_blocks(int M, int N) {
-    const int c = choose_cfg(M, N);
+// Heuristic (used as is for the reduce epilogues and as the fallback of the tuner): large problems stream their tiles
+// with LDS-DMA (configs 8-11: more resident waves, no ds_write pass); small-M problems are latency-bound per block and
+// do better with the register-prefetched 32-wide k tiles (configs 0-3).
+static int choose_cfg(int M, int N, int K) {
+    const int f = forced_cfg();
+    if (f >= 0 && f < kNumCfgs && K % kCfgs[f].bk == 0) return f;
+    if (f >= 100) return best_of(M, N, 8, 12);
+    return M >= 1024 ? best_of(M, N, 8, 12) : best_of(M, N, 0, kNumAuto);
+}
+
+int gemm_num_col_blocks(int M, int N, int K) {
+    const int c = choose_cfg(M, N, K);
     return (N + kCfgs[c].bn - 1) / kCfgs[c].bn;
+}
+
+static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
+    const int nb = ((p.M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((p.N + kCfgs[c].bn - 1) / kCfgs[c].bn);
+    switch (c) {
+        case 0: hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 64, 64, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_f32_kernel<64, 128, 32, 64, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_f32_kernel<128, 64, 64, 32, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, 32, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 64, 64, 32, true>), dim3(nb), dim3(256), 0, s, p); break;
+        case 5: hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 64, 64, 64, false>), dim3(nb), dim3(256), 0, s, p); break;
+        case 6: hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 64, 64, 32, false>), dim3(nb), dim3(512), 0, s, p); break;
+        case 7: hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 64, 64, 32, true>), dim3(nb), dim3(512), 0, s, p); break;
+        case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64>), dim3(nb), dim3(256), 0, s, p); break;
+        case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64>), dim3(nb), dim3(256), 0, s, p); break;
+        case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32>), dim3(nb), dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32>), dim3(nb), dim3(256), 0, s, p); break;
+    }
+    return hipGetLastError();
+}
+
+// ---- per-shape tile selection -------------------------------------------------------------------------------------
+// Every configuration accumulates each output element over k in the same order (k pairs (8g+e, 8g+4+e), g ascending),
+// so all of them produce bit-identical results: the choice is purely a speed choice.  Plain (non-reduce) epilogues of
+// large problems are tuned once per shape by timing the candidates on scratch outputs; reduce epilogues keep the
+// heuristic because their partial-sum layout depends on the column-block count the caller sized its buffer for.
+struct ShapeKey {
+    int M, N, K, epi, aload;
+    bool operator<(const ShapeKey& o) const {
+        if (M != o.M) return M < o.M;
+        if (N != o.N) return N < o.N;
+        if (K != o.K) return K < o.K;
+        if (epi != o.epi) return epi < o.epi;
+        return aload < o.aload;
+    }
+};
+static std::map<ShapeKey, int> g_tuned;
+static std::mutex g_tuned_mu;
+
+static bool tuning_enabled() {
+    static bool v = [] {
+        const char* e = getenv("FERN_GEMM_TUNE");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
+static int tune_shape(const GemmParams& p, hipStream_t s) {
+    const int fallback = choose_cfg(p.M, p.N, p.K);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return fallback;
+    long out_rows = p.M;
+    if (p.epi == EPI_PATCH_EMBED) out_rows = p.M + p.M / (p.grid * p.grid) + 2;
+    float* scratch = nullptr;
+    if (hipMalloc(&scratch, (size_t)out_rows * p.ldc * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fallback; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    GemmParams q = p;
+    q.C = scratch;            // residual input (p.R) is only read: tuning has no side effects on the caller's buffers
+    int best = fallback;
+    float best_ms = 1e30f;
+    static const int cands[] = {0, 1, 2, 3, 8, 9, 10, 11};
+    for (int c : cands) {
+        if (c >= 8 && p.aload != ALOAD_PLAIN) continue;
+        if (p.K % kCfgs[c].bk) continue;
+        if (launch_cfg(c, q, s) != hipSuccess) continue;                 // warm
+        (void)hipEventRecord(e0, s);
+        (void)launch_cfg(c, q, s);
+        (void)launch_cfg(c, q, s);
+        (void)hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(scratch);
+    return best;
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
-    if (p.K <= 0 || (p.K % BK) != 0 || (p.ldw & 3) || (p.aload == ALOAD_PLAIN && (p.lda & 3))) return hipErrorInvalidValue;
+    if (p.K <= 0 || (p.K % 32) != 0 || (p.ldw & 3) || (p.aload == ALOAD_PLAIN && (p.lda & 3))) return hipErrorInvalidValue;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return hipErrorInvalidValue;
     if (p.aload == ALOAD_IM2COL && ((p.patch & 3) || (p.img & 3))) return hipErrorInvalidValue;
-    const int c = choose_cfg(p.M, p.N);
-    const int nb = ((p.M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((p.N + kCfgs[c].bn - 1) / kCfgs[c].bn);
-    switch (c) {
-        case 0: hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 64, 64>), dim3(nb), dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_f32_kernel<64, 128, 32, 64>), dim3(nb), dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_f32_kernel<128, 64, 64, 32>), dim3(nb), dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, 32>), dim3(nb), dim3(256), 0, s, p); break;
+    int c = choose_cfg(p.M, p.N, p.K);
+    const bool tunable = forced_cfg() < 0 && tuning_enabled() && p.epi < EPI_RELU_DOT && 2.0 * p.M * (double)p.N * p.K >= 2.5e8;
+    if (tunable) {
+        const ShapeKey key{p.M, p.N, p.K, p.epi, p.aload};
+        std::lock_guard<std::mutex> lock(g_tuned_mu);
+        auto it = g_tuned.find(key);
+        if (it == g_tuned.end()) it = g_tuned.emplace(key, tune_shape(p, s)).first;
+        c = it->second;
     }
-    return hipGetLastError();
+    if (c >= 8 && p.aload != ALOAD_PLAIN) c -= 8;          // the LDS-DMA kernels take plain row-major A only
+    return launch_cfg(c, p, s);
 }
 
 }  // namespace fern

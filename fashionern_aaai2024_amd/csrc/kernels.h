@@ -38,7 +38,7 @@ struct GemmParams {
     int img, patch, grid;  // ALOAD_IM2COL: image side, patch side, patches per side; EPI_PATCH_EMBED uses grid*grid
 };
 // Number of column blocks the reduce epilogues write per row (depends on the tile chosen for this shape).
-int gemm_num_col_blocks(int M, int N);
+int gemm_num_col_blocks(int M, int N, int K);
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 
 // ---- attention (attn.hip) ---------------------------------------------------------------------

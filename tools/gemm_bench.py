@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Micro-benchmark of libfern's fp32 MFMA GEMM on the shapes of the hot path (A/B tool for kernel work).
+Usage: python tools/gemm_bench.py [--iters 20] [--shapes vit|text|fusion|all]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from fashionern_aaai2024_amd.engine import FernEngine  # noqa: E402
+
+SHAPES = {
+    "vit": [(12608, 3072, 768, 1), (12608, 768, 3072, 3), (12608, 2304, 768, 0), (12608, 768, 768, 3)],
+    "text": [(4928, 2048, 512, 1), (4928, 512, 2048, 3), (4928, 1536, 512, 0), (4928, 512, 512, 3)],
+    "fusion": [(5824, 3072, 512, 1), (5824, 512, 3072, 3), (5824, 1536, 512, 0), (64, 4096, 4096, 2), (64, 2048, 512, 2),
+               (64, 46000, 512, 0), (832, 512, 512, 0)],
+    "big": [(4096, 4096, 4096, 0), (8192, 8192, 1024, 0)],
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--shapes", default="all")
+    args = ap.parse_args()
+    eng = FernEngine("cuda:0")
+    groups = SHAPES if args.shapes == "all" else {args.shapes: SHAPES[args.shapes]}
+    tot_ms = tot_fl = 0.0
+    for gname, shapes in groups.items():
+        for (m, n, k, epi) in shapes:
+            a = torch.randn(m, k, device="cuda")
+            w = torch.randn(n, k, device="cuda") * k ** -0.5
+            b = torch.randn(n, device="cuda")
+            r = torch.randn(m, n, device="cuda") if epi == 3 else None
+            for _ in range(3):
+                eng.gemm(a, w, b, residual=r, epilogue=epi)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                eng.gemm(a, w, b, residual=r, epilogue=epi)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            fl = 2.0 * m * n * k
+            tot_ms += ms
+            tot_fl += fl
+            print(f"{gname:7s} M={m:6d} N={n:6d} K={k:5d} epi={epi}  {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.1f} TF/s", flush=True)
+    print(f"total {tot_ms:.3f} ms  {tot_fl / tot_ms / 1e9:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
