@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--gallery", type=int, default=GALLERY)
+    ap.add_argument("--pmc-mode", action="store_true",
+                    help="for `rocprofv3 --pmc`: warm up, emit a marker dispatch, run exactly --steps steps, exit (no JSON)")
     args = ap.parse_args()
 
     rank, world, local = fd.init_from_env()
@@ -129,6 +131,12 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if args.pmc_mode:      # tools/pmc_traffic.py keys on this single-workgroup l2norm dispatch to find the measured steps
+        eng.l2_normalize(torch.zeros(3, 64, device=device))
+        for _ in range(args.steps):
+            step()
+        barrier()
+        return
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -183,6 +191,13 @@ def main():
             "gallery_build": {"index_fuse_all_gather_s": gallery_build_s, "rows_per_s": n_gal / gallery_build_s,
                               "encode_images_per_s_per_gpu": enc_ips},
         }
+        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(traffic_file):      # HBM bytes per launch from a separate `rocprofv3 --pmc` pass of this command
+            tr = json.load(open(traffic_file))
+            result["roofline"]["traffic"] = tr.get("gemm", {}).get("hbm_bytes_per_launch")
+            result["roofline"]["traffic_source"] = tr.get("source")
+            result["roofline"]["algorithmic_bytes_per_launch"] = tr.get("gemm", {}).get("algorithmic_bytes_per_launch")
+            result["roofline_sim_sweep"]["traffic"] = tr.get("sweep", {}).get("hbm_bytes_per_launch")
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(clip_sd, fusion_sd, cfg, images, tokens, loc, gallery, args.cpu_sample)
         print(json.dumps(result), flush=True)

@@ -656,6 +656,35 @@ static int clip_block(fern_ctx* c, const ClipBlockW& Bk, float* X, float* XN, fl
     return run_gemm(c, p2, s);
 }
 
+// Last ViT block: only the class token is consumed afterwards (ln_post on token 0, modeling_clip.py:876-877), so
+// K/V are projected for every token but Q, the attention output, out_proj and the MLP run for the class rows only.
+// Bit-identical to the full block on the rows that are read.
+static int clip_block_cls_only(fern_ctx* c, const ClipBlockW& Bk, const float* X, float* XN, float* QKV, float* CLS /*[b,width] out*/,
+                               float* T0 /*[b,width]*/, float* T1 /*[b,width]*/, float* H /*[b,mlp]*/, int batch, int S, int width,
+                               int heads, hipStream_t s) {
+    const long R = (long)batch * S;
+    const int hd = width / heads;
+    HIP_TRY(launch_layernorm(X, nullptr, Bk.ln1.g, Bk.ln1.b, XN, R, width, width, width, 1e-5f, s));
+    LinearW kv{Bk.qkv.w + (size_t)width * width, Bk.qkv.b + width, 2 * width, width};
+    FERN_TRY(run_gemm(c, gemm_desc(XN, width, kv, QKV + width, 3 * width, (int)R, EPI_BIAS), s));      // K, V for all tokens
+    HIP_TRY(launch_gather_rows(XN, width, T0, width, batch, width, 1, S, 0, nullptr, s));              // ln_1(x)[:, 0]
+    LinearW qw{Bk.qkv.w, Bk.qkv.b, width, width};
+    FERN_TRY(run_gemm(c, gemm_desc(T0, width, qw, T1, width, batch, EPI_BIAS), s));                    // Q for the class rows
+    // one query per (batch, head): q rows are [batch, 1]; K/V are read in place from the packed buffer
+    AttnParams a{T1, QKV + width, QKV + 2 * width, T0, (long)width, 3L * width, 3L * width, (long)width,
+                 batch, heads, hd, 1, S, 0, 1.0f / std::sqrt((float)hd)};
+    FERN_TRY(run_attention(c, a, s));
+    HIP_TRY(launch_gather_rows(X, width, CLS, width, batch, width, 1, S, 0, nullptr, s));              // residual x[:, 0]
+    GemmParams po = gemm_desc(T0, width, Bk.out, CLS, width, batch, EPI_BIAS_RESIDUAL);
+    po.R = CLS;
+    FERN_TRY(run_gemm(c, po, s));
+    HIP_TRY(launch_layernorm(CLS, nullptr, Bk.ln2.g, Bk.ln2.b, T0, batch, width, width, width, 1e-5f, s));
+    FERN_TRY(run_gemm(c, gemm_desc(T0, width, Bk.fc, H, Bk.fc.out, batch, EPI_BIAS_GELU), s));
+    GemmParams p2 = gemm_desc(H, Bk.fc.out, Bk.proj, CLS, width, batch, EPI_BIAS_RESIDUAL);
+    p2.R = CLS;
+    return run_gemm(c, p2, s);
+}
+
 static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStream_t s) {
     const ClipW& W = c->clip;
     const fern_clip_config& cf = W.cfg;
@@ -677,8 +706,9 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
     FERN_TRY(run_gemm(c, pe, s));
     HIP_TRY(launch_vit_cls(W.cls, W.vpos, X, b, S, vw, s));
     HIP_TRY(launch_layernorm(X, nullptr, W.ln_pre.g, W.ln_pre.b, X, R, vw, vw, vw, 1e-5f, s));
-    for (int l = 0; l < cf.v_layers; ++l) FERN_TRY(clip_block(c, W.vblocks[l], X, XN, QKV, ATT, H, b, S, vw, cf.v_heads, 0, s));
-    HIP_TRY(launch_gather_rows(X, vw, CLS, vw, b, vw, 1, S, 0, nullptr, s));
+    for (int l = 0; l + 1 < cf.v_layers; ++l) FERN_TRY(clip_block(c, W.vblocks[l], X, XN, QKV, ATT, H, b, S, vw, cf.v_heads, 0, s));
+    // ATT / H are free after the last full block: reuse their heads as the [b, width] / [b, mlp] temporaries
+    FERN_TRY(clip_block_cls_only(c, W.vblocks[cf.v_layers - 1], X, XN, QKV, CLS, ATT, ATT + (size_t)b * vw, H, b, S, vw, cf.v_heads, s));
     HIP_TRY(launch_layernorm(CLS, nullptr, W.ln_post.g, W.ln_post.b, CLS, b, vw, vw, vw, 1e-5f, s));
     LinearW proj{W.vproj_t, nullptr, cf.embed_dim, vw};
     return run_gemm(c, gemm_desc(CLS, vw, proj, out, cf.embed_dim, b, EPI_BIAS), s);

@@ -22,11 +22,10 @@ namespace fern {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int HDP, int NT, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
+template <int HDP, int NT, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_f32_kernel(AttnParams p) {
     constexpr int KS = HDP + 4;          // K row stride in LDS (floats)
     constexpr int ROWS = NT * 32;        // padded key count
-    constexpr int NW = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                    // [ROWS][KS]
     float* Vs = smem + ROWS * KS;        // [ROWS][HDP]
@@ -41,7 +40,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
         constexpr int C4 = HDP / 4;
         const float* kb = p.k + (long)b * p.s_k * p.ldk + (long)h * hd;
         const float* vb = p.v + (long)b * p.s_k * p.ldv + (long)h * hd;
-        for (int i = tid; i < ROWS * C4; i += 256) {
+        for (int i = tid; i < ROWS * C4; i += NW * 64) {
             const int row = i / C4, c = (i % C4) * 4;
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
             if (row < p.s_k && c < hd) {
@@ -101,11 +100,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float m_new = fmaxf(m, mt);      // finite from tile 0 on: key 0 is valid for every query
-            const float alpha = expf(m - m_new);   // exp(-inf) = 0 on the first tile
+            const float alpha = __expf(m - m_new);   // exp(-inf) = 0 on the first tile
             float ps = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = expf(st[r] - m_new);   // masked entries: exp(-inf) = 0
+                const float e = __expf(st[r] - m_new);   // masked entries: exp(-inf) = 0
                 st[r] = e;
                 ps += e;
             }
@@ -147,13 +146,15 @@ template <int HDP, int NT, bool CAUSAL>
 static hipError_t launch_inst(const AttnParams& p, hipStream_t s) {
     constexpr size_t lds = (size_t)NT * 32 * (HDP + 4 + HDP) * sizeof(float);
     static bool attr_set = false;
-    auto kern = attn_f32_kernel<HDP, NT, CAUSAL>;
+    // 197-token ViT heads: 7 query tiles -> 8 waves (two per SIMD) so one wave's softmax VALU work overlaps its partner's MFMAs
+    constexpr int NW = NT >= 7 ? 8 : 4;
+    auto kern = attn_f32_kernel<HDP, NT, CAUSAL, NW>;
     if (!attr_set && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.batch * p.heads), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.batch * p.heads), dim3(NW * 64), lds, s, p);
     return hipGetLastError();
 }
 
