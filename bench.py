@@ -88,6 +88,8 @@ def main():
     rank, world, local = fd.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("FERN_BENCH_SHARE_GPU"):      # debug only: several ranks on one GPU (with FERN_DIST_BACKEND=gloo)
+        local = local % torch.cuda.device_count()
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     cfg = synth.CLIP_CONFIGS["ViT-B-16"]

@@ -837,7 +837,9 @@ extern "C" int fern_topk_merge(fern_ctx* c, const float* scores, const int32_t* 
 // ------------------------------------------------------------------------------------------------
 extern "C" int fern_gemm(fern_ctx* c, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* residual,
                          float* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream) {
-    if (!c || !A || !W || !C || M < 0 || N < 0 || K <= 0) return fail(FERN_ERR_ARG, "fern_gemm: bad argument");
+    if (!c || M < 0 || N < 0 || K <= 0) return fail(FERN_ERR_ARG, "fern_gemm: bad argument");
+    if (M == 0 || N == 0) return FERN_OK;
+    if (!A || !W || !C) return fail(FERN_ERR_ARG, "fern_gemm: NULL argument");
     if (epilogue < FERN_EPI_BIAS || epilogue > FERN_EPI_BIAS_RESIDUAL) return fail(FERN_ERR_ARG, "fern_gemm: unknown epilogue");
     if (epilogue == FERN_EPI_BIAS_RESIDUAL && !residual) return fail(FERN_ERR_ARG, "fern_gemm: residual is NULL");
     if (K % 32) return fail(FERN_ERR_ARG, "fern_gemm: K must be a multiple of 32");

@@ -404,15 +404,21 @@ static int best_of(int M, int N, int first, int last) {
 // Heuristic (used as is for the reduce epilogues and as the fallback of the tuner): large problems stream their tiles
 // with LDS-DMA (configs 8-11: more resident waves, no ds_write pass); small-M problems are latency-bound per block and
 // do better with the register-prefetched 32-wide k tiles (configs 0-3).
-static int choose_cfg(int M, int N, int K) {
+static int choose_cfg(int M, int N, int K, bool reduce = false) {
     const int f = forced_cfg();
+    if (reduce) {
+        // Reduce epilogues sum over columns: only the 128-column-block / 64-column-wave shapes are used (configs 0/1 and
+        // 8/9) so that the column summation order -- and with it every output row -- is independent of M (batch-invariant).
+        const int base = (f >= 8 || (f < 0 && M >= 1024)) ? 8 : 0;
+        return best_of(M, N, base, base + 2);
+    }
     if (f >= 0 && f < kNumCfgs && K % kCfgs[f].bk == 0) return f;
     if (f >= 100) return best_of(M, N, 8, 12);
     return M >= 1024 ? best_of(M, N, 8, 12) : best_of(M, N, 0, kNumAuto);
 }
 
 int gemm_num_col_blocks(int M, int N, int K) {
-    const int c = choose_cfg(M, N, K);
+    const int c = choose_cfg(M, N, K, true);
     return (N + kCfgs[c].bn - 1) / kCfgs[c].bn;
 }
 
@@ -462,7 +468,7 @@ static bool tuning_enabled() {
 }
 
 static int tune_shape(const GemmParams& p, hipStream_t s) {
-    const int fallback = choose_cfg(p.M, p.N, p.K);
+    const int fallback = choose_cfg(p.M, p.N, p.K, false);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return fallback;
     long out_rows = p.M;
@@ -501,7 +507,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.K <= 0 || (p.K % 32) != 0 || (p.ldw & 3) || (p.aload == ALOAD_PLAIN && (p.lda & 3))) return hipErrorInvalidValue;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return hipErrorInvalidValue;
     if (p.aload == ALOAD_IM2COL && ((p.patch & 3) || (p.img & 3))) return hipErrorInvalidValue;
-    int c = choose_cfg(p.M, p.N, p.K);
+    int c = choose_cfg(p.M, p.N, p.K, p.epi >= EPI_RELU_DOT);
     const bool tunable = forced_cfg() < 0 && tuning_enabled() && p.epi < EPI_RELU_DOT && 2.0 * p.M * (double)p.N * p.K >= 2.5e8;
     if (tunable) {
         const ShapeKey key{p.M, p.N, p.K, p.epi, p.aload};

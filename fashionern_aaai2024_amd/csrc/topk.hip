@@ -30,19 +30,26 @@ __device__ __forceinline__ float unorderable(unsigned k) {
 __device__ __forceinline__ u64 make_key(float score, unsigned idx) {
     return ((u64)orderable(score) << 32) | (u64)(0xFFFFFFFFu - idx);
 }
-__device__ __forceinline__ u64 shfl64(u64 v, int src) {
-    const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+// Cross-lane moves without the LDS crossbar: a wave-uniform source lane is a v_readlane_b32 (SGPR lane select), the
+// shift-by-one of the sorted list is a DPP wave_shr:1 move.  ds_bpermute-based __shfl made every insertion a chain of
+// ~4 dependent ~120-cycle LDS round trips; these are plain VALU/SALU latencies.
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {       // src must be wave-uniform
+    const int l = __builtin_amdgcn_readfirstlane(src);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
     return ((u64)hi << 32) | lo;
 }
-__device__ __forceinline__ u64 shfl_up64(u64 v) {
-    const unsigned lo = __shfl_up((unsigned)v, 1), hi = __shfl_up((unsigned)(v >> 32), 1);
-    return ((u64)hi << 32) | lo;
+__device__ __forceinline__ u64 shfl_up64(u64 v) {             // lane i <- lane i-1 (lane 0 keeps its value)
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)v, (int)(unsigned)v, 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(v >> 32), (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
+    return ((u64)(unsigned)hi << 32) | (unsigned)lo;
 }
 
 // Offer one candidate per lane (key 0 = no candidate) to the wave's sorted list `best` (lane i = i-th best).
 __device__ __forceinline__ void wave_offer(u64& best, u64 cand, int K, int lane) {
     u64 thr = shfl64(best, K - 1);
     u64 mask = __ballot(cand > thr);
+    if (mask == 0) return;                                        // the common case after warm-up: nothing beats the K-th entry
     while (mask) {
         const int src = __ffsll((long long)mask) - 1;
         const u64 c = shfl64(cand, src);

@@ -156,3 +156,22 @@ def test_clip_vit_b16_full_size():
     assert _maxerr(s, rs) < 1e-3 * max(1.0, rs.abs().max().item())
     assert (1 - F.cosine_similarity(g.cpu(), rg, dim=-1)).abs().max().item() < 1e-5
     eng.close()
+
+
+def test_zero_rows_fusion():
+    eng, sd = fusion_engine(128)
+    assert eng.index_fuse(torch.zeros(0, 128), torch.zeros(0, 13, 128)).shape == (0, 128)
+    assert eng.dvr_fuse(torch.zeros(0, 128), torch.zeros(0, 13, 128), torch.zeros(0, 128), torch.zeros(0, 77, 128)).shape == (0, 128)
+    with pytest.raises(ValueError):
+        eng.index_fuse(torch.zeros(3, 128), torch.zeros(3, 12, 128))          # VisualSR needs exactly 13 patches
+
+
+def test_batch_invariance_of_fusion_rows():
+    """Every GEMM tile shape accumulates over k in the same order, so a row's result does not depend on the batch it
+    travels in (what makes sharded gallery builds bit-identical to unsharded ones)."""
+    d = 128
+    eng, sd = fusion_engine(d)
+    raw, loc = _t(synth.global_feats(2000, d, tag="bi")), _t(synth.local_feats(2000, d, tag="bil"))
+    full = eng.index_fuse(raw, loc, normalize_input=True).cpu()
+    for a, b in ((0, 1), (5, 70), (100, 1124), (1990, 2000)):
+        assert torch.equal(eng.index_fuse(raw[a:b], loc[a:b], normalize_input=True).cpu(), full[a:b])

@@ -166,3 +166,36 @@ def test_l2_normalize(engine):
     x = _rand(100, 512, seed=9)
     x[3] = 0
     _close(engine.l2_normalize(x), F.normalize(x.double(), dim=-1), rel=1e-6)
+
+
+def test_empty_and_degenerate_inputs(engine):
+    """Zero-sized batches / galleries are legal (a rank's gallery shard can be empty) and must not launch garbage."""
+    q, g = _int_unit(4, 64, 1), _int_unit(10, 64, 2)
+    s, i = engine.sim_topk(q, g[:0], 5)
+    assert (i.cpu() == -1).all() and torch.isinf(s.cpu()).all() and (s.cpu() < 0).all()
+    s, i = engine.sim_topk(q[:0], g, 5)
+    assert s.shape == (0, 5) and i.shape == (0, 5)
+    assert engine.gemm(torch.zeros(0, 64), torch.zeros(8, 64)).shape == (0, 8)
+    assert engine.l2_normalize(torch.zeros(0, 64)).shape == (0, 64)
+    # K larger than the gallery: the tail is (-inf, -1), the head is the full ranking
+    s, i = engine.sim_topk(q, g, 64)
+    rs, ri = orank.cosine_topk(q, g, 64)
+    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
+
+
+def test_bad_arguments_are_reported_not_executed(engine):
+    from fashionern_aaai2024_amd._lib import FernError
+    with pytest.raises(FernError, match="K"):
+        engine.sim_topk(_int_unit(2, 64, 1), _int_unit(10, 64, 2), 65)
+    with pytest.raises(FernError, match="multiple of 32"):
+        engine.gemm(torch.zeros(4, 48), torch.zeros(4, 48))
+    with pytest.raises(ValueError):
+        engine.sim_topk(_int_unit(2, 64, 1), _int_unit(10, 32, 2), 5)
+
+
+def test_topk_large_gallery_many_segments(engine):
+    """200k rows = 25 level-1 segments per query; merge must still be exact (ties included)."""
+    q, g = _int_unit(3, 32, 11), _int_unit(200_000, 32, 12)
+    rs, ri = orank.cosine_topk(q, g, 51)
+    s, i = engine.sim_topk(q, g, 51)
+    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
