@@ -268,17 +268,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
 // 16 consecutive 64-byte tile rows, lane-linear, so the bank-conflict swizzle is applied on the per-lane SOURCE
 // address: the 16-byte chunk c of tile row r is stored at chunk position c ^ ((r >> 2) & 3), and the fragment reads
 // XOR the same value (conflict-free for the 16-lane groups of ds_read_b128).
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 4) void gemm_f32_glds_kernel(GemmParams p) {
+template <int BM, int BN, int WM, int WN, int BKT, int MINW>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_glds_kernel(GemmParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
     constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int BKT = 16;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int ROWS = BM + BN;                        // A rows then W rows
-    constexpr int PIECES = ROWS / 16;                    // 1 KiB pieces per tile
+    constexpr int C4 = BKT / 4;                          // 16-byte chunks per tile row (4 or 8)
+    constexpr int RPP = 64 / C4;                         // tile rows per 1 KiB piece (16 or 8)
+    constexpr int PIECES = ROWS / RPP;
     static_assert(PIECES % NW == 0, "pieces must divide over the waves");
     constexpr int PPW = PIECES / NW;                     // pieces per wave per tile
+    // swizzle: chunk c of row r lives at position c ^ f(r); f(r) = (r >> 2) & 3 for 64-byte rows, (r >> 1) & 7 for 128-byte rows
+    constexpr int FSH = BKT == 16 ? 2 : 1;
+    constexpr int FMASK = C4 - 1;
 
     __shared__ __attribute__((aligned(1024))) float lds[2][ROWS * BKT];
     __shared__ float red[WAVES_N][BM];
@@ -301,8 +305,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 4) void gemm_f32_glds_k
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int piece = wave + NW * j;                       // wave-uniform
-        const int trow = piece * 16 + (lane >> 2);             // row in the [A; W] tile-row space
-        const int chunk = (lane & 3) ^ ((lane >> 4) & 3);      // logical chunk stored at position lane & 3 ((trow >> 2) & 3 == (lane >> 4) & 3)
+        const int trow = piece * RPP + lane / C4;              // row in the [A; W] tile-row space (BM, BN multiples of 32)
+        const int chunk = (lane & FMASK) ^ ((trow >> FSH) & FMASK);   // logical chunk stored at position lane % C4
         if (trow < BM) {
             int row = bm * BM + trow;
             row = row < p.M ? row : p.M - 1;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 4) void gemm_f32_glds_k
         for (int j = 0; j < PPW; ++j) {
             const int piece = wave + NW * j;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
-                                             (__attribute__((address_space(3))) void*)(&lds[buf][piece * 16 * BKT]), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(&lds[buf][piece * 256]), 16, 0, 0);
         }
     };
 
@@ -330,7 +334,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 4) void gemm_f32_glds_k
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int sw = (l31 >> 2) & 3;                              // read-side swizzle of this lane's rows
+    const int sw = (l31 >> FSH) & FMASK;                        // read-side swizzle of this lane's rows
     auto compute = [&](int buf) {
         const float* As = &lds[buf][0];
         const float* Ws = &lds[buf][BM * BKT];
@@ -378,9 +382,11 @@ static const TileCfg kCfgs[] = {
     {64, 128, 16, 0.93f},    // 9
     {128, 64, 16, 0.93f},    // 10
     {64, 64, 16, 0.86f},     // 11
+    {128, 128, 32, 1.00f},   // 12: LDS-DMA, 32-wide k tiles, 2 workgroups per CU (experimental)
+    {256, 128, 16, 1.00f},   // 13: LDS-DMA, 8 waves (experimental)
 };
 constexpr int kNumAuto = 4;      // configs the heuristic may pick
-constexpr int kNumCfgs = 12;
+constexpr int kNumCfgs = 14;
 
 static int forced_cfg() {
     static int v = [] {
@@ -433,10 +439,12 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
         case 5: hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 64, 64, 64, false>), dim3(nb), dim3(256), 0, s, p); break;
         case 6: hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 64, 64, 32, false>), dim3(nb), dim3(512), 0, s, p); break;
         case 7: hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 64, 64, 32, true>), dim3(nb), dim3(512), 0, s, p); break;
-        case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64>), dim3(nb), dim3(256), 0, s, p); break;
-        case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64>), dim3(nb), dim3(256), 0, s, p); break;
-        case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32>), dim3(nb), dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32>), dim3(nb), dim3(256), 0, s, p); break;
+        case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 12: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 32, 2>), dim3(nb), dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 64, 64, 16, 2>), dim3(nb), dim3(512), 0, s, p); break;
     }
     return hipGetLastError();
 }
