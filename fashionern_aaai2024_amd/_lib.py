@@ -28,6 +28,7 @@ SIGNATURES = {
     "fern_abi_version": (c_int, []),
     "fern_last_error": (C.c_char_p, []),
     "fern_ctx_create": (c_int, [c_int, C.POINTER(c_void_p)]),
+    "fern_ctx_fork": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "fern_ctx_destroy": (c_int, [c_void_p]),
     "fern_sync": (c_int, [c_void_p, c_void_p]),
     "fern_load_tensor": (c_int, [c_void_p, C.c_char_p, c_void_p, c_int, c_int, C.POINTER(c_i64)]),

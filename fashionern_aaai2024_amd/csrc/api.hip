@@ -296,6 +296,18 @@ extern "C" int fern_ctx_create(int device, fern_ctx** out) {
     *out = c;
     return FERN_OK;
 }
+// A fork shares the parent's finalised device weights (read-only) but has its own workspace, tuner-independent launch
+// state and profiling records, so several forks can run concurrently on different HIP streams of the same device.
+extern "C" int fern_ctx_fork(fern_ctx* parent, fern_ctx** out) {
+    if (!parent || !out) return fail(FERN_ERR_ARG, "fern_ctx_fork: NULL argument");
+    auto* c = new fern_ctx();
+    c->device = parent->device;
+    c->fusion = parent->fusion;      // pointers into the parent's `owned` buffers; the parent must outlive its forks
+    c->clip = parent->clip;
+    *out = c;
+    return FERN_OK;
+}
+
 extern "C" int fern_ctx_destroy(fern_ctx* c) {
     if (!c) return FERN_OK;
     (void)hipSetDevice(c->device);

@@ -49,6 +49,18 @@ class FernEngine:
         self.feature_dim: Optional[int] = None
         self.clip_cfg: Optional[ClipConfig] = None
 
+    def fork(self) -> "FernEngine":
+        """A context that shares this engine's finalised weights (no copy) but owns its workspace: use one per extra
+        HIP stream.  Keep the parent alive (the fork holds a reference) and fork again after re-loading weights."""
+        child = object.__new__(FernEngine)
+        child.lib, child.device = self.lib, self.device
+        child.feature_dim, child.clip_cfg = self.feature_dim, self.clip_cfg
+        child._parent = self
+        h = C.c_void_p()
+        _lib.check(self.lib.fern_ctx_fork(self._h, C.byref(h)), "fern_ctx_fork")
+        child._h = h
+        return child
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.fern_ctx_destroy(self._h)

@@ -103,6 +103,10 @@ FERN_API const char* fern_last_error(void);
 
 /* lifetime ------------------------------------------------------------------------------ */
 FERN_API int fern_ctx_create(int device, fern_ctx** out);
+/* a second context on the same device that SHARES the parent's finalised weights (no copy) and owns its own workspace:
+ * one per extra HIP stream when several batches are kept in flight.  Destroy forks before the parent; re-finalising the
+ * parent invalidates them. */
+FERN_API int fern_ctx_fork(fern_ctx* parent, fern_ctx** out);
 FERN_API int fern_ctx_destroy(fern_ctx* ctx);
 FERN_API int fern_sync(fern_ctx* ctx, void* stream);
 

@@ -146,3 +146,64 @@ def test_c5_one_million_row_gallery():
     parts = [eng.sim_topk(q, g[r * per:(r + 1) * per], 50, idx_offset=r * per) for r in range(8)]
     ms, mi = eng.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     assert torch.equal(mi, i) and torch.equal(ms, s)
+
+
+def test_step_is_hipgraph_capturable():
+    """After one warm-up call per shape (workspace growth, tile tuning) the launch functions only enqueue kernels, so a
+    whole fuse -> rank sequence can be captured into a hipGraph and replayed with identical results."""
+    d = 128
+    eng, _ = fused_engine(d)
+    b, n = 8, 3000
+    rg, rl = torch.from_numpy(synth.global_feats(b, d, tag="gq")).cuda(), torch.from_numpy(synth.local_feats(b, d, tag="gql")).cuda()
+    tg, ts = torch.from_numpy(synth.global_feats(b, d, tag="gt")).cuda(), torch.from_numpy(synth._normal(1, "gts", (b, 77, d))).cuda()
+    gal = eng.index_fuse(torch.from_numpy(synth.global_feats(n, d, tag="gg")), torch.from_numpy(synth.local_feats(n, d, tag="ggl")), True)
+
+    def step():
+        q = eng.dvr_fuse(rg, rl, tg, ts)
+        return eng.sim_topk(q, gal, 50)
+
+    ref_s, ref_i = step()                       # warm-up: allocates workspaces, tunes tiles
+    step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_s, out_i = step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_i, ref_i) and torch.equal(out_s, ref_s)
+    rg.mul_(-1.0)                                # new inputs in the captured buffers -> new results on replay
+    graph.replay()
+    torch.cuda.synchronize()
+    exp_s, exp_i = step()
+    assert torch.equal(out_i, exp_i) and torch.equal(out_s, exp_s) and not torch.equal(exp_i, ref_i)
+
+
+def test_pipeline_lanes_are_bit_identical_to_serial():
+    """ComposedQueryPipeline: batches in flight on several HIP streams (forked contexts sharing one set of weights)."""
+    from fashionern_aaai2024_amd.clip_model import create_model
+    from fashionern_aaai2024_amd.model import ERN
+    from fashionern_aaai2024_amd.pipeline import ComposedQueryPipeline
+    cfg = synth.CLIP_CONFIGS["tiny"]
+    d = cfg.embed_dim
+    clip = create_model(cfg, device="cuda:0", seed=3)
+    model = ERN(clip, d, "cuda:0", engine=clip.engine).init_random(4)
+    eng = model.engine
+    gal = eng.index_fuse(torch.from_numpy(synth.global_feats(5000, d, tag="pg")), torch.from_numpy(synth.local_feats(5000, d, tag="pgl")), True)
+    batches = []
+    for j in range(7):
+        batches.append((torch.from_numpy(synth.images(9, cfg, 100 + j)).cuda(), torch.from_numpy(synth.captions(9, cfg, 100 + j)).cuda(),
+                        torch.from_numpy(synth.local_feats(9, d, 100 + j)).cuda()))
+    serial = []
+    for im, tk, lc in batches:
+        q = eng.dvr_fuse(eng.encode_image(im), lc, *eng.encode_text(tk))
+        serial.append(eng.sim_topk(q, gal, 20))
+    pipe = ComposedQueryPipeline(eng, lanes=3)
+    for _ in range(2):                                   # twice: lanes are reused with warm workspaces
+        futures = [pipe.submit(im, tk, lc, gal, 20) for im, tk, lc in batches]
+        for (rs, ri), fut in zip(serial, futures):
+            s, i = fut.wait()
+            torch.cuda.current_stream().synchronize()
+            assert torch.equal(i, ri) and torch.equal(s, rs)
+    pipe.close()
+    clip.engine.close()
