@@ -13,7 +13,8 @@ c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 class ClipConfigC(C.Structure):
     _fields_ = [(n, c_int) for n in (
         "embed_dim", "image_size", "patch_size", "v_width", "v_layers", "v_heads", "v_mlp",
-        "context_length", "vocab_size", "t_width", "t_heads", "t_layers", "t_mlp")]
+        "context_length", "vocab_size", "t_width", "t_heads", "t_layers", "t_mlp", "v_arch")] + [
+        ("r_layers", c_int * 4), ("r_width", c_int), ("r_heads", c_int)]
 
 
 class ProfStats(C.Structure):

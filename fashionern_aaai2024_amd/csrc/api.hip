@@ -3,6 +3,7 @@
 // reference interface each entry point replaces.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -68,8 +69,19 @@ struct FusionW {
     CombinerW comb[4];  // fern_combiner_id
 };
 struct ClipBlockW { LNW ln1, ln2; LinearW qkv, out, fc, proj; };
+struct ConvW { const float* w = nullptr; const float* b = nullptr; int cout = 0, k = 0; };   // BatchNorm folded; w [cout][k]
+struct BottleneckW { ConvW c1, c2, c3, down; bool has_down = false; int stride = 1, cin = 0, planes = 0; };
+struct ResNetW {
+    ConvW stem1, stem2, stem3;
+    int stem_c = 0;              // stem channel count padded to a multiple of 16 (RN50x4: 40 -> 48)
+    std::vector<BottleneckW> blocks;
+    const float* pos = nullptr;
+    LinearW q, kv, cproj;
+    const float* zeros = nullptr;
+};
 struct ClipW {
     bool ready = false;
+    ResNetW res;
     fern_clip_config cfg{};
     const float *conv_w = nullptr, *cls = nullptr, *vpos = nullptr, *vproj_t = nullptr;
     LNW ln_pre, ln_post, ln_final;
@@ -419,6 +431,76 @@ static int up_clip_block(fern_ctx* c, const std::string& p, int width, int mlp, 
     return up_linear(c, p + ".mlp.c_proj", width, mlp, &B->proj);
 }
 
+// conv (no bias) + BatchNorm(eval) -> [cout_pad][kh*kw*cin_pad] weights in (ky, kx, ci) order (or the original (ci, ky, kx)
+// order for the direct stem kernel) with the BN scale folded in, and a bias vector; padded rows / channels are zero.
+static int up_conv_bn(fern_ctx* c, const std::string& conv, const std::string& bn, int cout, int cin, int ks, int cout_pad, int cin_pad,
+                      bool tap_major, ConvW* out) {
+    const HostTensor *w, *g, *b, *rm, *rv;
+    FERN_TRY(need(c, conv + ".weight", {cout, cin, ks, ks}, &w));
+    FERN_TRY(need(c, bn + ".weight", {cout}, &g));
+    FERN_TRY(need(c, bn + ".bias", {cout}, &b));
+    FERN_TRY(need(c, bn + ".running_mean", {cout}, &rm));
+    FERN_TRY(need(c, bn + ".running_var", {cout}, &rv));
+    const int K = ks * ks * cin_pad;
+    std::vector<float> wf((size_t)cout_pad * K, 0.f), bf(cout_pad, 0.f);
+    for (int o = 0; o < cout; ++o) {
+        const float sc = g->f[o] / std::sqrt(rv->f[o] + 1e-5f);
+        bf[o] = b->f[o] - rm->f[o] * sc;
+        for (int i = 0; i < cin; ++i)
+            for (int ky = 0; ky < ks; ++ky)
+                for (int kx = 0; kx < ks; ++kx) {
+                    const float v = w->f[(((size_t)o * cin + i) * ks + ky) * ks + kx] * sc;
+                    const size_t k = tap_major ? ((size_t)(ky * ks + kx) * cin_pad + i) : (((size_t)i * ks + ky) * ks + kx);
+                    wf[(size_t)o * K + k] = v;
+                }
+    }
+    FERN_TRY(upload(c, wf.data(), wf.size(), &out->w));
+    FERN_TRY(upload(c, bf.data(), bf.size(), &out->b));
+    out->cout = cout_pad;
+    out->k = K;
+    return FERN_OK;
+}
+
+static int finalize_resnet(fern_ctx* c, const fern_clip_config* cfg) {
+    ResNetW& R = c->clip.res;
+    R = ResNetW();
+    const int w = cfg->r_width, half = w / 2;
+    if (w <= 0 || w % 16 || cfg->image_size % 32 || cfg->r_heads <= 0) return fail(FERN_ERR_ARG, "clip: unsupported ModifiedResNet shape");
+    const int embed = w * 32, hd = embed / cfg->r_heads, tokens = (cfg->image_size / 32) * (cfg->image_size / 32) + 1;
+    if (embed % cfg->r_heads || hd % 4 || hd > 96 || tokens > 224) return fail(FERN_ERR_ARG, "clip: unsupported attention-pool shape");
+    R.stem_c = (half + 15) / 16 * 16;
+    std::vector<float> z(64, 0.f);
+    FERN_TRY(upload(c, z.data(), z.size(), &R.zeros));
+    FERN_TRY(up_conv_bn(c, "visual.conv1", "visual.bn1", half, 3, 3, R.stem_c, 3, false, &R.stem1));
+    FERN_TRY(up_conv_bn(c, "visual.conv2", "visual.bn2", half, half, 3, R.stem_c, R.stem_c, true, &R.stem2));
+    FERN_TRY(up_conv_bn(c, "visual.conv3", "visual.bn3", w, half, 3, w, R.stem_c, true, &R.stem3));
+    int inplanes = w;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = w << li;
+        for (int bi = 0; bi < cfg->r_layers[li]; ++bi) {
+            const std::string p = "visual.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+            BottleneckW B;
+            B.stride = (bi == 0 && li > 0) ? 2 : 1;
+            B.cin = inplanes;
+            B.planes = planes;
+            FERN_TRY(up_conv_bn(c, p + ".conv1", p + ".bn1", planes, inplanes, 1, planes, inplanes, true, &B.c1));
+            FERN_TRY(up_conv_bn(c, p + ".conv2", p + ".bn2", planes, planes, 3, planes, planes, true, &B.c2));
+            FERN_TRY(up_conv_bn(c, p + ".conv3", p + ".bn3", planes * 4, planes, 1, planes * 4, planes, true, &B.c3));
+            B.has_down = B.stride > 1 || inplanes != planes * 4;
+            if (B.has_down)
+                FERN_TRY(up_conv_bn(c, p + ".downsample.0", p + ".downsample.1", planes * 4, inplanes, 1, planes * 4, inplanes, true, &B.down));
+            R.blocks.push_back(B);
+            inplanes = planes * 4;
+        }
+    }
+    if (inplanes != embed) return fail(FERN_ERR_ARG, "clip: ModifiedResNet needs four non-empty stages");
+    FERN_TRY(up_key(c, "visual.attnpool.positional_embedding", {tokens, embed}, &R.pos));
+    FERN_TRY(up_linear(c, "visual.attnpool.q_proj", embed, embed, &R.q));
+    FERN_TRY(up_packed(c, {"visual.attnpool.k_proj", "visual.attnpool.v_proj"}, embed, embed, &R.kv));
+    FERN_TRY(up_linear(c, "visual.attnpool.c_proj", cfg->embed_dim, embed, &R.cproj));
+    return FERN_OK;
+}
+
 extern "C" int fern_finalize_clip(fern_ctx* c, const fern_clip_config* cfg) {
     if (!c || !cfg) return fail(FERN_ERR_ARG, "fern_finalize_clip: NULL argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -429,7 +511,9 @@ extern "C" int fern_finalize_clip(fern_ctx* c, const fern_clip_config* cfg) {
     if (cfg->embed_dim <= 0 || cfg->embed_dim % 4 || cfg->embed_dim > 1024) return fail(FERN_ERR_ARG, "clip: unsupported embed_dim");
     if (cfg->t_layers > 0 && (bad(cfg->t_width, cfg->t_heads) || cfg->t_mlp % 32 || cfg->context_length > 96))
         return fail(FERN_ERR_ARG, "clip: unsupported text tower shape");
-    if (cfg->v_layers > 0) {
+    if (cfg->v_arch == 1) {
+        FERN_TRY(finalize_resnet(c, cfg));
+    } else if (cfg->v_layers > 0) {
         const int g = cfg->patch_size > 0 ? cfg->image_size / cfg->patch_size : 0;
         if (bad(cfg->v_width, cfg->v_heads) || cfg->v_mlp % 32 || cfg->patch_size % 4 || g * cfg->patch_size != cfg->image_size ||
             (3 * cfg->patch_size * cfg->patch_size) % 32 || g * g + 1 > 224)
@@ -726,19 +810,100 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
     return run_gemm(c, gemm_desc(CLS, vw, proj, out, cf.embed_dim, b, EPI_BIAS), s);
 }
 
+// ---- open_clip ModifiedResNet (RN50x4).  Activations are NHWC, so every 1x1 convolution is a plain GEMM over the pixel
+// rows, every 3x3 convolution the same GEMM with the 3x3-window A loader, BatchNorm is folded into the weights and the
+// ReLU / residual add live in the GEMM epilogue.
+static GemmParams conv_desc(const float* A, const ConvW& W, float* C, int M, int epi) {
+    GemmParams p{};
+    p.A = A; p.lda = W.k; p.W = W.w; p.ldw = W.k; p.bias = W.b; p.C = C; p.ldc = W.cout;
+    p.M = M; p.N = W.cout; p.K = W.k; p.epi = epi; p.aload = ALOAD_PLAIN;
+    return p;
+}
+static int conv3x3(fern_ctx* c, const float* A, const ConvW& W, float* C, int b, int H, int Wd, int cin, hipStream_t s) {
+    GemmParams p = conv_desc(A, W, C, b * H * Wd, EPI_BIAS_RELU);
+    p.aload = ALOAD_CONV3; p.conv_h = H; p.conv_w = Wd; p.conv_c = cin; p.zeros = c->clip.res.zeros;
+    return run_gemm(c, p, s);
+}
+
+static int resnet_chunk(fern_ctx* c, const float* images, float* out, int b, hipStream_t s) {
+    const ClipW& W = c->clip;
+    const ResNetW& R = W.res;
+    const fern_clip_config& cf = W.cfg;
+    const int S = cf.image_size, s1 = S / 2, w = cf.r_width;
+    // one arena slot sized for the largest activation of the tower, six of them reused round-robin
+    size_t max_act = (size_t)b * s1 * s1 * std::max(R.stem_c, w);
+    {
+        int H = S / 4;
+        for (const auto& B : R.blocks) {
+            max_act = std::max(max_act, (size_t)b * H * H * std::max(B.cin, B.planes * 4));
+            if (B.stride > 1) H /= 2;
+        }
+    }
+    {
+        const int hf = S / 32;
+        max_act = std::max(max_act, (size_t)b * (hf * hf + 1) * 2 * (size_t)(w * 32));      // attention-pool K/V
+    }
+    float* buf[6];
+    for (auto& p : buf) FERN_TRY(ws_get(c, max_act, &p));
+    // stem
+    HIP_TRY(launch_stem_conv(images, R.stem1.w, R.stem1.b, buf[0], b, S, R.stem_c, s));
+    FERN_TRY(conv3x3(c, buf[0], R.stem2, buf[1], b, s1, s1, R.stem_c, s));
+    FERN_TRY(conv3x3(c, buf[1], R.stem3, buf[0], b, s1, s1, R.stem_c, s));
+    HIP_TRY(launch_avgpool_nhwc(buf[0], buf[1], b, s1, s1, w, 2, s));
+    float* X = buf[1];
+    float* OUT = buf[0];
+    int H = S / 4;
+    for (const auto& B : R.blocks) {
+        const int rows = b * H * H, Ho = H / B.stride, rows_o = b * Ho * Ho;
+        float *T1 = buf[2], *T2 = buf[3], *TP = buf[4], *ID = buf[5];
+        FERN_TRY(run_gemm(c, conv_desc(X, B.c1, T1, rows, EPI_BIAS_RELU), s));                    // 1x1 + BN + ReLU
+        FERN_TRY(conv3x3(c, T1, B.c2, T2, b, H, H, B.planes, s));                                  // 3x3 + BN + ReLU
+        const float* t2 = T2;
+        const float* xin = X;
+        if (B.stride > 1) {
+            HIP_TRY(launch_avgpool_nhwc(T2, T1, b, H, H, B.planes, B.stride, s));                  // anti-aliasing avg-pool
+            t2 = T1;
+            HIP_TRY(launch_avgpool_nhwc(X, TP, b, H, H, B.cin, B.stride, s));
+            xin = TP;
+        }
+        const float* identity = X;
+        if (B.has_down) {
+            FERN_TRY(run_gemm(c, conv_desc(xin, B.down, ID, rows_o, EPI_BIAS), s));                // shortcut: [avg-pool] + 1x1 + BN
+            identity = ID;
+        }
+        GemmParams p3 = conv_desc(t2, B.c3, OUT, rows_o, EPI_BIAS_RESIDUAL_RELU);                  // 1x1 + BN + identity + ReLU
+        p3.R = identity;
+        FERN_TRY(run_gemm(c, p3, s));
+        std::swap(X, OUT);
+        H = Ho;
+    }
+    // AttentionPool2d: NHWC rows of one image are already its HW tokens
+    const int HW = H * H, E = w * 32, heads = cf.r_heads, hd = E / heads;
+    float *T = buf[2], *T0 = buf[3], *MEAN = buf[3] + (size_t)b * E, *KV = buf[4], *Q = buf[5], *ATT = buf[5] + (size_t)b * E;
+    HIP_TRY(launch_attnpool_tokens(X, MEAN, R.pos, T, T0, b, HW, E, s));
+    FERN_TRY(run_gemm(c, gemm_desc(T, E, R.kv, KV, 2 * E, b * (HW + 1), EPI_BIAS), s));
+    FERN_TRY(run_gemm(c, gemm_desc(T0, E, R.q, Q, E, b, EPI_BIAS), s));
+    AttnParams a{Q, KV, KV + E, ATT, (long)E, 2L * E, 2L * E, (long)E, b, heads, hd, 1, HW + 1, 0, 1.0f / std::sqrt((float)hd)};
+    FERN_TRY(run_attention(c, a, s));
+    return run_gemm(c, gemm_desc(ATT, E, R.cproj, out, cf.embed_dim, b, EPI_BIAS), s);
+}
+
 extern "C" int fern_vit_encode_image(fern_ctx* c, const float* images, float* out, int b, void* stream) {
     if (!c) return fail(FERN_ERR_ARG, "fern_vit_encode_image: ctx is NULL");
-    if (!c->clip.ready || c->clip.cfg.v_layers <= 0) return fail(FERN_ERR_STATE, "fern_vit_encode_image: image tower not finalised (fern_finalize_clip)");
+    if (!c->clip.ready || (c->clip.cfg.v_arch == 0 && c->clip.cfg.v_layers <= 0))
+        return fail(FERN_ERR_STATE, "fern_vit_encode_image: image tower not finalised (fern_finalize_clip)");
     if (b < 0 || (b && (!images || !out))) return fail(FERN_ERR_ARG, "fern_vit_encode_image: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     const fern_clip_config& cf = c->clip.cfg;
     const long img_sz = 3L * cf.image_size * cf.image_size;
-    const int CH = 64;
+    const bool resnet = cf.v_arch == 1;
+    const int CH = resnet ? 32 : 64;
     for (int o = 0; o < b; o += CH) {
         const int m = std::min(CH, b - o);
         FERN_TRY(ws_begin(c, s));
-        FERN_TRY(vit_chunk(c, images + o * img_sz, out + (long)o * cf.embed_dim, m, s));
+        if (resnet) FERN_TRY(resnet_chunk(c, images + o * img_sz, out + (long)o * cf.embed_dim, m, s));
+        else FERN_TRY(vit_chunk(c, images + o * img_sz, out + (long)o * cf.embed_dim, m, s));
     }
     return FERN_OK;
 }

@@ -267,6 +267,81 @@ __global__ __launch_bounds__(256) void gather_scores_kernel(const float* q, cons
     if (lane == 0) out[item] = s;
 }
 
+// ---- ModifiedResNet (open_clip RN50x4 image tower) helpers -------------------------------------------------------
+// Stem conv1: 3 input channels -> K = 27, far too thin for MFMA; a direct convolution (0.1 % of the tower's flops).
+// One thread = one output pixel x 4 output channels; NCHW image in, NHWC activation out, BatchNorm folded, ReLU.
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* img, const float* w, const float* bias, float* out, int B, int S,
+                                                        int cout) {
+    const int So = S / 2, c4n = cout / 4;
+    const long total = (long)B * So * So * c4n;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c4 = (int)(t % c4n);
+    const long pix = t / c4n;
+    const int x = (int)(pix % So), y = (int)((pix / So) % So), b = (int)(pix / ((long)So * So));
+    f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = 2 * y + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = 2 * x + kx - 1;
+                float v = 0.f;
+                if (yy >= 0 && yy < S && xx >= 0 && xx < S) v = img[(((long)b * 3 + c) * S + yy) * S + xx];
+                const int k = (c * 3 + ky) * 3 + kx;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, w[(c4 * 4 + e) * 27 + k], acc[e]);
+            }
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+    *reinterpret_cast<f32x4*>(out + pix * cout + c4 * 4) = acc;
+}
+
+__global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const float* x, float* y, int B, int H, int W, int C, int k) {
+    const int Ho = H / k, Wo = W / k, c4n = C / 4;
+    const long total = (long)B * Ho * Wo * c4n;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c4 = (int)(t % c4n);
+    const long pix = t / c4n;
+    const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int dy = 0; dy < k; ++dy)
+        for (int dx = 0; dx < k; ++dx)
+            acc += *reinterpret_cast<const f32x4*>(x + (((long)b * H + yo * k + dy) * W + xo * k + dx) * C + c4 * 4);
+    acc = acc * (1.0f / (float)(k * k));
+    *reinterpret_cast<f32x4*>(y + pix * C + c4 * 4) = acc;
+}
+
+// mean over the HW tokens of each image (any width C % 4 == 0): one thread per (image, 4 channels)
+__global__ __launch_bounds__(256) void mean_tokens_kernel(const float* x, float* mean, int B, int HW, int C) {
+    const int c4n = C / 4;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * c4n) return;
+    const int c4 = (int)(t % c4n), b = (int)(t / c4n);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < HW; ++i) acc += *reinterpret_cast<const f32x4*>(x + ((long)b * HW + i) * C + c4 * 4);
+    *reinterpret_cast<f32x4*>(mean + (long)b * C + c4 * 4) = acc * (1.0f / (float)HW);
+}
+
+__global__ __launch_bounds__(256) void attnpool_tokens_kernel(const float* x, const float* mean, const float* pos, float* T, float* T0,
+                                                              int B, int HW, int C) {
+    const int c4n = C / 4;
+    const long total = (long)B * (HW + 1) * c4n;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c4 = (int)(t % c4n);
+    const long row = t / c4n;
+    const int tok = (int)(row % (HW + 1)), b = (int)(row / (HW + 1));
+    const float* src = tok == 0 ? mean + (long)b * C : x + ((long)b * HW + tok - 1) * C;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + c4 * 4) + *reinterpret_cast<const f32x4*>(pos + (long)tok * C + c4 * 4);
+    *reinterpret_cast<f32x4*>(T + row * C + c4 * 4) = v;
+    if (tok == 0) *reinterpret_cast<f32x4*>(T0 + (long)b * C + c4 * 4) = v;      // compact copy of the query (mean) token
+}
+
 static inline bool bad_width(int d) { return d <= 0 || (d & 3) || d > 64 * 4 * MAXV; }
 static inline dim3 row_grid(long rows) { return dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)); }
 
@@ -330,6 +405,28 @@ hipError_t launch_sr_finalize(const float* partial, int nb, const float* bc, con
     if (n <= 0) return hipSuccess;
     if (bad_width(d)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sr_finalize_kernel, row_grid(n), dim3(256), 0, s, partial, nb, bc, local, out, n, d);
+    return hipGetLastError();
+}
+hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, float* out, int B, int S, int cout_pad, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if ((S & 1) || (cout_pad & 3)) return hipErrorInvalidValue;
+    const long total = (long)B * (S / 2) * (S / 2) * (cout_pad / 4);
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, w, bias, out, B, S, cout_pad);
+    return hipGetLastError();
+}
+hipError_t launch_avgpool_nhwc(const float* x, float* y, int B, int H, int W, int C, int k, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if ((C & 3) || k < 1 || H % k || W % k) return hipErrorInvalidValue;
+    const long total = (long)B * (H / k) * (W / k) * (C / 4);
+    hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, B, H, W, C, k);
+    return hipGetLastError();
+}
+hipError_t launch_attnpool_tokens(const float* x, float* mean, const float* pos, float* T, float* T0, int B, int HW, int C, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (C & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mean_tokens_kernel, dim3((unsigned)(((long)B * (C / 4) + 255) / 256)), dim3(256), 0, s, x, mean, B, HW, C);
+    const long total = (long)B * (HW + 1) * (C / 4);
+    hipLaunchKernelGGL(attnpool_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, mean, pos, T, T0, B, HW, C);
     return hipGetLastError();
 }
 hipError_t launch_gather_scores(const float* q, const float* gallery, const int* idx, float* out, int B, int m, int d, hipStream_t s) {

@@ -48,7 +48,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                                               int wm, int wn, int l31, int lh, int tid) {
     const int row_w = bm * BM + wm * WM;
     const int col_w = bn * BN + wn * WN;
-    if (p.epi < EPI_RELU_DOT) {
+    if (!epi_is_reduce(p.epi)) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -68,6 +68,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         case EPI_BIAS_GELU: v = gelu_erf(v); break;
                         case EPI_BIAS_RELU: v = fmaxf(v, 0.0f); break;
                         case EPI_BIAS_RESIDUAL: v += p.R[(long)row * p.ldc + col]; break;
+                        case EPI_BIAS_RESIDUAL_RELU: v = fmaxf(v + p.R[(long)row * p.ldc + col], 0.0f); break;
                         case EPI_COLAFFINE_TANH: v = tanhf(v * sc + sh); break;
                         case EPI_PATCH_EMBED: {
                             const int g2 = p.grid * p.grid;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
 // 16 consecutive 64-byte tile rows, lane-linear, so the bank-conflict swizzle is applied on the per-lane SOURCE
 // address: the 16-byte chunk c of tile row r is stored at chunk position c ^ ((r >> 2) & 3), and the fragment reads
 // XOR the same value (conflict-free for the 16-lane groups of ds_read_b128).
-template <int BM, int BN, int WM, int WN, int BKT, int MINW>
+template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool CONV = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_glds_kernel(GemmParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
@@ -302,15 +303,26 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
 
     // per-lane source row pointers (already offset by the swizzled 16-byte chunk) for this wave's pieces
     const float* src[PPW];
+    int cb[PPW], cy[PPW], cx[PPW];                             // CONV: (image, y, x) of this lane's output pixel
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int piece = wave + NW * j;                       // wave-uniform
         const int trow = piece * RPP + lane / C4;              // row in the [A; W] tile-row space (BM, BN multiples of 32)
         const int chunk = (lane & FMASK) ^ ((trow >> FSH) & FMASK);   // logical chunk stored at position lane % C4
+        cb[j] = cy[j] = cx[j] = 0;
         if (trow < BM) {
             int row = bm * BM + trow;
             row = row < p.M ? row : p.M - 1;
-            src[j] = p.A + (long)row * p.lda + chunk * 4;
+            if (CONV) {
+                const int hw = p.conv_h * p.conv_w;
+                cb[j] = row / hw;
+                const int rem = row - cb[j] * hw;
+                cy[j] = rem / p.conv_w;
+                cx[j] = rem - cy[j] * p.conv_w;
+                src[j] = p.A + chunk * 4;
+            } else {
+                src[j] = p.A + (long)row * p.lda + chunk * 4;
+            }
         } else {
             int row = bn * BN + (trow - BM);
             row = row < p.N ? row : p.N - 1;
@@ -318,10 +330,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
         }
     }
     auto stage = [&](int buf, int k0) {
+        int ky = 0, kx = 0, c0 = 0;
+        if (CONV) {                                            // a 16/32-wide k tile lies inside one filter tap (conv_c % BKT == 0)
+            const int tap = k0 / p.conv_c;
+            c0 = k0 - tap * p.conv_c;
+            ky = tap / 3 - 1;
+            kx = tap - (tap / 3) * 3 - 1;
+        }
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int piece = wave + NW * j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + k0),
+            const float* g = src[j] + k0;
+            if (CONV && piece * RPP < BM) {                    // wave-uniform: this piece holds A (activation) rows
+                const int yy = cy[j] + ky, xx = cx[j] + kx;
+                const bool inside = yy >= 0 && yy < p.conv_h && xx >= 0 && xx < p.conv_w;
+                g = inside ? src[j] + (((long)cb[j] * p.conv_h + yy) * p.conv_w + xx) * p.conv_c + c0 : p.zeros + (lane & 3) * 4;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(&lds[buf][piece * 256]), 16, 0, 0);
         }
     };
@@ -415,12 +440,12 @@ static int choose_cfg(int M, int N, int K, bool reduce = false) {
     if (reduce) {
         // Reduce epilogues sum over columns: only the 128-column-block / 64-column-wave shapes are used (configs 0/1 and
         // 8/9) so that the column summation order -- and with it every output row -- is independent of M (batch-invariant).
-        const int base = (f >= 8 || (f < 0 && M >= 1024)) ? 8 : 0;
+        const int base = (f >= 8 || (f < 0 && M >= 1024) || (K & 31)) ? 8 : 0;
         return best_of(M, N, base, base + 2);
     }
     if (f >= 0 && f < kNumCfgs && K % kCfgs[f].bk == 0) return f;
     if (f >= 100) return best_of(M, N, 8, 12);
-    return M >= 1024 ? best_of(M, N, 8, 12) : best_of(M, N, 0, kNumAuto);
+    return (M >= 1024 || (K & 31)) ? best_of(M, N, 8, 12) : best_of(M, N, 0, kNumAuto);   // K % 32 != 0: only the 16-wide k tiles fit
 }
 
 int gemm_num_col_blocks(int M, int N, int K) {
@@ -430,6 +455,16 @@ int gemm_num_col_blocks(int M, int N, int K) {
 
 static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((p.N + kCfgs[c].bn - 1) / kCfgs[c].bn);
+    if (p.aload == ALOAD_CONV3) {      // 3x3 window loader exists for the LDS-DMA family only
+        switch (c) {
+            case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+            case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+            case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+            case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (c) {
         case 0: hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 64, 64, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
         case 1: hipLaunchKernelGGL((gemm_f32_kernel<64, 128, 32, 64, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
@@ -492,7 +527,8 @@ static int tune_shape(const GemmParams& p, hipStream_t s) {
     float best_ms = 1e30f;
     static const int cands[] = {0, 1, 2, 3, 8, 9, 10, 11};
     for (int c : cands) {
-        if (c >= 8 && p.aload != ALOAD_PLAIN) continue;
+        if (c >= 8 && p.aload == ALOAD_IM2COL) continue;
+        if (c < 8 && p.aload == ALOAD_CONV3) continue;
         if (p.K % kCfgs[c].bk) continue;
         if (launch_cfg(c, q, s) != hipSuccess) continue;                 // warm
         (void)hipEventRecord(e0, s);
@@ -512,11 +548,12 @@ static int tune_shape(const GemmParams& p, hipStream_t s) {
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
-    if (p.K <= 0 || (p.K % 32) != 0 || (p.ldw & 3) || (p.aload == ALOAD_PLAIN && (p.lda & 3))) return hipErrorInvalidValue;
+    if (p.K <= 0 || (p.K % 16) != 0 || (p.ldw & 3) || (p.aload == ALOAD_PLAIN && (p.lda & 3))) return hipErrorInvalidValue;
+    if (p.aload == ALOAD_CONV3 && (p.conv_c % 16 || p.K != 9 * p.conv_c || !p.zeros || p.M % (p.conv_h * p.conv_w))) return hipErrorInvalidValue;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return hipErrorInvalidValue;
     if (p.aload == ALOAD_IM2COL && ((p.patch & 3) || (p.img & 3))) return hipErrorInvalidValue;
-    int c = choose_cfg(p.M, p.N, p.K, p.epi >= EPI_RELU_DOT);
-    const bool tunable = forced_cfg() < 0 && tuning_enabled() && p.epi < EPI_RELU_DOT && 2.0 * p.M * (double)p.N * p.K >= 2.5e8;
+    int c = choose_cfg(p.M, p.N, p.K, epi_is_reduce(p.epi));
+    const bool tunable = forced_cfg() < 0 && tuning_enabled() && !epi_is_reduce(p.epi) && 2.0 * p.M * (double)p.N * p.K >= 2.5e8;
     if (tunable) {
         const ShapeKey key{p.M, p.N, p.K, p.epi, p.aload};
         std::lock_guard<std::mutex> lock(g_tuned_mu);
@@ -524,7 +561,8 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
         if (it == g_tuned.end()) it = g_tuned.emplace(key, tune_shape(p, s)).first;
         c = it->second;
     }
-    if (c >= 8 && p.aload != ALOAD_PLAIN) c -= 8;          // the LDS-DMA kernels take plain row-major A only
+    if (p.aload == ALOAD_CONV3 && (c < 8 || c > 11)) c = 8 + (c & 3);     // 3x3 window: LDS-DMA family only
+    if (c >= 8 && p.aload == ALOAD_IM2COL) c -= 8;                        // patch loader: register-staged family only
     return launch_cfg(c, p, s);
 }
 

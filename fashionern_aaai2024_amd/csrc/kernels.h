@@ -15,10 +15,14 @@ enum GemmEpi : int {
     EPI_COLAFFINE_TANH = 4,  // C = tanh((acc + bias[col]) * aux0[col] + aux1[col])   (Linear + BatchNorm1d(D) eval + Tanh)
     EPI_PATCH_EMBED = 5,     // C[(row + row/G2 + 1)] = acc + aux0[((row % G2) + 1)*N + col]   (conv1 patches + pos-emb, cls slot skipped)
     EPI_RELU_DOT = 6,        // partial[row][nb] = sum_col relu(acc + bias[col]) * aux0[col]       (Combiner hidden layer . w2)
-    EPI_SR_LOCAL = 7         // p = row % 13: v = tanh((acc + bias[col] - aux1[p]) * aux2[p] + aux3[p]);
+    EPI_SR_LOCAL = 7,        // p = row % 13: v = tanh((acc + bias[col] - aux1[p]) * aux2[p] + aux3[p]);
                              // partial[row][nb] = sum_col v * G[(row/13)*ldg + col] * aux0[col]     (VisualSR local branch)
+    EPI_BIAS_RESIDUAL_RELU = 8  // C = relu(acc + bias + R[row*ldc + col])   (ResNet bottleneck tail: conv3 + BN folded + identity)
 };
-enum GemmALoad : int { ALOAD_PLAIN = 0, ALOAD_IM2COL = 1 };
+__host__ __device__ inline bool epi_is_reduce(int e) { return e == EPI_RELU_DOT || e == EPI_SR_LOCAL; }
+// ALOAD_IM2COL: non-overlapping patches of an NCHW image (ViT conv1); ALOAD_CONV3: 3x3 / stride 1 / pad 1 window over an
+// NHWC activation [B, conv_h, conv_w, conv_c] (k = (ky*3 + kx)*conv_c + c), out-of-image taps read from `zeros`.
+enum GemmALoad : int { ALOAD_PLAIN = 0, ALOAD_IM2COL = 1, ALOAD_CONV3 = 2 };
 
 struct GemmParams {
     const float* A;
@@ -36,6 +40,8 @@ struct GemmParams {
     int M, N, K;
     int epi, aload;
     int img, patch, grid;  // ALOAD_IM2COL: image side, patch side, patches per side; EPI_PATCH_EMBED uses grid*grid
+    int conv_h, conv_w, conv_c;   // ALOAD_CONV3
+    const float* zeros;           // ALOAD_CONV3: >= 64 bytes of zeros (16-byte aligned)
 };
 // Number of column blocks the reduce epilogues write per row (depends on the tile chosen for this shape).
 int gemm_num_col_blocks(int M, int N, int K);
@@ -76,6 +82,13 @@ hipError_t launch_combiner_finalize(const float* partial, int nb, const float* b
 // VisualSR tail: logits[p] = sum_nb partial[row*13+p][nb] + bc; w = softmax_13; new = sum w_p local_p; out = new/(||new||+1e-8)
 hipError_t launch_sr_finalize(const float* partial, int nb, const float* bc, const float* local, float* out,
                               long n, int d, hipStream_t s);
+// ModifiedResNet stem conv1: 3x3 / stride 2 / pad 1 from NCHW [B,3,S,S] to NHWC [B,S/2,S/2,cout_pad], folded BN + ReLU
+hipError_t launch_stem_conv(const float* img, const float* w /*[cout_pad,27] (c,ky,kx)*/, const float* bias, float* out, int B, int S,
+                            int cout_pad, hipStream_t s);
+// NHWC average pool k x k, stride k: [B,H,W,C] -> [B,H/k,W/k,C]
+hipError_t launch_avgpool_nhwc(const float* x, float* y, int B, int H, int W, int C, int k, hipStream_t s);
+// AttentionPool2d tokens: mean[b] = mean_t x[b,t]; T[b,0] = mean[b] + pos[0]; T[b,1+t] = x[b,t] + pos[1+t]; T0[b] = T[b,0]
+hipError_t launch_attnpool_tokens(const float* x, float* mean, const float* pos, float* T, float* T0, int B, int HW, int C, hipStream_t s);
 // scores[b, j] = q[b] . gallery[idx[b, j]]  (idx < 0 -> -inf)
 hipError_t launch_gather_scores(const float* q, const float* gallery, const int* idx, float* out, int B, int m, int d,
                                 hipStream_t s);

@@ -105,7 +105,8 @@ class FernEngine:
 
     def finalize_clip(self, cfg: ClipConfig) -> None:
         cc = _lib.ClipConfigC(cfg.embed_dim, cfg.image_size, cfg.patch_size, cfg.v_width, cfg.v_layers, cfg.v_heads,
-                              cfg.v_mlp, cfg.context_length, cfg.vocab_size, cfg.t_width, cfg.t_heads, cfg.t_layers, cfg.t_mlp)
+                              cfg.v_mlp, cfg.context_length, cfg.vocab_size, cfg.t_width, cfg.t_heads, cfg.t_layers, cfg.t_mlp,
+                              1 if cfg.v_arch == "resnet" else 0, (C.c_int * 4)(*cfg.r_layers), cfg.r_width, cfg.r_heads)
         _lib.check(self.lib.fern_finalize_clip(self._h, C.byref(cc)), "fern_finalize_clip")
         self.clip_cfg = cfg
 

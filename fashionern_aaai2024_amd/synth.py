@@ -129,6 +129,11 @@ class ClipConfig:
     t_heads: int
     t_layers: int
     t_mlp: int
+    # image tower architecture: "vit" (above) or "resnet" = open_clip ModifiedResNet (RN50x4: layers (4,6,10,6), width 80)
+    v_arch: str = "vit"
+    r_layers: tuple = (0, 0, 0, 0)
+    r_width: int = 0
+    r_heads: int = 0
 
     @property
     def grid(self) -> int:
@@ -142,12 +147,46 @@ class ClipConfig:
 CLIP_CONFIGS = {
     # open_clip "ViT-B-16" (run/test/test_fiq.py:134 default --clip-model-name)
     "ViT-B-16": ClipConfig("ViT-B-16", 512, 224, 16, 768, 12, 12, 3072, 77, 49408, 512, 8, 12, 2048),
-    # text tower of open_clip "RN50x4" (image tower = ModifiedResNet, SURVEY.md 8f rank 1: not built yet)
+    # open_clip "RN50x4" (run/test/test_cirr.py:149 default): ModifiedResNet (4,6,10,6) width 80 @288 px, attention pool 40 heads
+    "RN50x4": ClipConfig("RN50x4", 640, 288, 32, 0, 1, 0, 0, 77, 49408, 640, 10, 12, 2560, "resnet", (4, 6, 10, 6), 80, 40),
     "RN50x4-text": ClipConfig("RN50x4-text", 640, 288, 16, 768, 0, 12, 3072, 77, 49408, 640, 10, 12, 2560),
+    "tiny-resnet": ClipConfig("tiny-resnet", 128, 64, 32, 0, 1, 0, 0, 77, 1000, 128, 4, 2, 512, "resnet", (2, 1, 1, 1), 32, 16),
     # small shapes for tests / fixtures (same arithmetic, seconds on CPU)
     "tiny": ClipConfig("tiny", 128, 64, 16, 128, 2, 4, 512, 77, 1000, 128, 4, 2, 512),
     "tiny-hd64": ClipConfig("tiny-hd64", 64, 48, 16, 192, 2, 3, 384, 77, 600, 128, 2, 2, 256),
 }
+
+
+def _conv_bn(sd, seed, conv, bn, cout, cin, k, gamma=1.0):
+    sd[conv + ".weight"] = _normal(seed, conv + ".weight", (cout, cin, k, k), 1.4 / np.sqrt(cin * k * k))
+    _batchnorm(sd, seed, bn, cout)
+    sd[bn + ".weight"] = (sd[bn + ".weight"] * np.float32(gamma)).astype(np.float32)
+
+
+def _resnet_state(sd, cfg: ClipConfig, seed: int) -> None:
+    """open_clip ModifiedResNet key layout (visual.conv1..3 / bn1..3, visual.layerL.i.{conv1,bn1,...,downsample.0/1}, visual.attnpool.*)."""
+    w = cfg.r_width
+    _conv_bn(sd, seed, "visual.conv1", "visual.bn1", w // 2, 3, 3)
+    _conv_bn(sd, seed, "visual.conv2", "visual.bn2", w // 2, w // 2, 3)
+    _conv_bn(sd, seed, "visual.conv3", "visual.bn3", w, w // 2, 3)
+    inplanes = w
+    for li, nblocks in enumerate(cfg.r_layers):
+        planes = w * (2 ** li)
+        for bi in range(nblocks):
+            p = f"visual.layer{li + 1}.{bi}"
+            stride = 2 if (bi == 0 and li > 0) else 1
+            _conv_bn(sd, seed, p + ".conv1", p + ".bn1", planes, inplanes, 1)
+            _conv_bn(sd, seed, p + ".conv2", p + ".bn2", planes, planes, 3)
+            _conv_bn(sd, seed, p + ".conv3", p + ".bn3", planes * 4, planes, 1, gamma=0.3)   # small residual branch: activations stay O(1)
+            if stride > 1 or inplanes != planes * 4:
+                _conv_bn(sd, seed, p + ".downsample.0", p + ".downsample.1", planes * 4, inplanes, 1)
+            inplanes = planes * 4
+    embed = w * 32
+    tokens = (cfg.image_size // 32) ** 2 + 1
+    sd["visual.attnpool.positional_embedding"] = _normal(seed, "visual.attnpool.positional_embedding", (tokens, embed), 0.5)
+    for n in ("q_proj", "k_proj", "v_proj"):
+        _linear(sd, seed, "visual.attnpool." + n, embed, embed, gain=1.5)
+    _linear(sd, seed, "visual.attnpool.c_proj", cfg.embed_dim, embed)
 
 
 def clip_state_dict(cfg: ClipConfig, seed: int = 0) -> Dict[str, np.ndarray]:
@@ -164,7 +203,9 @@ def clip_state_dict(cfg: ClipConfig, seed: int = 0) -> Dict[str, np.ndarray]:
         _linear(sd, seed, prefix + ".mlp.c_fc", mlp, width)
         _linear(sd, seed, prefix + ".mlp.c_proj", width, mlp, gain=0.7)
 
-    if cfg.v_layers > 0:
+    if cfg.v_arch == "resnet":
+        _resnet_state(sd, cfg, seed)
+    elif cfg.v_layers > 0:
         vw = cfg.v_width
         sd["visual.class_embedding"] = _normal(seed, "visual.class_embedding", (vw,), 0.5)
         sd["visual.positional_embedding"] = _normal(seed, "visual.positional_embedding", (cfg.v_tokens, vw), 0.3)

@@ -71,8 +71,12 @@ typedef enum {
 /* CLIP tower shapes (open_clip model config) */
 typedef struct {
     int embed_dim;
-    int image_size, patch_size, v_width, v_layers, v_heads, v_mlp;   /* v_layers == 0: no image tower */
+    int image_size, patch_size, v_width, v_layers, v_heads, v_mlp;   /* ViT tower; v_layers == 0: none */
     int context_length, vocab_size, t_width, t_heads, t_layers, t_mlp;
+    int v_arch;          /* 0 = ViT (fields above), 1 = open_clip ModifiedResNet (fields below; e.g. RN50x4) */
+    int r_layers[4];     /* bottleneck blocks per stage, RN50x4: 4,6,10,6 */
+    int r_width;         /* stem / stage-1 width, RN50x4: 80 */
+    int r_heads;         /* attention-pool heads, RN50x4: 40 */
 } fern_clip_config;
 
 /* GEMM epilogues exposed for tests and for reference-side composition */

@@ -50,8 +50,53 @@ def _block(sd, prefix, x, heads, causal):
     return x + F.linear(h, sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"])
 
 
+def _bn(sd, prefix, x):
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"], sd[prefix + ".bias"],
+                        training=False, eps=1e-5)
+
+
+def encode_image_resnet(sd, cfg, images):
+    """open_clip 2.20.0 ``ModifiedResNet`` (third party, NOT under /root/reference: environment.yml:114; selected by
+    ``--clip-model-name RN50x4``, run/test/test_cirr.py:149).  PARITY UNPINNED: there is no statement of this tower in
+    the reference tree and the package is not installed, so the published architecture is restated here:
+    3-conv stem (3x3 s2, 3x3, 3x3; BN + ReLU each) + 2x2 avg-pool; Bottleneck blocks (1x1 -> 3x3 -> [avg-pool(stride)]
+    -> 1x1 x4, BN after every conv, avg-pool + 1x1 + BN shortcut, ReLU after the add); AttentionPool2d (mean token
+    prepended, learned positions, one multi-head attention read-out of the mean token, c_proj to embed_dim)."""
+    x = F.relu(_bn(sd, "visual.bn1", F.conv2d(images, sd["visual.conv1.weight"], stride=2, padding=1)))
+    x = F.relu(_bn(sd, "visual.bn2", F.conv2d(x, sd["visual.conv2.weight"], padding=1)))
+    x = F.relu(_bn(sd, "visual.bn3", F.conv2d(x, sd["visual.conv3.weight"], padding=1)))
+    x = F.avg_pool2d(x, 2)
+    for li, nblocks in enumerate(cfg.r_layers):
+        for bi in range(nblocks):
+            p = f"visual.layer{li + 1}.{bi}"
+            stride = 2 if (bi == 0 and li > 0) else 1
+            out = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"])))
+            out = F.relu(_bn(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], padding=1)))
+            if stride > 1:
+                out = F.avg_pool2d(out, stride)
+            out = _bn(sd, p + ".bn3", F.conv2d(out, sd[p + ".conv3.weight"]))
+            identity = x
+            if p + ".downsample.0.weight" in sd:
+                identity = F.avg_pool2d(x, stride) if stride > 1 else x
+                identity = _bn(sd, p + ".downsample.1", F.conv2d(identity, sd[p + ".downsample.0.weight"]))
+            x = F.relu(out + identity)
+    b, c, h, w = x.shape
+    t = x.reshape(b, c, h * w).permute(0, 2, 1)                          # [b, HW, C]
+    t = torch.cat((t.mean(dim=1, keepdim=True), t), dim=1) + sd["visual.attnpool.positional_embedding"]
+    heads = cfg.r_heads
+    hd = c // heads
+    a = "visual.attnpool."
+    q = F.linear(t[:, :1], sd[a + "q_proj.weight"], sd[a + "q_proj.bias"]).view(b, 1, heads, hd).transpose(1, 2) * (hd ** -0.5)
+    k = F.linear(t, sd[a + "k_proj.weight"], sd[a + "k_proj.bias"]).view(b, -1, heads, hd).transpose(1, 2)
+    v = F.linear(t, sd[a + "v_proj.weight"], sd[a + "v_proj.bias"]).view(b, -1, heads, hd).transpose(1, 2)
+    o = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(b, c)
+    return F.linear(o, sd[a + "c_proj.weight"], sd[a + "c_proj.bias"])
+
+
 def encode_image(sd, cfg, images):
     """[b,3,H,W] f32 -> [b,embed_dim] un-normalised (call site utils/utils.py:64)."""
+    if getattr(cfg, "v_arch", "vit") == "resnet":
+        return encode_image_resnet(sd, cfg, images)
     w = sd["visual.conv1.weight"]
     x = F.conv2d(images, w, stride=cfg.patch_size)                      # modeling_clip.py:180-196
     x = x.flatten(2).transpose(1, 2)                                    # [b, g*g, width]

@@ -175,3 +175,28 @@ def test_batch_invariance_of_fusion_rows():
     full = eng.index_fuse(raw, loc, normalize_input=True).cpu()
     for a, b in ((0, 1), (5, 70), (100, 1124), (1990, 2000)):
         assert torch.equal(eng.index_fuse(raw[a:b], loc[a:b], normalize_input=True).cpu(), full[a:b])
+
+
+def test_modified_resnet_tower_tiny_and_rn50x4():
+    """open_clip ModifiedResNet image tower (RN50x4 for BASELINE configs C1/C3): NHWC GEMM convolutions with the 3x3-window
+    LDS-DMA loader, folded BatchNorm, fused ReLU / residual epilogues, attention pool -- against the CPU oracle."""
+    for name, n, tol in (("tiny-resnet", 5, 2e-4), ("RN50x4", 2, 1e-3)):
+        cfg = synth.CLIP_CONFIGS[name]
+        sd_np = synth.clip_state_dict(cfg, seed=8)
+        sd = ofusion.as_torch(sd_np)
+        eng = FernEngine("cuda:0")
+        eng.load_tensors(sd_np)
+        eng.finalize_clip(cfg)
+        imgs = _t(synth.images(n, cfg))
+        ref = oclip.encode_image(sd, cfg, imgs)
+        got = eng.encode_image(imgs)
+        scale = max(1.0, ref.abs().max().item())
+        assert _maxerr(got, ref) < tol * scale, (name, _maxerr(got, ref), scale)
+        assert (1 - F.cosine_similarity(got.cpu(), ref, dim=-1)).abs().max().item() < 1e-5
+        # batch invariance: one image alone gives the same row
+        assert torch.equal(eng.encode_image(imgs[1:2]), got[1:2])
+        toks = _t(synth.captions(3, cfg))
+        rg, rs = oclip.encode_text(sd, cfg, toks)
+        g, s = eng.encode_text(toks)
+        assert _maxerr(s, rs) < 1e-3 * max(1.0, rs.abs().max().item())
+        eng.close()
