@@ -41,6 +41,9 @@ SIGNATURES = {
     "fern_index_fuse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "fern_combiner": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "fern_visual_sr": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p]),
+    "fern_finalize_clip4cir": (c_int, [c_void_p]),
+    "fern_combiner_clip4cir": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "fern_element_wise_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "fern_l2_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "fern_sim_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_i64,
                               c_void_p, c_void_p]),

@@ -58,6 +58,7 @@ struct SRW {
     const float *wc = nullptr, *bc = nullptr;
 };
 struct BertLayerW { LinearW qkv, attn_out, inter, out; LNW ln1, ln2; };
+struct Clip4CirW { bool ready = false; int width = 0; LinearW text, image, comb, outl, hidden; const float* w2 = nullptr; const float* b2 = nullptr; };
 struct FusionW {
     int parts = 0;      // FERN_PART_* bits that are finalised
     int D = 0;
@@ -98,6 +99,7 @@ struct fern_ctx {
     std::vector<void*> owned;        // device weight buffers
     FusionW fusion;
     ClipW clip;
+    Clip4CirW c4c;
     // workspace arena (bump allocator; blocks are consolidated at the start of the next op)
     struct Block { char* p; size_t cap; };
     std::vector<Block> blocks;
@@ -316,6 +318,7 @@ extern "C" int fern_ctx_fork(fern_ctx* parent, fern_ctx** out) {
     c->device = parent->device;
     c->fusion = parent->fusion;      // pointers into the parent's `owned` buffers; the parent must outlive its forks
     c->clip = parent->clip;
+    c->c4c = parent->c4c;
     *out = c;
     return FERN_OK;
 }
@@ -618,6 +621,71 @@ extern "C" int fern_visual_sr(fern_ctx* c, int which, const float* local, float*
         FERN_TRY(ws_begin(c, s));
         FERN_TRY(run_visual_sr(c, c->fusion.sr[which], local + o * 13 * D, out + o * D, m, D, s));
     }
+    return FERN_OK;
+}
+
+// models/others/Combiner_Model.py (CLIP4Cir Combiner, CVPR'22): the variant of CombinerSimple with a residual
+// output_layer(relu(combiner_layer(cat))) branch; its Linear layers take inputs of width 2 * clip_feature_dim.
+extern "C" int fern_finalize_clip4cir(fern_ctx* c) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_finalize_clip4cir: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    Clip4CirW& W = c->c4c;
+    W = Clip4CirW();
+    const std::string p = "clip4cir.";
+    const HostTensor *tp, *cl;
+    FERN_TRY(need(c, p + "text_projection_layer.weight", {}, &tp));
+    FERN_TRY(need(c, p + "combiner_layer.weight", {}, &cl));
+    if (tp->shape.size() != 2 || cl->shape.size() != 2) return fail(FERN_ERR_STATE, "clip4cir: weights must be 2-D");
+    const int Pj = (int)tp->shape[0], Wd = (int)tp->shape[1], Hd = (int)cl->shape[0];
+    if (Wd % 32 || Wd > 1280 || Pj % 16 || Hd % 32) return fail(FERN_ERR_ARG, "clip4cir: need 2*clip_dim % 32 == 0 (<= 1280), projection % 16, hidden % 32");
+    FERN_TRY(up_linear(c, p + "text_projection_layer", Pj, Wd, &W.text));
+    FERN_TRY(up_linear(c, p + "image_projection_layer", Pj, Wd, &W.image));
+    FERN_TRY(up_linear(c, p + "combiner_layer", Hd, 2 * Pj, &W.comb));
+    FERN_TRY(up_linear(c, p + "output_layer", Wd, Hd, &W.outl));
+    FERN_TRY(up_linear(c, p + "dynamic_scalar.0", Hd, 2 * Pj, &W.hidden));
+    FERN_TRY(up_key(c, p + "dynamic_scalar.3.weight", {1, Hd}, &W.w2));
+    FERN_TRY(up_key(c, p + "dynamic_scalar.3.bias", {1}, &W.b2));
+    W.width = Wd;
+    W.ready = true;
+    return FERN_OK;
+}
+
+extern "C" int fern_combiner_clip4cir(fern_ctx* c, const float* image, const float* text, float* out, int64_t n, void* stream) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_combiner_clip4cir: ctx is NULL");
+    if (!c->c4c.ready) return fail(FERN_ERR_STATE, "fern_combiner_clip4cir: weights not finalised (fern_finalize_clip4cir)");
+    if (n < 0 || (n && (!image || !text || !out))) return fail(FERN_ERR_ARG, "fern_combiner_clip4cir: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const Clip4CirW& W = c->c4c;
+    const int Wd = W.width, Pj = W.text.out, H2 = 2 * Pj, Hd = W.comb.out;
+    const long CH = 8192;
+    for (long o = 0; o < n; o += CH) {
+        const int m = (int)std::min(CH, (long)n - o);
+        FERN_TRY(ws_begin(c, s));
+        float *cat, *comb, *O, *partial;
+        FERN_TRY(ws_get(c, (size_t)m * H2, &cat));
+        FERN_TRY(ws_get(c, (size_t)m * Hd, &comb));
+        FERN_TRY(ws_get(c, (size_t)m * Wd, &O));
+        const float *im = image + o * Wd, *tx = text + o * Wd;
+        FERN_TRY(run_gemm(c, gemm_desc(tx, Wd, W.text, cat, H2, m, EPI_BIAS_RELU), s));              // :49-51
+        FERN_TRY(run_gemm(c, gemm_desc(im, Wd, W.image, cat + Pj, H2, m, EPI_BIAS_RELU), s));        // :52-54
+        FERN_TRY(run_gemm(c, gemm_desc(cat, H2, W.comb, comb, Hd, m, EPI_BIAS_RELU), s));            // :59-61
+        FERN_TRY(run_gemm(c, gemm_desc(comb, Hd, W.outl, O, Wd, m, EPI_BIAS), s));                   // output_layer
+        const int nb = gemm_num_col_blocks(m, Hd, H2);
+        FERN_TRY(ws_get(c, (size_t)m * nb, &partial));
+        GemmParams ph = gemm_desc(cat, H2, W.hidden, nullptr, H2, m, EPI_RELU_DOT);                  // dynamic_scalar
+        ph.aux0 = W.w2; ph.partial = partial;
+        FERN_TRY(run_gemm(c, ph, s));
+        HIP_TRY(launch_combiner_finalize(partial, nb, W.b2, im, tx, out + o * Wd, m, Wd, s, O));     // :63-70
+    }
+    return FERN_OK;
+}
+
+// utils.element_wise_sum (utils/utils.py:133-140): F.normalize(image_features + text_features)
+extern "C" int fern_element_wise_sum(fern_ctx* c, const float* image, const float* text, float* out, int64_t n, int d, void* stream) {
+    if (!c || n < 0 || (n && (!image || !text || !out))) return fail(FERN_ERR_ARG, "fern_element_wise_sum: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_l2norm(image, d, out, d, n, d, 1e-12f, 0, (hipStream_t)stream, text));
     return FERN_OK;
 }
 

@@ -10,7 +10,7 @@ namespace fern {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWS_PER_BLOCK = 4;   // 4 waves per workgroup, one row each
-constexpr int MAXV = 4;             // row width <= 64 lanes * 4 floats * MAXV = 1024
+constexpr int MAXV = 5;             // row width <= 64 lanes * 4 floats * MAXV = 1280 (2 x 640 for the CLIP4Cir Combiner)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -91,12 +91,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     row_store(r, y + row * ldy, d, lane);
 }
 
-__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode) {
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, const float* x2, long ldx, float* y, long ldy, long rows, int d,
+                                                     float eps, int mode) {
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     RowRegs r;
     row_load(r, x + row * ldx, d, lane);
+    if (x2) {                                   // normalize(x + x2): utils.element_wise_sum
+        RowRegs q;
+        row_load(q, x2 + row * ldx, d, lane);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) r.v[i] += q.v[i];
+    }
     const float nrm = sqrtf(row_sumsq(r));
     const float den = mode == 0 ? fmaxf(nrm, eps) : nrm + eps;
 #pragma unroll
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256) void vit_cls_kernel(const float* cls, const fl
 }
 
 __global__ __launch_bounds__(256) void combiner_finalize_kernel(const float* partial, int nb, const float* b2, const float* image,
-                                                                const float* text, float* out, long n, int d) {
+                                                                const float* text, const float* extra, float* out, long n, int d) {
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= n) return;
@@ -208,8 +215,15 @@ __global__ __launch_bounds__(256) void combiner_finalize_kernel(const float* par
     RowRegs im, tx;
     row_load(im, image + row * d, d, lane);
     row_load(tx, text + row * d, d, lane);
+    if (extra) {                                // CLIP4Cir Combiner: output_layer(...) + s*text + (1-s)*image (Combiner_Model.py:63-67)
+        RowRegs ex;
+        row_load(ex, extra + row * d, d, lane);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) im.v[i] = tx.v[i] * s + im.v[i] * (1.0f - s);
+        for (int i = 0; i < MAXV; ++i) im.v[i] = (ex.v[i] + tx.v[i] * s) + im.v[i] * (1.0f - s);
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) im.v[i] = tx.v[i] * s + im.v[i] * (1.0f - s);
+    }
     const float den = fmaxf(sqrtf(row_sumsq(im)), 1e-12f);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) im.v[i] = im.v[i] / den;
@@ -352,10 +366,11 @@ hipError_t launch_layernorm(const float* x, const float* res, const float* gamma
     hipLaunchKernelGGL(layernorm_kernel, row_grid(rows), dim3(256), 0, s, x, res, gamma, beta, y, rows, d, ldx, ldy, eps);
     return hipGetLastError();
 }
-hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s) {
+hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s,
+                         const float* x2) {
     if (rows <= 0) return hipSuccess;
     if (bad_width(d) || (ldx & 3) || (ldy & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(l2norm_kernel, row_grid(rows), dim3(256), 0, s, x, ldx, y, ldy, rows, d, eps, mode);
+    hipLaunchKernelGGL(l2norm_kernel, row_grid(rows), dim3(256), 0, s, x, x2, ldx, y, ldy, rows, d, eps, mode);
     return hipGetLastError();
 }
 hipError_t launch_mean_rows(const float* x, long ldx, float* y, long ldy, long n, int P, int d, long group_stride, long row_add,
@@ -395,10 +410,10 @@ hipError_t launch_vit_cls(const float* cls, const float* pos, float* X, int B, i
     return hipGetLastError();
 }
 hipError_t launch_combiner_finalize(const float* partial, int nb, const float* b2, const float* image, const float* text, float* out,
-                                    long n, int d, hipStream_t s) {
+                                    long n, int d, hipStream_t s, const float* extra) {
     if (n <= 0) return hipSuccess;
     if (bad_width(d)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(combiner_finalize_kernel, row_grid(n), dim3(256), 0, s, partial, nb, b2, image, text, out, n, d);
+    hipLaunchKernelGGL(combiner_finalize_kernel, row_grid(n), dim3(256), 0, s, partial, nb, b2, image, text, extra, out, n, d);
     return hipGetLastError();
 }
 hipError_t launch_sr_finalize(const float* partial, int nb, const float* bc, const float* local, float* out, long n, int d, hipStream_t s) {

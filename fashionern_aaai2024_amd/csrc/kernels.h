@@ -60,7 +60,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s);   // hipErrorIn
 hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                             long rows, int d, long ldx, long ldy, float eps, hipStream_t s);
 // mode 0: x / max(||x||, eps) (F.normalize); mode 1: x / (||x|| + eps) (VisualSR.l2norm)
-hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s);
+hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s,
+                         const float* x2 = nullptr);   // x2: optional addend (normalize(x + x2))
 // y[i, :] = mean_{p<P} x[i*group_stride + row_add + p, :]
 hipError_t launch_mean_rows(const float* x, long ldx, float* y, long ldy, long n, int P, int d, long group_stride, long row_add,
                             hipStream_t s);
@@ -78,7 +79,7 @@ hipError_t launch_text_embed(const int64_t* text, const float* tok_emb, const fl
 hipError_t launch_vit_cls(const float* cls, const float* pos, float* X, int B, int tokens, int d, hipStream_t s);
 // CombinerSimple tail: s = sigmoid(sum_nb partial[row][nb] + b2); out = normalize(s*text + (1-s)*image)
 hipError_t launch_combiner_finalize(const float* partial, int nb, const float* b2, const float* image, const float* text,
-                                    float* out, long n, int d, hipStream_t s);
+                                    float* out, long n, int d, hipStream_t s, const float* extra = nullptr);
 // VisualSR tail: logits[p] = sum_nb partial[row*13+p][nb] + bc; w = softmax_13; new = sum w_p local_p; out = new/(||new||+1e-8)
 hipError_t launch_sr_finalize(const float* partial, int nb, const float* bc, const float* local, float* out,
                               long n, int d, hipStream_t s);

@@ -187,6 +187,24 @@ class FernEngine:
         _lib.check(self.lib.fern_visual_sr(self._h, which, _ptr(x), _ptr(out), x.shape[0], _stream()), "fern_visual_sr")
         return out
 
+    def finalize_clip4cir(self) -> None:
+        _lib.check(self.lib.fern_finalize_clip4cir(self._h), "fern_finalize_clip4cir")
+
+    def combiner_clip4cir(self, image, text) -> torch.Tensor:
+        im = self._f32(image)
+        tx = self._f32(text, tuple(im.shape))
+        out = torch.empty_like(im)
+        _lib.check(self.lib.fern_combiner_clip4cir(self._h, _ptr(im), _ptr(tx), _ptr(out), im.shape[0], _stream()), "fern_combiner_clip4cir")
+        return out
+
+    def element_wise_sum(self, image, text) -> torch.Tensor:
+        im = self._f32(image)
+        tx = self._f32(text, tuple(im.shape))
+        out = torch.empty_like(im)
+        _lib.check(self.lib.fern_element_wise_sum(self._h, _ptr(im), _ptr(tx), _ptr(out), im.shape[0], im.shape[1], _stream()),
+                   "fern_element_wise_sum")
+        return out
+
     def l2_normalize(self, x) -> torch.Tensor:
         x = self._f32(x)
         out = torch.empty_like(x)

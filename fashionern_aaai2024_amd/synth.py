@@ -112,6 +112,19 @@ def fusion_state_dict(feature_dim: int, seed: int = 0, with_cls_token: bool = Tr
     return sd
 
 
+def clip4cir_state_dict(clip_feature_dim: int, projection_dim: int, hidden_dim: int, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Synthetic state dict of models/others/Combiner_Model.py:Combiner (its Linear inputs are 2 * clip_feature_dim wide)."""
+    sd: Dict[str, np.ndarray] = {}
+    w = 2 * clip_feature_dim
+    _linear(sd, seed, "text_projection_layer", projection_dim, w)
+    _linear(sd, seed, "image_projection_layer", projection_dim, w)
+    _linear(sd, seed, "combiner_layer", hidden_dim, 2 * projection_dim)
+    _linear(sd, seed, "output_layer", w, hidden_dim)
+    _linear(sd, seed, "dynamic_scalar.0", hidden_dim, 2 * projection_dim)
+    _linear(sd, seed, "dynamic_scalar.3", 1, hidden_dim, gain=2.0)
+    return sd
+
+
 @dataclass(frozen=True)
 class ClipConfig:
     """Shape of a CLIP model in open_clip's vocabulary."""

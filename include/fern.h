@@ -149,6 +149,12 @@ FERN_API int fern_combiner(fern_ctx* ctx, int which, const float* image /*[n,D]*
 /* VisualSR.forward(local_feature) -- fusion_model.py:141-154 */
 FERN_API int fern_visual_sr(fern_ctx* ctx, int which, const float* local /*[n,13,D]*/, float* out /*[n,D]*/,
                    int64_t n, void* stream);
+/* models/others/Combiner_Model.py:6-70 (CLIP4Cir `Combiner`, not called by the reference's own scripts): weights are loaded
+ * under the prefix "clip4cir." with that class's key names; image / text / out are [n, 2*clip_feature_dim]. */
+FERN_API int fern_finalize_clip4cir(fern_ctx* ctx);
+FERN_API int fern_combiner_clip4cir(fern_ctx* ctx, const float* image, const float* text, float* out, int64_t n, void* stream);
+/* utils.element_wise_sum(image_features, text_features) = F.normalize(image + text) -- utils/utils.py:133-140 */
+FERN_API int fern_element_wise_sum(fern_ctx* ctx, const float* image, const float* text, float* out, int64_t n, int d, void* stream);
 /* F.normalize(x, dim=-1) -- run/test/test_fiq.py:45 */
 FERN_API int fern_l2_normalize(fern_ctx* ctx, const float* x, float* out, int64_t n, int d, void* stream);
 

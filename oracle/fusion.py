@@ -135,3 +135,21 @@ def index_fuse(sd, tar_feats, tar_local):
     """ERN mode="index" -- models/model.py:64-66 (caller normalises tar_feats first, test_fiq.py:45)."""
     sr = visual_sr(sd, "SR_module", tar_local)
     return combiner_simple(sd, "Combiner_module", tar_feats, sr)
+
+
+def combiner_clip4cir(sd, prefix, image_features, text_features):
+    """CLIP4Cir Combiner.forward -- /root/reference/models/others/Combiner_Model.py:37-70 (eval: dropouts off)."""
+    p = prefix + "." if prefix else ""
+    tp = F.relu(F.linear(text_features, sd[p + "text_projection_layer.weight"], sd[p + "text_projection_layer.bias"]))
+    ip = F.relu(F.linear(image_features, sd[p + "image_projection_layer.weight"], sd[p + "image_projection_layer.bias"]))
+    raw = torch.cat((tp, ip), -1)                                                              # :56-58
+    comb = F.relu(F.linear(raw, sd[p + "combiner_layer.weight"], sd[p + "combiner_layer.bias"]))
+    h = F.relu(F.linear(raw, sd[p + "dynamic_scalar.0.weight"], sd[p + "dynamic_scalar.0.bias"]))
+    s = torch.sigmoid(F.linear(h, sd[p + "dynamic_scalar.3.weight"], sd[p + "dynamic_scalar.3.bias"]))
+    out = F.linear(comb, sd[p + "output_layer.weight"], sd[p + "output_layer.bias"]) + s * text_features + (1 - s) * image_features
+    return F.normalize(out, dim=-1)                                                            # :69
+
+
+def element_wise_sum(image_features, text_features):
+    """utils.element_wise_sum -- /root/reference/utils/utils.py:133-140."""
+    return F.normalize(image_features + text_features, dim=-1)

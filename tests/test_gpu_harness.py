@@ -138,3 +138,26 @@ def test_clip_matches_in_tree_reference_statement():
             assert np.abs(g.cpu().numpy() - gold[f"{name}_text_{tag}_global"]).max() < tol
             assert torch.equal(clip.encode_text(toks, mode="seq"), s)
         clip.engine.close()
+
+
+@pytest.mark.parametrize("cdim", [64, 640])
+def test_clip4cir_combiner_and_element_wise_sum(cdim):
+    from fashionern_aaai2024_amd.others import Combiner, element_wise_sum
+    gold = np.load(os.path.join(GOLD, "fusion.npz"))
+    comb = Combiner(cdim, 4 * cdim, 8 * cdim, device=DEV).load_state_dict(synth.clip4cir_state_dict(cdim, 4 * cdim, 8 * cdim, seed=11))
+    im, tx = torch.from_numpy(synth.global_feats(5, 2 * cdim, 42, "c4i")), torch.from_numpy(synth.global_feats(5, 2 * cdim, 42, "c4t"))
+    assert np.abs(comb(im, tx).cpu().numpy() - gold[f"clip4cir_c{cdim}"]).max() < 2e-5
+    assert np.abs(element_wise_sum(im.cuda(), tx.cuda(), engine=comb.engine).cpu().numpy() - gold[f"ews_c{cdim}"]).max() < 1e-6
+
+
+def test_cli_driver_runs_on_synthetic_split():
+    """python -m fashionern_aaai2024_amd.run.test_fiq: the reference driver's flags on a seeded synthetic split."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mod, extra in (("test_fiq", []), ("test_cirr", [])):
+        r = subprocess.run([sys.executable, "-m", f"fashionern_aaai2024_amd.run.{mod}", "--clip-model-name", "tiny", "--feature-dim", "128",
+                            "--input-dim", "64", "--synthetic-gallery", "300", "--synthetic-queries", "40", "--batch-size", "16"] + extra,
+                           cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "Average:" in r.stdout

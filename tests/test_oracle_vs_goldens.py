@@ -117,3 +117,12 @@ def test_recall_oracle_matches_reference_harness():
     assert list(orank.recall_unique(pred, idx, gal.names, targets, ks=(1, 5, 10, 15, 20, 30, 40, 50))) == meta["recalls"]["val"]
     _, top = orank.cosine_topk(pred, idx, 50)
     assert np.array_equal(top.numpy(), arr["fiq_top50"])
+
+
+@pytest.mark.parametrize("cdim", [64, 640])
+def test_adjacent_surface_oracle_matches_reference(fusion_gold, cdim):
+    """CLIP4Cir Combiner (models/others/Combiner_Model.py) and utils.element_wise_sum."""
+    sd = ofusion.as_torch(synth.clip4cir_state_dict(cdim, 4 * cdim, 8 * cdim, seed=FUSION_SEED))
+    im, tx = t(synth.global_feats(5, 2 * cdim, INPUT_SEED, "c4i")), t(synth.global_feats(5, 2 * cdim, INPUT_SEED, "c4t"))
+    assert np.abs(ofusion.combiner_clip4cir(sd, "", im, tx).numpy() - fusion_gold[f"clip4cir_c{cdim}"]).max() < 1e-6
+    assert np.abs(ofusion.element_wise_sum(im, tx).numpy() - fusion_gold[f"ews_c{cdim}"]).max() < 1e-7

@@ -87,6 +87,18 @@ def fusion_goldens():
                                    ref_local_feats=t(synth.local_feats(4, d, INPUT_SEED, "rl")),
                                    text_feats=t(synth.global_feats(4, d, INPUT_SEED, "tg")),
                                    text_seq_feats=t(synth._normal(INPUT_SEED, f"tseq/{d}", (4, 77, d))), mode="test").numpy()
+    # adjacent surface: CLIP4Cir Combiner (models/others/Combiner_Model.py) and utils.element_wise_sum
+    sys.path.insert(0, os.path.join(REF, "models", "others"))
+    from Combiner_Model import Combiner as RefCombiner
+    import utils.utils as ru
+    for cdim in (64, 640):
+        pj, hd = 4 * cdim, 8 * cdim
+        m = RefCombiner(cdim, pj, hd).eval().float()
+        m.load_state_dict(as_torch(synth.clip4cir_state_dict(cdim, pj, hd, seed=FUSION_SEED)), strict=True)
+        im, tx = t(synth.global_feats(5, 2 * cdim, INPUT_SEED, "c4i")), t(synth.global_feats(5, 2 * cdim, INPUT_SEED, "c4t"))
+        with torch.no_grad():
+            out[f"clip4cir_c{cdim}"] = m(im, tx).numpy()
+            out[f"ews_c{cdim}"] = ru.element_wise_sum(im, tx).numpy()
     np.savez_compressed(os.path.join(OUT, "fusion.npz"), **out)
     print("fusion.npz", {k: v.shape for k, v in out.items()})
 
