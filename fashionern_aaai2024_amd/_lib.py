@@ -45,6 +45,10 @@ SIGNATURES = {
     "fern_combiner_clip4cir": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "fern_element_wise_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "fern_l2_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "fern_resample_u8_horizontal": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "fern_resample_u8_vertical": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "fern_u8_to_normalized_chw": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_i64, c_void_p, c_int, c_int, c_int,
+                                          C.POINTER(c_float), C.POINTER(c_float), c_void_p]),
     "fern_sim_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_i64,
                               c_void_p, c_void_p]),
     "fern_gather_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -1078,6 +1078,31 @@ extern "C" int fern_topk_merge(fern_ctx* c, const float* scores, const int32_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// image side: PIL-exact 8-bit resampling + ToTensor/Normalize
+// ------------------------------------------------------------------------------------------------
+extern "C" int fern_resample_u8_horizontal(fern_ctx* c, const uint8_t* src, int64_t src_ld, int x0, int y0, int rows, uint8_t* dst, int ow,
+                                           const int32_t* bounds, const int32_t* coeffs, int ksize, void* stream) {
+    if (!c || !src || !dst || !bounds || !coeffs || rows < 0 || ow < 0 || ksize < 1) return fail(FERN_ERR_ARG, "fern_resample_u8_horizontal: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_resample_h(src, src_ld, x0, y0, rows, dst, ow, bounds, coeffs, ksize, (hipStream_t)stream));
+    return FERN_OK;
+}
+extern "C" int fern_resample_u8_vertical(fern_ctx* c, const uint8_t* src, int64_t src_ld, int x0, int y0, int cols, uint8_t* dst, int oh,
+                                         const int32_t* bounds, const int32_t* coeffs, int ksize, void* stream) {
+    if (!c || !src || !dst || !bounds || !coeffs || cols < 0 || oh < 0 || ksize < 1) return fail(FERN_ERR_ARG, "fern_resample_u8_vertical: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_resample_v(src, src_ld, x0, y0, cols, dst, oh, bounds, coeffs, ksize, (hipStream_t)stream));
+    return FERN_OK;
+}
+extern "C" int fern_u8_to_normalized_chw(fern_ctx* c, const uint8_t* src, int64_t src_ld, int x0, int y0, int64_t src_image_stride, float* dst,
+                                         int n, int oh, int ow, const float* host_mean, const float* host_std, void* stream) {
+    if (!c || !src || !dst || !host_mean || !host_std || n < 0 || oh < 0 || ow < 0) return fail(FERN_ERR_ARG, "fern_u8_to_normalized_chw: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_u8_to_chw(src, src_ld, x0, y0, dst, n, src_image_stride, oh, ow, host_mean, host_std, (hipStream_t)stream));
+    return FERN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // building blocks
 // ------------------------------------------------------------------------------------------------
 extern "C" int fern_gemm(fern_ctx* c, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* residual,

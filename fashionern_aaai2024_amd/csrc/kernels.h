@@ -94,6 +94,14 @@ hipError_t launch_attnpool_tokens(const float* x, float* mean, const float* pos,
 hipError_t launch_gather_scores(const float* q, const float* gallery, const int* idx, float* out, int B, int m, int d,
                                 hipStream_t s);
 
+// ---- 8-bit image resampling / tensor conversion (image.hip) -------------------------------------------------------
+hipError_t launch_resample_h(const unsigned char* src, long src_ld, int x0, int y0, int rows, unsigned char* dst, int ow, const int* bounds,
+                             const int* kk, int ksize, hipStream_t s);
+hipError_t launch_resample_v(const unsigned char* src, long src_ld, int x0, int y0, int cols, unsigned char* dst, int oh, const int* bounds,
+                             const int* kk, int ksize, hipStream_t s);
+hipError_t launch_u8_to_chw(const unsigned char* src, long src_ld, int x0, int y0, float* dst, int n, long src_img_stride, int oh, int ow,
+                            const float* mean, const float* stdv, hipStream_t s);
+
 // ---- top-K (topk.hip) ------------------------------------------------------------------------
 // Per row of `scores` [B, ld] (n valid columns): K best (score desc, index asc).  out idx = col + idx_offset.
 // `keys_ws` must hold B * nseg * 64 uint64 (nseg = topk_num_segments(n)).

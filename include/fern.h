@@ -158,6 +158,21 @@ FERN_API int fern_element_wise_sum(fern_ctx* ctx, const float* image, const floa
 /* F.normalize(x, dim=-1) -- run/test/test_fiq.py:45 */
 FERN_API int fern_l2_normalize(fern_ctx* ctx, const float* x, float* out, int64_t n, int d, void* stream);
 
+/* image side (data formats either side of the path) ----------------------------------------------
+ * PIL `Image.resize` on 8-bit RGB, as called by utils/extract_fashioniq_patch.py:142-149 (`resize((360,360), ANTIALIAS)`)
+ * and by torchvision `Resize(dim, BICUBIC)` in dataloader/dataset.py:73-87.  One separable pass each; `bounds` [out,2] =
+ * (first tap, tap count) and `coeffs` [out,ksize] = fixed-point (2^-22) weights are DEVICE arrays computed by the host
+ * exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do.  src is HWC u8 with `src_ld` pixels per row; (x0, y0)
+ * is the origin of the region being resampled (`Image.crop`).  Bit-identical to PIL. */
+FERN_API int fern_resample_u8_horizontal(fern_ctx* ctx, const uint8_t* src, int64_t src_ld, int x0, int y0, int rows, uint8_t* dst /*[rows,ow,3]*/,
+                                         int ow, const int32_t* bounds, const int32_t* coeffs, int ksize, void* stream);
+FERN_API int fern_resample_u8_vertical(fern_ctx* ctx, const uint8_t* src, int64_t src_ld, int x0, int y0, int cols, uint8_t* dst /*[oh,cols,3]*/,
+                                       int oh, const int32_t* bounds, const int32_t* coeffs, int ksize, void* stream);
+/* torchvision ToTensor + Normalize (dataloader/dataset.py:84-86) with a crop window: n images [.,src_ld,3] u8, `src_image_stride`
+ * bytes apart -> dst [n,3,oh,ow] f32 = (v/255 - mean[c]) / std[c]; mean / std are HOST arrays of 3 floats. */
+FERN_API int fern_u8_to_normalized_chw(fern_ctx* ctx, const uint8_t* src, int64_t src_ld, int x0, int y0, int64_t src_image_stride, float* dst,
+                                       int n, int oh, int ow, const float* host_mean, const float* host_std, void* stream);
+
 /* rank ---------------------------------------------------------------------------------- */
 /* distances = 1 - q @ g.T ; argsort(distances)[:, :K] -- run/test/test_fiq.py:49-50.
  * Scores are cosines (q.g), sorted descending, ties -> lower gallery index.  out_idx holds

@@ -1,0 +1,92 @@
+"""Image side: PIL-exact resize + CLIP preprocessing + 13-patch extraction.  CPU part: the host-side restatement of Pillow's
+coefficient tables, checked by emulating the integer passes in numpy against PIL itself.  GPU part: the kernels against PIL."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from fashionern_aaai2024_amd import preprocess as pp
+from oracle import preprocess as opp
+
+
+def _img(w, h, seed):
+    return np.random.default_rng(seed).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+
+
+def _emulate(img, ow, oh, flt):
+    cur = img
+    h, w, _ = cur.shape
+    if ow != w:
+        b, k = pp.pil_coeffs(w, ow, flt)
+        tmp = np.zeros((h, ow, 3), np.uint8)
+        for xx in range(ow):
+            x0, n = b[xx]
+            acc = (cur[:, x0:x0 + n].astype(np.int64) * k[xx, :n][None, :, None]).sum(1) + (1 << 21)
+            tmp[:, xx] = np.clip(acc >> 22, 0, 255)
+        cur = tmp
+    if oh != h:
+        b, k = pp.pil_coeffs(h, oh, flt)
+        tmp = np.zeros((oh, cur.shape[1], 3), np.uint8)
+        for yy in range(oh):
+            y0, n = b[yy]
+            acc = (cur[y0:y0 + n].astype(np.int64) * k[yy, :n][:, None, None]).sum(0) + (1 << 21)
+            tmp[yy] = np.clip(acc >> 22, 0, 255)
+        cur = tmp
+    return cur
+
+
+CASES = [(500, 375, 360, 360, "lanczos", Image.LANCZOS), (180, 180, 224, 224, "bicubic", Image.BICUBIC),
+         (120, 120, 288, 288, "bicubic", Image.BICUBIC), (640, 480, 298, 224, "bicubic", Image.BICUBIC),
+         (300, 800, 224, 597, "bicubic", Image.BICUBIC), (224, 300, 224, 224, "bicubic", Image.BICUBIC), (97, 61, 360, 360, "lanczos", Image.LANCZOS)]
+
+
+@pytest.mark.parametrize("w,h,ow,oh,flt,pil", CASES)
+def test_coefficient_tables_reproduce_pil_bit_exactly(w, h, ow, oh, flt, pil):
+    img = _img(w, h, 1)
+    ref = np.asarray(Image.fromarray(img).resize((ow, oh), pil))
+    assert np.array_equal(_emulate(img, ow, oh, flt), ref)
+
+
+def test_cut_boxes_match_reference_crop_grid():
+    assert pp.cut_boxes(360, 360, 2) == [(0, 0, 180, 180), (180, 0, 360, 180), (0, 180, 180, 360), (180, 180, 360, 360)]
+    assert len(pp.cut_boxes(360, 360, 3)) == 9 and pp.cut_boxes(360, 360, 3)[4] == (120, 120, 240, 240)
+    assert [c.size for c in opp.cut(Image.fromarray(_img(360, 360, 2)), 3)] == [(120, 120)] * 9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,ow,oh,flt,pil", CASES)
+def test_gpu_resize_is_bit_identical_to_pil(engine, w, h, ow, oh, flt, pil):
+    img = _img(w, h, 3)
+    ref = np.asarray(Image.fromarray(img).resize((ow, oh), pil))
+    got = pp.resize_u8(engine, torch.from_numpy(img).cuda(), ow, oh, flt).cpu().numpy()
+    assert np.array_equal(got, ref)
+    box = (w // 7, h // 5, w - 3, h - 2)
+    ref = np.asarray(Image.fromarray(img).crop(box).resize((ow, oh), pil))
+    assert np.array_equal(pp.resize_u8(engine, torch.from_numpy(img).cuda(), ow, oh, flt, box=box).cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,dim", [(500, 375, 224), (375, 500, 288), (900, 300, 224), (300, 1000, 288), (224, 224, 224)])
+def test_gpu_targetpad_transform_matches_reference_pipeline(engine, w, h, dim):
+    img = _img(w, h, 4)
+    ref = opp.targetpad_transform(Image.fromarray(img), 1.25, dim)
+    got = pp.targetpad_transform(engine, torch.from_numpy(img).cuda(), 1.25, dim).cpu()
+    assert got.shape == (3, dim, dim) and torch.equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_gpu_patch_extraction_matches_reference_pipeline(engine):
+    from fashionern_aaai2024_amd import synth
+    from fashionern_aaai2024_amd.clip_model import create_model
+    from oracle import clip as oclip, fusion as ofusion
+    img = _img(533, 400, 5)
+    ref = opp.patch_images(Image.fromarray(img), 224)
+    got = pp.patch_images(engine, torch.from_numpy(img).cuda(), 224)
+    assert got.shape == (13, 3, 224, 224) and torch.equal(got.cpu(), ref)
+    cfg = synth.CLIP_CONFIGS["tiny"]                      # 64-px tower: 13 crops -> [13, D] local features
+    clip = create_model(cfg, device="cuda:0", seed=2)
+    feats = pp.extract_patch_features(clip, torch.from_numpy(img).cuda())
+    sd = ofusion.as_torch(synth.clip_state_dict(cfg, 2))
+    exp = oclip.encode_image(sd, cfg, opp.patch_images(Image.fromarray(img), cfg.image_size))
+    assert feats.shape == (13, cfg.embed_dim) and (feats.cpu() - exp).abs().max().item() < 2e-4 * max(1.0, exp.abs().max().item())
+    clip.engine.close()
