@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s me
 QUERY_BATCH, GALLERY, TOPK, D = 64, 46000, 50, 512
 
 
-def cpu_baseline(clip_sd, fusion_sd, cfg, images, tokens, loc, gallery, sample, repeats=2):
+def cpu_baseline(clip_sd, fusion_sd, cfg, images, tokens, loc, gallery, sample, gpu_topk, repeats=2):
     """The CPU oracle (kind "port": this repo's restatement, pinned against the imported reference by tests/golden)
     on `sample` composed queries: encode image + text, fuse, rank against the same fused gallery."""
     from oracle import clip as oclip, fusion as ofusion, rank as orank
@@ -63,9 +63,16 @@ def cpu_baseline(clip_sd, fusion_sd, cfg, images, tokens, loc, gallery, sample, 
 
     warm = _timed(one)
     best = min([warm] + [_timed(one) for _ in range(repeats)]) if warm < 20 else warm      # keep the run bounded
+    # the oracle is the checker as well: same queries, same gallery -> compare the HIP path's top-K with the CPU result
+    o_s, o_i = one()
+    g_s, g_i = gpu_topk[0][:sample].cpu(), gpu_topk[1][:sample].cpu()
+    same_rows = int((g_i == o_i).all(dim=1).sum().item())
     return {"value": sample / best, "unit": "composed queries/sec", "cores": threads, "kind": "port",
             "sample": f"{sample} composed queries (ViT-B/16 image + text encode, fusion, top-{TOPK} of {gallery.shape[0]} rows), "
-                      f"torch CPU fp32, best of {repeats}"}
+                      f"torch CPU fp32, best of {repeats}",
+            "parity_vs_hip": {"queries": sample, "rows_with_identical_top%d_order" % TOPK: same_rows,
+                              "positions_equal_frac": float((g_i == o_i).float().mean().item()),
+                              "max_abs_cosine_diff": float((g_s - o_s).abs().max().item())}}
 
 
 def _timed(fn):
@@ -210,7 +217,9 @@ def main():
             result["roofline"]["algorithmic_bytes_per_launch"] = tr.get("gemm", {}).get("algorithmic_bytes_per_launch")
             result["roofline_sim_sweep"]["traffic"] = tr.get("sweep", {}).get("hbm_bytes_per_launch")
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(clip_sd, fusion_sd, cfg, images, tokens, loc, gallery, args.cpu_sample)
+            gpu_topk = step_serial()
+            torch.cuda.synchronize()
+            result["cpu_baseline"] = cpu_baseline(clip_sd, fusion_sd, cfg, images, tokens, loc, gallery, args.cpu_sample, gpu_topk)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
