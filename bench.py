@@ -184,6 +184,24 @@ def main():
     torch.cuda.synchronize()
     enc_ips = 3 * QUERY_BATCH / (time.perf_counter() - t0)
 
+    # HBM-bound variant of the sweep (BASELINE config 5 "bf16 similarity"): 1M-row bf16 gallery, same 64 queries
+    big_n = 1_000_000
+    gal_big = torch.nn.functional.normalize(torch.randn(big_n, D, device=device, generator=torch.Generator(device=device).manual_seed(3)), dim=-1)
+    gal_bf16 = eng.gallery_to_bf16(gal_big)
+    del gal_big
+    qq = step_serial()      # warm
+    q_unit = torch.nn.functional.normalize(torch.randn(QUERY_BATCH, D, device=device), dim=-1)
+    for _ in range(2):
+        eng.sim_topk_bf16(q_unit, gal_bf16, TOPK)
+    eng.prof_enable(True)
+    for _ in range(5):
+        eng.sim_topk_bf16(q_unit, gal_bf16, TOPK)
+    sb = eng.prof_collect()
+    eng.prof_enable(False)
+    bf16_us = sb["sweep_ms"] / max(1, sb["sweep_launches"]) * 1e3
+    bf16_gbs = sb["sweep_bytes"] / max(1, sb["sweep_launches"]) / (bf16_us * 1e-6) / 1e9 if bf16_us > 0 else 0.0
+    del gal_bf16
+
     result = None
     if rank == 0:
         result = {
@@ -205,6 +223,10 @@ def main():
                                    "kernel": "gemm_f32_kernel as the cosine sweep inside fern_sim_topk",
                                    "sweep_us": st["sweep_ms"] / max(1, st["sweep_launches"]) * 1e3,
                                    "topk_us": st["topk_ms"] / max(1, st["topk_launches"]) * 1e3},
+            "roofline_sim_sweep_bf16_1M": {"bound": "hbm", "achieved": bf16_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": bf16_gbs / HBM_PEAK_GBS, "traffic": None,
+                                           "kernel": "sweep_bf16_kernel: 64 queries x 1M-row bf16 gallery (config 5's similarity mode)",
+                                           "sweep_us": bf16_us, "topk_us": sb["topk_ms"] / max(1, sb["topk_launches"]) * 1e3},
             "attention": {"achieved_tflops": attn_tflops, "ms_per_step": st["attn_ms"] / prof_steps},
             "gallery_build": {"index_fuse_all_gather_s": gallery_build_s, "rows_per_s": n_gal / gallery_build_s,
                               "encode_images_per_s_per_gpu": enc_ips},

@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libfern.so")
-SOURCES = ["api.hip", "gemm.hip", "attn.hip", "elem.hip", "topk.hip", "image.hip"]
+SOURCES = ["api.hip", "gemm.hip", "attn.hip", "elem.hip", "topk.hip", "image.hip", "sweep_bf16.hip"]
 HEADERS = ["kernels.h", os.path.join("..", "..", "include", "fern.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DFERN_BUILD"]
 

@@ -1037,9 +1037,9 @@ extern "C" int fern_sim_topk(fern_ctx* c, const float* q, const float* gallery, 
     // queries are processed in chunks so the [chunk, N] score tile stays cache-sized
     long chunk = std::max<long>(64, std::min<long>(1024, ((long)64 << 20) / std::max<long>(1, (long)N * 4)));
     chunk = (chunk / 64) * 64;
-    const int nseg = topk_num_segments(N);
     for (long o = 0; o < B; o += chunk) {
         const int m = (int)std::min<long>(chunk, B - o);
+        const int nseg = topk_num_segments(m, N);
         FERN_TRY(ws_begin(c, s));
         float* scores = nullptr;
         unsigned long long* keys;
@@ -1053,6 +1053,45 @@ extern "C" int fern_sim_topk(fern_ctx* c, const float* q, const float* gallery, 
             FERN_TRY(run_gemm(c, p, s, PROF_SWEEP, (double)N * D * 4 + (double)m * D * 4 + (double)m * N * 4));
         }
         int slot;
+        FERN_TRY(prof_open(c, PROF_TOPK, 0, s, &slot));
+        HIP_TRY(launch_topk_rows(scores, ld, m, N, K, idx_offset, exclude_idx ? exclude_idx + o : nullptr, keys, out_scores + o * K,
+                                 out_idx + o * K, s));
+        FERN_TRY(prof_close(c, slot, s));
+    }
+    return FERN_OK;
+}
+
+// BASELINE config 5 ("bf16 similarity"): the gallery is stored in bf16 (half the HBM bytes), queries are rounded to bf16 in
+// the kernel, products accumulate in fp32.  Same outputs and tie rule as fern_sim_topk.
+extern "C" int fern_gallery_to_bf16(fern_ctx* c, const float* src, uint16_t* dst, int64_t n, int d, void* stream) {
+    if (!c || n < 0 || d <= 0 || (n && (!src || !dst))) return fail(FERN_ERR_ARG, "fern_gallery_to_bf16: bad argument");
+    if (d % 4) return fail(FERN_ERR_ARG, "fern_gallery_to_bf16: D must be a multiple of 4");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_f32_to_bf16(src, dst, (long)n * d, (hipStream_t)stream));
+    return FERN_OK;
+}
+
+extern "C" int fern_sim_topk_bf16(fern_ctx* c, const float* q, const uint16_t* gallery, int B, int64_t N, int D, int K, float* out_scores,
+                                  int32_t* out_idx, int64_t idx_offset, const int32_t* exclude_idx, void* stream) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_sim_topk_bf16: ctx is NULL");
+    if (B < 0 || N < 0 || K < 1 || K > 64 || D <= 0 || D % 64 || D > 1024) return fail(FERN_ERR_ARG, "fern_sim_topk_bf16: need 1<=K<=64, D % 64 == 0, D <= 1024");
+    if (B && (!q || !out_scores || !out_idx || (N && !gallery))) return fail(FERN_ERR_ARG, "fern_sim_topk_bf16: NULL argument");
+    if (N > 0x7FFFFFF0LL) return fail(FERN_ERR_ARG, "fern_sim_topk_bf16: N too large for int32 indices");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const long ld = ((long)N + 3) & ~3L;
+    for (long o = 0; o < B; o += 64) {                         // the kernel keeps <= 64 queries resident in LDS
+        const int m = (int)std::min<long>(64, B - o);
+        const int nseg = topk_num_segments(m, N);
+        FERN_TRY(ws_begin(c, s));
+        float* scores;
+        unsigned long long* keys;
+        FERN_TRY(ws_get(c, (size_t)m * std::max<long>(ld, 4), &scores));
+        FERN_TRY(ws_get(c, (size_t)m * nseg * 64, &keys));
+        int slot;
+        FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + (double)m * D * 4 + (double)m * N * 4, s, &slot, m, (int)N, D, 16));
+        HIP_TRY(launch_sweep_bf16(q + o * D, gallery, scores, ld, m, N, D, s));
+        FERN_TRY(prof_close(c, slot, s));
         FERN_TRY(prof_open(c, PROF_TOPK, 0, s, &slot));
         HIP_TRY(launch_topk_rows(scores, ld, m, N, K, idx_offset, exclude_idx ? exclude_idx + o : nullptr, keys, out_scores + o * K,
                                  out_idx + o * K, s));

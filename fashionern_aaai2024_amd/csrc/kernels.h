@@ -102,10 +102,15 @@ hipError_t launch_resample_v(const unsigned char* src, long src_ld, int x0, int 
 hipError_t launch_u8_to_chw(const unsigned char* src, long src_ld, int x0, int y0, float* dst, int n, long src_img_stride, int oh, int ow,
                             const float* mean, const float* stdv, hipStream_t s);
 
+// ---- bf16 gallery sweep (sweep_bf16.hip) ---------------------------------------------------------------------------
+hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStream_t s);
+// scores[q, n] = Q[q] . G[n] for q < B <= 64, bf16 gallery [N, D] (D % 64 == 0), fp32 accumulate, scores row stride ld
+hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, hipStream_t s);
+
 // ---- top-K (topk.hip) ------------------------------------------------------------------------
 // Per row of `scores` [B, ld] (n valid columns): K best (score desc, index asc).  out idx = col + idx_offset.
-// `keys_ws` must hold B * nseg * 64 uint64 (nseg = topk_num_segments(n)).
-int topk_num_segments(long n);
+// `keys_ws` must hold B * nseg * 64 uint64 (nseg = topk_num_segments(B, n)).
+int topk_num_segments(int B, long n);
 hipError_t launch_topk_rows(const float* scores, long ld, int B, long n, int K, long idx_offset, const int* exclude_idx,
                             unsigned long long* keys_ws, float* out_scores, int* out_idx, hipStream_t s);
 // Merge R lists [R,B,K] (score, idx) -> [B,K]

@@ -1,0 +1,169 @@
+// HBM-bound cosine sweep over a bf16 gallery (BASELINE config 5: "bf16 similarity"): scores[q][n] = Q[q] . G[n] with
+// fp32 accumulation on v_mfma_f32_32x32x16_bf16.
+//
+// In fp32 the B = 64 sweep is MFMA-bound (2*B*N*D / 157 TF > N*D*4 / 8 TB/s); with a bf16 gallery the matrix cores are
+// 16x faster and the gallery bytes halve, so the kernel is a pure HBM stream and is built as one:
+//   * the (<= 64) queries are converted to bf16 once and stay in LDS (padded rows: conflict-free ds_read_b128);
+//   * every WAVE streams its own 32-row gallery tiles through a private LDS ring with global_load_lds_dwordx4
+//     (4 KiB stages = 32 rows x 64 k, swizzle on the per-lane source address) -- there is NO workgroup barrier in the
+//     main loop, only the wave's own counted s_waitcnt vmcnt(N), and STAGES-1 stages (12-16 KiB per wave, 48-64 KiB
+//     per CU) stay in flight to cover HBM latency;
+//   * MFMA operands: A = queries (rows on the registers), B = gallery rows (row on the lane), so a 32x32 accumulator
+//     register holds 32 consecutive gallery rows of one query: score stores are 128-byte coalesced.
+// Top-K selection then runs on the fp32 score chunk exactly as in the fp32 path.
+#include "kernels.h"
+
+namespace fern {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ u16 f32_to_bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);      // round to nearest even (inputs are finite cosine features)
+    return (u16)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* x, u16* y, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    ushort4 o;
+    o.x = f32_to_bf16_rne(v[0]); o.y = f32_to_bf16_rne(v[1]); o.z = f32_to_bf16_rne(v[2]); o.w = f32_to_bf16_rne(v[3]);
+    reinterpret_cast<ushort4*>(y)[i] = o;
+}
+
+constexpr int ROWS_T = 32;              // gallery rows per wave tile
+constexpr int KSTAGE = 64;              // k elements per ring stage (128 bytes per row)
+constexpr int STAGE_BYTES = ROWS_T * KSTAGE * 2;   // 4096
+
+template <int STAGES>
+__global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u16* g, float* scores, long ld, int B, long N, int D) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int q_stride = D * 2 + 16;                               // bytes; +16 spreads rows over the banks
+    unsigned char* ring_base = smem + ((64 * q_stride + 1023) & ~1023);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- queries -> bf16 -> LDS (rows >= B are zero) ----
+    for (int i = tid; i < 64 * (D / 8); i += 256) {
+        const int row = i / (D / 8), c8 = (i % (D / 8)) * 8;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < B) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(q + (long)row * D + c8);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(q + (long)row * D + c8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (short)f32_to_bf16_rne(a[e]); v[4 + e] = (short)f32_to_bf16_rne(b[e]); }
+        }
+        *reinterpret_cast<bf16x8*>(smem + row * q_stride + c8 * 2) = v;
+    }
+    __syncthreads();
+
+    unsigned char* ring = ring_base + wave * (STAGES * STAGE_BYTES);
+    const int kchunks = D / KSTAGE;                                // stages per tile
+    const long ntiles = (N + ROWS_T - 1) / ROWS_T;
+    const long gw = (long)blockIdx.x * 4 + wave, GW = (long)gridDim.x * 4;
+    const long my_tiles = gw < ntiles ? (ntiles - gw + GW - 1) / GW : 0;
+    const long nstages = my_tiles * kchunks;
+
+    // DMA source of this lane inside a stage: piece p = 8 rows x 128 B; lane -> row p*8 + lane/8, position lane%8 holds
+    // logical chunk (lane%8) ^ ((row >> 1) & 7)
+    auto issue = [&](long s) {
+        const long t = gw + (s / kchunks) * GW;
+        const int kc = (int)(s % kchunks);
+        unsigned char* dst = ring + (int)(s % STAGES) * STAGE_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = p * 8 + (lane >> 3);
+            long n = t * ROWS_T + row;
+            n = n < N ? n : N - 1;
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const u16* src = g + n * D + kc * KSTAGE + chunk * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    for (long s = 0; s < STAGES - 1 && s < nstages; ++s) issue(s);
+    const int sw = (l31 >> 1) & 7;
+    for (long s = 0; s < nstages; ++s) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot about to be refilled has been read
+        if (s + STAGES - 1 < nstages) {
+            issue(s + STAGES - 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (STAGES - 1)) : "memory");   // stage s landed; newer ones stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned char* st = ring + (int)(s % STAGES) * STAGE_BYTES;
+        const int kc = (int)(s % kchunks);
+#pragma unroll
+        for (int ks = 0; ks < KSTAGE / 16; ++ks) {
+            const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(st + l31 * 128 + (((2 * ks + lh) ^ sw) * 16));
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(smem + (tm * 32 + l31) * q_stride + (kc * KSTAGE + ks * 16 + lh * 8) * 2);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[tm], 0, 0, 0);
+            }
+        }
+        if (kc == kchunks - 1) {                                     // tile finished: 128-byte coalesced score stores
+            const long t = gw + (s / kchunks) * GW;
+            const long n = t * ROWS_T + l31;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qi = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (qi < B && n < N) scores[(long)qi * ld + n] = acc[tm][r];
+                    acc[tm][r] = 0.0f;
+                }
+        }
+    }
+}
+
+hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, y, n / 4);
+    return hipGetLastError();
+}
+
+template <int STAGES>
+static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, hipStream_t s) {
+    const size_t lds = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024 + (size_t)4 * STAGES * STAGE_BYTES;
+    static size_t attr_set = 0;
+    auto kern = sweep_bf16_kernel<STAGES>;
+    if (lds > attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = lds;
+    }
+    const long ntiles = (N + ROWS_T - 1) / ROWS_T;
+    long blocks = (ntiles + 3) / 4;
+    if (blocks > 256) blocks = 256;                                // one persistent workgroup per CU
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, q, g, scores, ld, B, N, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, hipStream_t s) {
+    if (B <= 0 || N <= 0) return hipSuccess;
+    if (B > 64 || D % 64 || D > 1024) return hipErrorInvalidValue;
+    const size_t qbytes = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024;
+    const size_t room = (size_t)160 * 1024 - qbytes;
+    const int stages = (int)(room / (4 * STAGE_BYTES));
+    if (stages >= 5) return launch_sweep_inst<5>(q, g, scores, ld, B, N, D, s);
+    if (stages >= 4) return launch_sweep_inst<4>(q, g, scores, ld, B, N, D, s);
+    if (stages >= 3) return launch_sweep_inst<3>(q, g, scores, ld, B, N, D, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fern

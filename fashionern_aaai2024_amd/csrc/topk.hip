@@ -17,7 +17,6 @@
 namespace fern {
 
 typedef unsigned long long u64;
-constexpr int SEG = 8192;          // scores per level-1 workgroup
 
 __device__ __forceinline__ unsigned orderable(float f) {
     const unsigned u = __float_as_uint(f);
@@ -64,20 +63,31 @@ __device__ __forceinline__ void wave_offer(u64& best, u64 cand, int K, int lane)
 }
 
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, long ld, long n, int K, const int* exclude_idx,
-                                                        long idx_offset, u64* keys_ws, int nseg) {
+                                                        long idx_offset, u64* keys_ws, int nseg, long seg_size) {
     __shared__ u64 lists[4][64];
     const int seg = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* row = scores + (long)b * ld;
-    const long seg_lo = (long)seg * SEG;
-    const long seg_hi = seg_lo + SEG < n ? seg_lo + SEG : n;
-    const long per_wave = (SEG / 4);
+    const long seg_lo = (long)seg * seg_size;
+    const long seg_hi = seg_lo + seg_size < n ? seg_lo + seg_size : n;
+    const long per_wave = seg_size / 4;
     const long lo = seg_lo + wave * per_wave;
     const long hi = lo + per_wave < seg_hi ? lo + per_wave : seg_hi;
     const long excl = exclude_idx ? (long)exclude_idx[b] - idx_offset : -1;   // local column to drop
 
     u64 best = 0;
-    for (long base = lo; base < hi; base += 64) {
+    long base = lo;
+    for (; base + 256 <= hi; base += 256) {                  // 4 independent coalesced loads in flight, then 4 offers
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = row[base + u * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long j = base + u * 64 + lane;
+            wave_offer(best, j != excl ? make_key(v[u], (unsigned)j) : 0, K, lane);
+        }
+    }
+    for (; base < hi; base += 64) {
         const long j = base + lane;
         u64 cand = 0;
         if (j < hi && j != excl) cand = make_key(row[j], (unsigned)j);
@@ -138,14 +148,26 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float* scores, con
     }
 }
 
-int topk_num_segments(long n) { return (int)((n + SEG - 1) / SEG > 0 ? (n + SEG - 1) / SEG : 1); }
+// Scores per level-1 workgroup (4 waves): long enough that the number of per-wave lists -- and with it the total number
+// of insertions, ~K (1 + ln(len / K)) per list -- stays small on big galleries, short enough to fill the chip on small ones.
+long topk_segment_size(int B, long n) {
+    long per_wave = ((long)B * n / 4096 + 63) / 64 * 64;
+    per_wave = per_wave < 2048 ? 2048 : (per_wave > 65536 ? 65536 : per_wave);
+    return per_wave * 4;
+}
+int topk_num_segments(int B, long n) {
+    const long seg = topk_segment_size(B, n);
+    const long k = (n + seg - 1) / seg;
+    return (int)(k > 0 ? k : 1);
+}
 
 hipError_t launch_topk_rows(const float* scores, long ld, int B, long n, int K, long idx_offset, const int* exclude_idx, u64* keys_ws,
                             float* out_scores, int* out_idx, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (K < 1 || K > 64 || n < 0 || n > 0x7FFFFFF0L) return hipErrorInvalidValue;
-    const int nseg = topk_num_segments(n);
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(nseg, B), dim3(256), 0, s, scores, ld, n, K, exclude_idx, idx_offset, keys_ws, nseg);
+    const int nseg = topk_num_segments(B, n);
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(nseg, B), dim3(256), 0, s, scores, ld, n, K, exclude_idx, idx_offset, keys_ws, nseg,
+                       topk_segment_size(B, n));
     hipLaunchKernelGGL(topk_final_kernel, dim3(B), dim3(64), 0, s, keys_ws, nseg, K, idx_offset, out_scores, out_idx);
     return hipGetLastError();
 }

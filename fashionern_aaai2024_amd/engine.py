@@ -228,6 +228,28 @@ class FernEngine:
                                           int(idx_offset), _ptr(ex), _stream()), "fern_sim_topk")
         return scores, idx
 
+    def gallery_to_bf16(self, gallery) -> torch.Tensor:
+        """fp32 [N,D] -> bf16 [N,D] (round to nearest even) for `sim_topk_bf16`."""
+        g = self._f32(gallery)
+        out = torch.empty(g.shape, dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.fern_gallery_to_bf16(self._h, _ptr(g), _ptr(out), g.shape[0], g.shape[1], _stream()), "fern_gallery_to_bf16")
+        return out
+
+    def sim_topk_bf16(self, q, gallery_bf16: torch.Tensor, k: int, idx_offset: int = 0, exclude_idx=None):
+        q = self._f32(q)
+        g = gallery_bf16
+        if g.dtype != torch.bfloat16 or g.dim() != 2 or not g.is_cuda or not g.is_contiguous() or g.shape[1] != q.shape[1]:
+            raise ValueError("gallery must be a contiguous bf16 [N,D] device tensor sharing D with q")
+        b = q.shape[0]
+        scores = self._empty(b, k)
+        idx = self._empty(b, k, dtype=torch.int32)
+        ex = None
+        if exclude_idx is not None:
+            ex = torch.as_tensor(exclude_idx).to(device=self.device, dtype=torch.int32).contiguous()
+        _lib.check(self.lib.fern_sim_topk_bf16(self._h, _ptr(q), _ptr(g), b, g.shape[0], q.shape[1], int(k), _ptr(scores), _ptr(idx),
+                                               int(idx_offset), _ptr(ex), _stream()), "fern_sim_topk_bf16")
+        return scores, idx
+
     def gather_scores(self, q, gallery, idx):
         q, g = self._f32(q), self._f32(gallery)
         ix = torch.as_tensor(idx).to(device=self.device, dtype=torch.int32).contiguous()

@@ -182,6 +182,12 @@ FERN_API int fern_u8_to_normalized_chw(fern_ctx* ctx, const uint8_t* src, int64_
 FERN_API int fern_sim_topk(fern_ctx* ctx, const float* q /*[B,D]*/, const float* gallery /*[N,D]*/, int B,
                   int64_t N, int D, int K, float* out_scores /*[B,K]*/, int32_t* out_idx /*[B,K]*/,
                   int64_t idx_offset, const int32_t* exclude_idx, void* stream);
+/* bf16-gallery variant (BASELINE.json config 5, "bf16 similarity"): `gallery` is [N,D] bf16 produced by fern_gallery_to_bf16
+ * (round to nearest even); queries are rounded to bf16 inside the kernel; fp32 accumulation.  HBM-bound stream over the gallery.
+ * Cosine scores differ from the fp32 path by <= ~5e-4 (inside north_star's 1e-3); ordering is exact for the rounded operands. */
+FERN_API int fern_gallery_to_bf16(fern_ctx* ctx, const float* src, uint16_t* dst, int64_t n, int d, void* stream);
+FERN_API int fern_sim_topk_bf16(fern_ctx* ctx, const float* q /*[B,D] f32*/, const uint16_t* gallery /*[N,D] bf16*/, int B, int64_t N, int D,
+                                int K, float* out_scores, int32_t* out_idx, int64_t idx_offset, const int32_t* exclude_idx, void* stream);
 /* scores of explicitly named gallery rows (CIRR subset ranking, run/test/test_cirr.py:64-66);
  * idx < 0 -> -inf */
 FERN_API int fern_gather_scores(fern_ctx* ctx, const float* q /*[B,D]*/, const float* gallery /*[N,D]*/,

@@ -207,3 +207,46 @@ def test_pipeline_lanes_are_bit_identical_to_serial():
             assert torch.equal(i, ri) and torch.equal(s, rs)
     pipe.close()
     clip.engine.close()
+
+
+def _bf16_ref(q, g, k):
+    """Oracle for the bf16 sweep: the same rounding of both operands, fp32 products, exact ranking (score desc, index asc)."""
+    return orank.cosine_topk(q.bfloat16().float(), g.bfloat16().float(), k)
+
+
+@pytest.mark.parametrize("b,n,d", [(64, 46000, 512), (5, 1000, 640), (64, 33, 64), (130, 5000, 128), (1, 100_000, 512)])
+def test_bf16_gallery_sweep(b, n, d):
+    eng, _ = fused_engine(512)
+    q, g = unit(b, d, "bq"), unit(n, d, "bg")
+    gb = eng.gallery_to_bf16(g)
+    assert torch.equal(gb.cpu(), g.bfloat16()), "fp32 -> bf16 must be round-to-nearest-even"
+    s, i = eng.sim_topk_bf16(q, gb, 50)
+    rs, ri = _bf16_ref(q, g, 50)
+    kk = min(50, n)
+    assert (s.cpu()[:, :kk] - rs[:, :kk]).abs().max().item() < 2e-6          # same operands: only the fp32 summation order differs
+    full = q.bfloat16().float() @ g.bfloat16().float().T
+    for row, col in zip(*np.nonzero((i.cpu() != ri).numpy())):
+        assert abs(full[row, i[row, col].item()].item() - full[row, ri[row, col]].item()) < 2e-6
+    fs, fi = orank.cosine_topk(q, g, 50)                                       # vs fp32 truth: north_star's 1e-3 at the path's widths
+    assert (s.cpu()[:, :kk] - fs[:, :kk]).abs().max().item() < (1e-3 if d >= 512 else 4e-3)
+
+
+def test_bf16_sweep_exact_ties_and_one_million_rows():
+    eng, _ = fused_engine(512)
+    g = torch.Generator().manual_seed(5)
+    q = torch.randint(-1, 2, (7, 64), generator=g).float() / 8          # exactly representable in bf16: exact products, many ties
+    gal = torch.randint(-1, 2, (70_000, 64), generator=g).float() / 8
+    ex = torch.tensor([1000, -1, 1005, 3, 2000, -1, 1001], dtype=torch.int32)
+    s, i = eng.sim_topk_bf16(q, eng.gallery_to_bf16(gal), 51, idx_offset=1000, exclude_idx=ex)
+    rs, ri = orank.cosine_topk(q, gal, 51, idx_offset=1000, exclude_idx=ex)
+    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
+    big = torch.from_numpy(synth.unit_rows(125_000, 512, tag="c5g")).cuda().repeat(8, 1)
+    big[125_000:] += torch.linspace(0, 1e-3, 875_000, device="cuda")[:, None]
+    qq = unit(64, 512, "c5q").cuda()
+    bb = eng.gallery_to_bf16(big)
+    s, i = eng.sim_topk_bf16(qq, bb, 50)
+    s_c, i_c = s.cpu(), i.cpu()
+    assert (s_c[:, :-1] >= s_c[:, 1:]).all() and (i_c >= 0).all() and (i_c < 1_000_000).all()
+    rows = bb[i_c[:4].flatten().long().cuda()].float().cpu().view(4, 50, 512)
+    got = (qq[:4].bfloat16().float().cpu().unsqueeze(1) * rows).sum(-1)
+    assert (got - s_c[:4]).abs().max().item() < 2e-6
