@@ -103,3 +103,37 @@ def gather_rows(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x.contiguous())
     return out
+
+
+def extract_index_features_sharded(dataset, clip_model, patch_num, device, feature_dim, batch_size: int = 32, num_workers: int = 0):
+    """Gallery ENCODE sharded over the ranks (the other half of the gallery build): rank r runs the reference's
+    `extract_index_features` loop (utils/utils.py:44-69) on items [r*ceil(N/W), ...) of `dataset`, then the raw features, the
+    13-patch local features and the names are all-gathered so that every rank returns the same
+    `(index_whole_features [N,D], index_names, index_local_features [N,P,D])` the single-GPU function returns."""
+    from torch.utils.data import Subset
+
+    from .utils import extract_index_features
+    rank, world = world_info()
+    n = len(dataset)
+    if world == 1:
+        return extract_index_features(dataset, clip_model, patch_num, device, feature_dim, batch_size, num_workers)
+    start, stop, per = shard_rows(n, rank, world)
+    device = torch.device(device)
+    feats = torch.zeros((per, feature_dim), dtype=torch.float32, device=device)
+    local = torch.zeros((per, patch_num, feature_dim), dtype=torch.float32, device=device)
+    names = []
+    if stop > start:
+        f, names, l = extract_index_features(Subset(dataset, range(start, stop)), clip_model, patch_num, device, feature_dim,
+                                             batch_size, num_workers)
+        feats[: f.shape[0]] = f
+        local[: l.shape[0]] = l
+    all_f = torch.empty((world * per, feature_dim), dtype=torch.float32, device=device)
+    all_l = torch.empty((world * per, patch_num, feature_dim), dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(all_f, feats)
+    dist.all_gather_into_tensor(all_l, local)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, list(names))
+    counts = [len(g) for g in gathered]
+    keep = torch.cat([torch.arange(r * per, r * per + c, device=device) for r, c in enumerate(counts)]) if sum(counts) else \
+        torch.empty(0, dtype=torch.long, device=device)
+    return all_f[keep], [nm for g in gathered for nm in g], all_l[keep]

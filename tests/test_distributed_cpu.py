@@ -44,8 +44,14 @@ def _worker(rank, world, port, n, out_dir):
     start, stop, _ = fd.shard_rows(n, rank, world)
     ex = torch.tensor([3, -1, n - 1, 0, 5, -1, 7, 8, 9, 1], dtype=torch.int32)
     s_sh, i_sh = fd.rank_sharded(eng, q_all, gallery[start:stop], start, 7, exclude_idx=ex)
+    # sharded gallery ENCODE: every rank ends up with the same (features, names, local features) as the single-process loop
+    import synthetic_data as sdata
+    gal = sdata.Gallery(n, d, seed=5)
+    clip = sdata.StubCLIP(d).eval()
+    ef, en, el = fd.extract_index_features_sharded(sdata.ClassicDataset(gal), clip, 13, "cpu", d, batch_size=16)
     if rank == 0:
-        np.savez(os.path.join(out_dir, "r0.npz"), gallery=gallery.numpy(), s=s_all.numpy(), i=i_all.numpy(), s_sh=s_sh.numpy(), i_sh=i_sh.numpy())
+        np.savez(os.path.join(out_dir, "r0.npz"), gallery=gallery.numpy(), s=s_all.numpy(), i=i_all.numpy(), s_sh=s_sh.numpy(), i_sh=i_sh.numpy(),
+                 ef=ef.numpy(), el=el.numpy(), en=np.array(en))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,6 +75,11 @@ def test_two_rank_layout_matches_single_process(tmp_path, n):
     q = torch.from_numpy(synth.unit_rows(10, d, tag="q"))
     s, i = orank.cosine_topk(q, gallery, 7)
     assert np.array_equal(got["i"], i.numpy()) and np.allclose(got["s"], s.numpy(), atol=1e-6)
+    import synthetic_data as sdata
+    from fashionern_aaai2024_amd.utils import extract_index_features
+    gal = sdata.Gallery(n, d, seed=5)
+    f1, n1, l1 = extract_index_features(sdata.ClassicDataset(gal), sdata.StubCLIP(d).eval(), 13, "cpu", d, num_workers=0)
+    assert list(got["en"]) == n1 and np.allclose(got["ef"], f1.numpy(), atol=1e-6) and np.array_equal(got["el"], l1.numpy())
     ex = torch.tensor([3, -1, n - 1, 0, 5, -1, 7, 8, 9, 1], dtype=torch.int32)
     s2, i2 = orank.cosine_topk(q, gallery, 7, exclude_idx=ex)
     assert np.array_equal(got["i_sh"], i2.numpy()) and np.allclose(got["s_sh"], s2.numpy(), atol=1e-6)
