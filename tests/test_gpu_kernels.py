@@ -199,3 +199,26 @@ def test_topk_large_gallery_many_segments(engine):
     rs, ri = orank.cosine_topk(q, g, 51)
     s, i = engine.sim_topk(q, g, 51)
     assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 8, 9, 10, 11])
+def test_every_gemm_tile_variant_passes_the_shape_suite(cfg):
+    """The launcher autotunes the tile per shape, so each variant is also forced (FERN_GEMM_CFG, read once per process) over
+    the whole GEMM shape / epilogue suite, incl. the integer-exactness test: all variants must agree bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FERN_GEMM_CFG=str(cfg))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "-m", "gpu", "-q", "-x", "-k", "test_gemm", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_gemm_variants_are_bit_identical(engine):
+    """Same k summation order in every tile shape: forcing nothing but changing M (which changes the tuned tile) must not
+    change a row's bits."""
+    a, w, b = _rand(3000, 768, seed=11), _rand(768, 768, seed=12, scale=768 ** -0.5), _rand(768, seed=13)
+    full = engine.gemm(a, w, b, epilogue=1).cpu()
+    for lo, hi in ((0, 1), (0, 64), (100, 1124), (2990, 3000)):
+        assert torch.equal(engine.gemm(a[lo:hi], w, b, epilogue=1).cpu(), full[lo:hi])
