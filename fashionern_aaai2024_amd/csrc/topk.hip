@@ -38,17 +38,62 @@ __device__ __forceinline__ u64 shfl64(u64 v, int src) {       // src must be wav
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
     return ((u64)hi << 32) | lo;
 }
+__device__ __forceinline__ u64 shfl64v(u64 v, int src) {      // per-lane source
+    const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
 __device__ __forceinline__ u64 shfl_up64(u64 v) {             // lane i <- lane i-1 (lane 0 keeps its value)
     const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)v, (int)(unsigned)v, 0x138, 0xf, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(v >> 32), (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
     return ((u64)(unsigned)hi << 32) | (unsigned)lo;
 }
 
-// Offer one candidate per lane (key 0 = no candidate) to the wave's sorted list `best` (lane i = i-th best).
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
+    return ((u64)hi << 32) | lo;
+}
+// v holds a BITONIC sequence across the lanes: sort it descending (lane 0 = largest) with log2(64) compare-exchange stages.
+__device__ __forceinline__ u64 bitonic_finish_desc(u64 v, int lane) {
+#pragma unroll
+    for (int st = 32; st >= 1; st >>= 1) {
+        const u64 o = shfl_xor64(v, st);
+        const bool low = (lane & st) == 0;                         // the lower lane of a pair keeps the larger key
+        v = low ? (v > o ? v : o) : (v > o ? o : v);
+    }
+    return v;
+}
+// Top-64 of the union of two descending-sorted 64-entry lists: max(a[i], b[63-i]) is bitonic and holds exactly those.
+__device__ __forceinline__ u64 merge_sorted_desc(u64 a, u64 b_sorted, int lane) {
+    const u64 r = shfl64v(b_sorted, 63 - lane);
+    return bitonic_finish_desc(a > r ? a : r, lane);
+}
+// Full bitonic sort (descending) of one key per lane.
+__device__ __forceinline__ u64 sort64_desc(u64 v, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            const u64 o = shfl_xor64(v, j);
+            const bool desc = (lane & k) == 0 || k == 64;          // final pass: whole wave descending
+            const bool low = (lane & j) == 0;
+            const bool keep_max = desc ? low : !low;
+            v = keep_max ? (v > o ? v : o) : (v > o ? o : v);
+        }
+    }
+    return v;
+}
+
+// Offer one candidate per lane (key 0 = no candidate) to the wave's sorted list `best` (lane i = i-th best).  Few
+// survivors of the threshold test are inserted one by one (O(1) wave ops each); many (list still filling) are sorted and
+// merged as a batch, which costs the same whatever their number.
 __device__ __forceinline__ void wave_offer(u64& best, u64 cand, int K, int lane) {
     u64 thr = shfl64(best, K - 1);
     u64 mask = __ballot(cand > thr);
     if (mask == 0) return;                                        // the common case after warm-up: nothing beats the K-th entry
+    if (__popcll(mask) > 6) {
+        best = merge_sorted_desc(best, sort64_desc(cand, lane), lane);
+        return;
+    }
     while (mask) {
         const int src = __ffsll((long long)mask) - 1;
         const u64 c = shfl64(cand, src);
@@ -97,7 +142,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, lon
     __syncthreads();
     if (wave == 0) {
 #pragma unroll 1
-        for (int w = 1; w < 4; ++w) wave_offer(best, lists[w][lane], K, lane);
+        for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, lists[w][lane], lane);     // the other waves' lists are sorted
         keys_ws[((long)b * nseg + seg) * 64 + lane] = best;
     }
 }
@@ -108,7 +153,7 @@ __global__ __launch_bounds__(64) void topk_final_kernel(const u64* keys_ws, int 
     const int b = blockIdx.x, lane = threadIdx.x;
     u64 best = keys_ws[(long)b * nlists * 64 + lane];
 #pragma unroll 1
-    for (int l = 1; l < nlists; ++l) wave_offer(best, keys_ws[((long)b * nlists + l) * 64 + lane], K, lane);
+    for (int l = 1; l < nlists; ++l) best = merge_sorted_desc(best, keys_ws[((long)b * nlists + l) * 64 + lane], lane);
     if (lane < K) {
         float s = -INFINITY;
         int idx = -1;
