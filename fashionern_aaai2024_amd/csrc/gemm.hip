@@ -424,9 +424,11 @@ static const TileCfg kCfgs[] = {
     {128, 128, 16, 1.00f},   // 14: as 8, copy drained before the MFMAs (A/B)
     {128, 128, 16, 1.00f},   // 15: as 8, wait/barrier pinned after all MFMAs (A/B)
     {64, 64, 16, 0.86f},     // 16: ONE wave per workgroup (64x64 tile): no inter-wave barrier at all (experimental)
+    {128, 128, 16, 1.00f},   // 17: 8 waves of 64x32 (more resident waves per SIMD; experimental)
+    {128, 128, 16, 1.00f},   // 18: 8 waves of 32x64 (experimental)
 };
 constexpr int kNumAuto = 4;      // configs the heuristic may pick
-constexpr int kNumCfgs = 17;
+constexpr int kNumCfgs = 19;
 
 static int forced_cfg() {
     static int v = [] {
@@ -497,7 +499,9 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
         case 13: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 64, 64, 16, 2>), dim3(nb), dim3(512), 0, s, p); break;
         case 14: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4, false, 1>), dim3(nb), dim3(256), 0, s, p); break;
         case 15: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4, false, 2>), dim3(nb), dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 64, 64, 16, 4>), dim3(nb), dim3(64), 0, s, p); break;
+        case 16: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 64, 64, 16, 4>), dim3(nb), dim3(64), 0, s, p); break;
+        case 17: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 32, 16, 6>), dim3(nb), dim3(512), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 32, 64, 16, 6>), dim3(nb), dim3(512), 0, s, p); break;
     }
     return hipGetLastError();
 }
