@@ -48,7 +48,7 @@ struct HostTensor {
     size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
 };
 
-struct LinearW { const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0; };
+struct LinearW { const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0; const unsigned short* wb = nullptr; /* bf16 copy of w (encoder blocks) */ };
 struct LNW { const float* g = nullptr; const float* b = nullptr; };
 struct CombinerW { LinearW text, image, hidden; const float* w2 = nullptr; const float* b2 = nullptr; };
 struct SRW {
@@ -100,6 +100,7 @@ struct fern_ctx {
     FusionW fusion;
     ClipW clip;
     Clip4CirW c4c;
+    int precision = FERN_PREC_FP32;  // operand precision of the CLIP towers' token-level GEMMs (fern_set_precision)
     // workspace arena (bump allocator; blocks are consolidated at the start of the next op)
     struct Block { char* p; size_t cap; };
     std::vector<Block> blocks;
@@ -179,6 +180,19 @@ static GemmParams gemm_desc(const float* A, long lda, const LinearW& L, float* C
     p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.in; p.bias = L.b; p.C = C; p.ldc = ldc;
     p.M = M; p.N = L.out; p.K = L.in; p.epi = epi; p.aload = ALOAD_PLAIN;
     return p;
+}
+// bf16-operand GEMM of the encoder "perf mode": A is a bf16 activation buffer, the weight is the layer's bf16 copy
+static GemmParams gemm_desc_b(const unsigned short* A, long lda, const LinearW& L, void* C, long ldc, int M, int epi, bool out_bf16) {
+    GemmParams p{};
+    p.Ab = A; p.lda = lda; p.Wb = L.wb; p.ldw = L.in; p.bias = L.b; p.C = reinterpret_cast<float*>(C); p.ldc = ldc;
+    p.M = M; p.N = L.out; p.K = L.in; p.epi = epi; p.aload = ALOAD_PLAIN; p.out_bf16 = out_bf16 ? 1 : 0;
+    return p;
+}
+static int run_gemm_b(fern_ctx* c, const GemmParams& p, hipStream_t s) {
+    int slot;
+    FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, 100 + p.epi));
+    HIP_TRY(launch_gemm_bf16(p, s));
+    return prof_close(c, slot, s);
 }
 static int run_attention(fern_ctx* c, const AttnParams& a, hipStream_t s) {
     int slot;
@@ -319,6 +333,7 @@ extern "C" int fern_ctx_fork(fern_ctx* parent, fern_ctx** out) {
     c->fusion = parent->fusion;      // pointers into the parent's `owned` buffers; the parent must outlive its forks
     c->clip = parent->clip;
     c->c4c = parent->c4c;
+    c->precision = parent->precision;
     *out = c;
     return FERN_OK;
 }
@@ -423,6 +438,17 @@ extern "C" int fern_finalize_fusion(fern_ctx* c, int D, int parts) {
     return FERN_OK;
 }
 
+// bf16 (round-to-nearest-even) device copy of an uploaded fp32 weight matrix, for the perf-mode GEMMs
+static int make_bf16(fern_ctx* c, LinearW* L) {
+    const size_t n = (size_t)L->out * L->in;
+    unsigned short* d = nullptr;
+    HIP_TRY(hipMalloc(&d, n * sizeof(unsigned short)));
+    c->owned.push_back(d);
+    HIP_TRY(launch_f32_to_bf16(L->w, d, (long)n, nullptr));
+    L->wb = d;
+    return FERN_OK;
+}
+
 static int up_clip_block(fern_ctx* c, const std::string& p, int width, int mlp, ClipBlockW* B) {
     FERN_TRY(up_ln(c, p + ".ln_1", width, &B->ln1));
     FERN_TRY(up_key(c, p + ".attn.in_proj_weight", {3 * width, width}, &B->qkv.w));
@@ -431,7 +457,11 @@ static int up_clip_block(fern_ctx* c, const std::string& p, int width, int mlp, 
     FERN_TRY(up_linear(c, p + ".attn.out_proj", width, width, &B->out));
     FERN_TRY(up_ln(c, p + ".ln_2", width, &B->ln2));
     FERN_TRY(up_linear(c, p + ".mlp.c_fc", mlp, width, &B->fc));
-    return up_linear(c, p + ".mlp.c_proj", width, mlp, &B->proj);
+    FERN_TRY(up_linear(c, p + ".mlp.c_proj", width, mlp, &B->proj));
+    FERN_TRY(make_bf16(c, &B->qkv));
+    FERN_TRY(make_bf16(c, &B->out));
+    FERN_TRY(make_bf16(c, &B->fc));
+    return make_bf16(c, &B->proj);
 }
 
 // conv (no bias) + BatchNorm(eval) -> [cout_pad][kh*kw*cin_pad] weights in (ky, kx, ci) order (or the original (ci, ky, kx)
@@ -542,9 +572,18 @@ extern "C" int fern_finalize_clip(fern_ctx* c, const fern_clip_config* cfg) {
         for (int i = 0; i < cfg->t_layers; ++i)
             FERN_TRY(up_clip_block(c, "transformer.resblocks." + std::to_string(i), tw, cfg->t_mlp, &W.tblocks[i]));
     }
+    HIP_TRY(hipStreamSynchronize(nullptr));      // bf16 weight copies are converted on the null stream
     W.ready = true;
     return FERN_OK;
 }
+
+extern "C" int fern_set_precision(fern_ctx* c, int precision) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_set_precision: ctx is NULL");
+    if (precision != FERN_PREC_FP32 && precision != FERN_PREC_BF16) return fail(FERN_ERR_ARG, "fern_set_precision: unknown precision");
+    c->precision = precision;
+    return FERN_OK;
+}
+extern "C" int fern_get_precision(fern_ctx* c) { return c ? c->precision : FERN_ERR_ARG; }
 
 // ------------------------------------------------------------------------------------------------
 // fusion building blocks (internal; workspace comes from the caller's arena)
@@ -820,6 +859,28 @@ static int clip_block(fern_ctx* c, const ClipBlockW& Bk, float* X, float* XN, fl
     return run_gemm(c, p2, s);
 }
 
+// Perf-mode block: the four token-level GEMMs take bf16 operands (LayerNorm / attention / GELU outputs are rounded to bf16
+// as they are written, weights are the bf16 copies) and accumulate in fp32; the residual stream X, the LayerNorm
+// statistics and the attention softmax stay fp32.
+static int clip_block_bf16(fern_ctx* c, const ClipBlockW& Bk, float* X, unsigned short* XNb, float* QKV, unsigned short* ATTb,
+                           unsigned short* Hb, int batch, int S, int width, int heads, int causal, hipStream_t s) {
+    const long R = (long)batch * S;
+    const int hd = width / heads;
+    HIP_TRY(launch_layernorm_bf16(X, Bk.ln1.g, Bk.ln1.b, XNb, R, width, width, width, 1e-5f, s));
+    FERN_TRY(run_gemm_b(c, gemm_desc_b(XNb, width, Bk.qkv, QKV, 3 * width, (int)R, EPI_BIAS, false), s));
+    AttnParams a{QKV, QKV + width, QKV + 2 * width, nullptr, 3L * width, 3L * width, 3L * width, (long)width,
+                 batch, heads, hd, S, S, causal, 1.0f / std::sqrt((float)hd), ATTb};
+    FERN_TRY(run_attention(c, a, s));
+    GemmParams po = gemm_desc_b(ATTb, width, Bk.out, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
+    po.R = X;
+    FERN_TRY(run_gemm_b(c, po, s));
+    HIP_TRY(launch_layernorm_bf16(X, Bk.ln2.g, Bk.ln2.b, XNb, R, width, width, width, 1e-5f, s));
+    FERN_TRY(run_gemm_b(c, gemm_desc_b(XNb, width, Bk.fc, Hb, Bk.fc.out, (int)R, EPI_BIAS_GELU, true), s));
+    GemmParams p2 = gemm_desc_b(Hb, Bk.fc.out, Bk.proj, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
+    p2.R = X;
+    return run_gemm_b(c, p2, s);
+}
+
 // Last ViT block: only the class token is consumed afterwards (ln_post on token 0, modeling_clip.py:876-877), so
 // K/V are projected for every token but Q, the attention output, out_proj and the MLP run for the class rows only.
 // Bit-identical to the full block on the rows that are read.
@@ -828,10 +889,19 @@ static int clip_block_cls_only(fern_ctx* c, const ClipBlockW& Bk, const float* X
                                int heads, hipStream_t s) {
     const long R = (long)batch * S;
     const int hd = width / heads;
-    HIP_TRY(launch_layernorm(X, nullptr, Bk.ln1.g, Bk.ln1.b, XN, R, width, width, width, 1e-5f, s));
-    LinearW kv{Bk.qkv.w + (size_t)width * width, Bk.qkv.b + width, 2 * width, width};
-    FERN_TRY(run_gemm(c, gemm_desc(XN, width, kv, QKV + width, 3 * width, (int)R, EPI_BIAS), s));      // K, V for all tokens
-    HIP_TRY(launch_gather_rows(XN, width, T0, width, batch, width, 1, S, 0, nullptr, s));              // ln_1(x)[:, 0]
+    LinearW kv{Bk.qkv.w + (size_t)width * width, Bk.qkv.b + width, 2 * width, width, Bk.qkv.wb + (size_t)width * width};
+    if (c->precision == FERN_PREC_BF16) {
+        // perf mode: the token-level K/V projection takes bf16 operands; the class-row chain below stays fp32
+        unsigned short* XNb = reinterpret_cast<unsigned short*>(XN);
+        HIP_TRY(launch_layernorm_bf16(X, Bk.ln1.g, Bk.ln1.b, XNb, R, width, width, width, 1e-5f, s));
+        FERN_TRY(run_gemm_b(c, gemm_desc_b(XNb, width, kv, QKV + width, 3 * width, (int)R, EPI_BIAS, false), s));
+        HIP_TRY(launch_gather_rows(X, width, T1, width, batch, width, 1, S, 0, nullptr, s));           // x[:, 0]
+        HIP_TRY(launch_layernorm(T1, nullptr, Bk.ln1.g, Bk.ln1.b, T0, batch, width, width, width, 1e-5f, s));   // ln_1(x)[:, 0]
+    } else {
+        HIP_TRY(launch_layernorm(X, nullptr, Bk.ln1.g, Bk.ln1.b, XN, R, width, width, width, 1e-5f, s));
+        FERN_TRY(run_gemm(c, gemm_desc(XN, width, kv, QKV + width, 3 * width, (int)R, EPI_BIAS), s));  // K, V for all tokens
+        HIP_TRY(launch_gather_rows(XN, width, T0, width, batch, width, 1, S, 0, nullptr, s));          // ln_1(x)[:, 0]
+    }
     LinearW qw{Bk.qkv.w, Bk.qkv.b, width, width};
     FERN_TRY(run_gemm(c, gemm_desc(T0, width, qw, T1, width, batch, EPI_BIAS), s));                    // Q for the class rows
     // one query per (batch, head): q rows are [batch, 1]; K/V are read in place from the packed buffer
@@ -870,7 +940,13 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
     FERN_TRY(run_gemm(c, pe, s));
     HIP_TRY(launch_vit_cls(W.cls, W.vpos, X, b, S, vw, s));
     HIP_TRY(launch_layernorm(X, nullptr, W.ln_pre.g, W.ln_pre.b, X, R, vw, vw, vw, 1e-5f, s));
-    for (int l = 0; l + 1 < cf.v_layers; ++l) FERN_TRY(clip_block(c, W.vblocks[l], X, XN, QKV, ATT, H, b, S, vw, cf.v_heads, 0, s));
+    for (int l = 0; l + 1 < cf.v_layers; ++l) {
+        if (c->precision == FERN_PREC_BF16)     // XN / ATT / H double as the bf16 operand buffers (half filled)
+            FERN_TRY(clip_block_bf16(c, W.vblocks[l], X, reinterpret_cast<unsigned short*>(XN), QKV, reinterpret_cast<unsigned short*>(ATT),
+                                     reinterpret_cast<unsigned short*>(H), b, S, vw, cf.v_heads, 0, s));
+        else
+            FERN_TRY(clip_block(c, W.vblocks[l], X, XN, QKV, ATT, H, b, S, vw, cf.v_heads, 0, s));
+    }
     // ATT / H are free after the last full block: reuse their heads as the [b, width] / [b, mlp] temporaries
     FERN_TRY(clip_block_cls_only(c, W.vblocks[cf.v_layers - 1], X, XN, QKV, CLS, ATT, ATT + (size_t)b * vw, H, b, S, vw, cf.v_heads, s));
     HIP_TRY(launch_layernorm(CLS, nullptr, W.ln_post.g, W.ln_post.b, CLS, b, vw, vw, vw, 1e-5f, s));
@@ -990,7 +1066,13 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
     FERN_TRY(ws_get(c, (size_t)R * cf.t_mlp, &H));
     FERN_TRY(ws_get(c, (size_t)B, &eot));
     HIP_TRY(launch_text_embed(tokens, W.tok_emb, W.tpos, X, eot, B, T, tw, cf.vocab_size, s));
-    for (int l = 0; l < cf.t_layers; ++l) FERN_TRY(clip_block(c, W.tblocks[l], X, XN, QKV, ATT, H, B, T, tw, cf.t_heads, 1, s));
+    for (int l = 0; l < cf.t_layers; ++l) {
+        if (c->precision == FERN_PREC_BF16)
+            FERN_TRY(clip_block_bf16(c, W.tblocks[l], X, reinterpret_cast<unsigned short*>(XN), QKV, reinterpret_cast<unsigned short*>(ATT),
+                                     reinterpret_cast<unsigned short*>(H), B, T, tw, cf.t_heads, 1, s));
+        else
+            FERN_TRY(clip_block(c, W.tblocks[l], X, XN, QKV, ATT, H, B, T, tw, cf.t_heads, 1, s));
+    }
     HIP_TRY(launch_layernorm(X, nullptr, W.ln_final.g, W.ln_final.b, XN, R, tw, tw, tw, 1e-5f, s));
     LinearW proj{W.tproj_t, nullptr, E, tw};
     if (out_seq) {
@@ -1157,6 +1239,24 @@ extern "C" int fern_gemm(fern_ctx* c, const float* A, int64_t lda, const float* 
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.R = residual; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aload = ALOAD_PLAIN;
     return run_gemm(c, p, (hipStream_t)stream);
+}
+
+extern "C" int fern_gemm_bf16(fern_ctx* c, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias,
+                              const float* residual, void* C, int64_t ldc, int M, int N, int K, int epilogue, int out_bf16, void* stream) {
+    if (!c || M < 0 || N < 0 || K <= 0) return fail(FERN_ERR_ARG, "fern_gemm_bf16: bad argument");
+    if (M == 0 || N == 0) return FERN_OK;
+    if (!A || !W || !C) return fail(FERN_ERR_ARG, "fern_gemm_bf16: NULL argument");
+    if (epilogue < FERN_EPI_BIAS || epilogue > FERN_EPI_BIAS_RESIDUAL) return fail(FERN_ERR_ARG, "fern_gemm_bf16: unknown epilogue");
+    if (epilogue == FERN_EPI_BIAS_RESIDUAL && (!residual || out_bf16)) return fail(FERN_ERR_ARG, "fern_gemm_bf16: the residual epilogue needs a residual and fp32 output");
+    if (K % 32 || lda % 8 || ldw % 8) return fail(FERN_ERR_ARG, "fern_gemm_bf16: K % 32, lda % 8 and ldw % 8 must be 0");
+    HIP_TRY(hipSetDevice(c->device));
+    GemmParams p{};
+    p.Ab = A; p.lda = lda; p.Wb = W; p.ldw = ldw; p.bias = bias; p.R = residual; p.C = reinterpret_cast<float*>(C); p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aload = ALOAD_PLAIN; p.out_bf16 = out_bf16 ? 1 : 0;
+    int slot;
+    FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * M * (double)N * K, (hipStream_t)stream, &slot, M, N, K, 100 + epilogue));
+    HIP_TRY(launch_gemm_bf16(p, (hipStream_t)stream));
+    return prof_close(c, slot, (hipStream_t)stream);
 }
 
 extern "C" int fern_layernorm(fern_ctx* c, const float* x, const float* residual, const float* gamma, const float* beta, float* y,

@@ -126,7 +126,21 @@ __global__ __launch_bounds__(NW * 64) void attn_f32_kernel(AttnParams p) {
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
         // ---- store: lane (query, half) holds d = 32*db + 8*g + 4*half + {0..3} in registers 4g..4g+3 ----
-        if (qi < p.s_q) {
+        if (qi < p.s_q && p.out_b) {
+            unsigned short* ob = p.out_b + ((long)b * p.s_q + qi) * p.ldo + (long)h * hd;
+#pragma unroll
+            for (int db = 0; db < HDP / 32; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = db * 32 + 8 * g + 4 * lh;
+                    if (d < hd) {
+                        ushort4 t;
+                        t.x = f32_to_bf16_bits(o[db][4 * g] * inv); t.y = f32_to_bf16_bits(o[db][4 * g + 1] * inv);
+                        t.z = f32_to_bf16_bits(o[db][4 * g + 2] * inv); t.w = f32_to_bf16_bits(o[db][4 * g + 3] * inv);
+                        *reinterpret_cast<ushort4*>(ob + d) = t;
+                    }
+                }
+        } else if (qi < p.s_q) {
             float* ob = p.out + ((long)b * p.s_q + qi) * p.ldo + (long)h * hd;
 #pragma unroll
             for (int db = 0; db < HDP / 32; ++db)

@@ -91,6 +91,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     row_store(r, y + row * ldy, d, lane);
 }
 
+__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* x, const float* gamma, const float* beta, unsigned short* y,
+                                                             long rows, int d, long ldx, long ldy, float eps) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    RowRegs r;
+    row_load(r, x + row * ldx, d, lane);
+    row_layernorm(r, gamma, beta, d, lane, eps);
+    unsigned short* yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            ushort4 o;
+            o.x = f32_to_bf16_bits(r.v[i][0]); o.y = f32_to_bf16_bits(r.v[i][1]);
+            o.z = f32_to_bf16_bits(r.v[i][2]); o.w = f32_to_bf16_bits(r.v[i][3]);
+            *reinterpret_cast<ushort4*>(yr + c) = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* x, const float* x2, long ldx, float* y, long ldy, long rows, int d,
                                                      float eps, int mode) {
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -364,6 +385,13 @@ hipError_t launch_layernorm(const float* x, const float* res, const float* gamma
     if (rows <= 0) return hipSuccess;
     if (bad_width(d) || (ldx & 3) || (ldy & 3)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(layernorm_kernel, row_grid(rows), dim3(256), 0, s, x, res, gamma, beta, y, rows, d, ldx, ldy, eps);
+    return hipGetLastError();
+}
+hipError_t launch_layernorm_bf16(const float* x, const float* gamma, const float* beta, unsigned short* y, long rows, int d, long ldx,
+                                 long ldy, float eps, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (bad_width(d) || (ldx & 3) || (ldy & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_bf16_kernel, row_grid(rows), dim3(256), 0, s, x, gamma, beta, y, rows, d, ldx, ldy, eps);
     return hipGetLastError();
 }
 hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s,

@@ -15,118 +15,13 @@
 //     ds_read_b128 feeds four MFMAs; both operands use the same permutation, so the sum is unchanged;
 //   * workgroup ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
 #include "kernels.h"
+#include "gemm_epilogue.h"
 
 #include <cstdlib>
 #include <map>
 #include <mutex>
 
 namespace fern {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// Exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at
-// fp32 rounding level) evaluated branch-free: 1 + erf(z) = 2 - P(t) e^{-z^2} for z >= 0 and P(t) e^{-z^2} for z < 0
-// (t = 1 / (1 + p |z|)), which also avoids the cancellation of 1 + erf(z) in the negative tail.  ~15 VALU ops per
-// element instead of the ~45 of libm's erff: the GELU epilogue of the 3072-wide MLP GEMMs was VALU-bound.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = x * 0.70710678118654752440f;
-    const float az = fabsf(z);
-    const float t = __frcp_rn(fmaf(0.3275911f, az, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float pe = poly * t * __expf(-az * az);
-    const float cdf2 = z >= 0.0f ? 2.0f - pe : pe;
-    return 0.5f * x * cdf2;
-}
-
-// Shared epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-template <int BM, int BN, int WM, int WN, int TM, int TN, int WAVES_N>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], float (*red)[BM], int bm, int bn, int nbn,
-                                              int wm, int wn, int l31, int lh, int tid) {
-    const int row_w = bm * BM + wm * WM;
-    const int col_w = bn * BN + wn * WN;
-    if (!epi_is_reduce(p.epi)) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = col_w + j * 32 + l31;
-                if (col >= p.N) continue;
-                const float bia = p.bias ? p.bias[col] : 0.0f;
-                float sc = 1.0f, sh = 0.0f;
-                if (p.epi == EPI_COLAFFINE_TANH) { sc = p.aux0[col]; sh = p.aux1[col]; }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row >= p.M) continue;
-                    float v = acc[i][j][r] + bia;
-                    long orow = row;
-                    switch (p.epi) {
-                        case EPI_BIAS_GELU: v = gelu_erf(v); break;
-                        case EPI_BIAS_RELU: v = fmaxf(v, 0.0f); break;
-                        case EPI_BIAS_RESIDUAL: v += p.R[(long)row * p.ldc + col]; break;
-                        case EPI_BIAS_RESIDUAL_RELU: v = fmaxf(v + p.R[(long)row * p.ldc + col], 0.0f); break;
-                        case EPI_COLAFFINE_TANH: v = tanhf(v * sc + sh); break;
-                        case EPI_PATCH_EMBED: {
-                            const int g2 = p.grid * p.grid;
-                            orow = row + row / g2 + 1;
-                            v += p.aux0[(long)((row % g2) + 1) * p.N + col];
-                        } break;
-                        default: break;
-                    }
-                    p.C[orow * p.ldc + col] = v;
-                }
-            }
-    } else {
-        // reduce epilogues: one partial sum per (row, column block); fixed summation order => deterministic
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // row inside the block tile
-                const int row = bm * BM + rl;
-                const int rowc = row < p.M ? row : p.M - 1;
-                float s = 0.0f;
-                float mu = 0.0f, inv = 1.0f, beta = 0.0f;
-                const float* grow = nullptr;
-                if (p.epi == EPI_SR_LOCAL) {
-                    const int pidx = rowc % 13;
-                    mu = p.aux1[pidx]; inv = p.aux2[pidx]; beta = p.aux3[pidx];
-                    grow = p.G + (long)(rowc / 13) * p.ldg;
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = col_w + j * 32 + l31;
-                    if (col < p.N) {
-                        float v = acc[i][j][r] + p.bias[col];
-                        if (p.epi == EPI_RELU_DOT) v = fmaxf(v, 0.0f) * p.aux0[col];
-                        else v = tanhf((v - mu) * inv + beta) * grow[col] * p.aux0[col];
-                        s += v;
-                    }
-                }
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 8);
-                s += __shfl_xor(s, 4);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 1);
-                if (l31 == 0) red[wn][rl] = s;
-            }
-        }
-        __syncthreads();
-        if (tid < BM) {
-            const int row = bm * BM + tid;
-            if (row < p.M) {
-                float s = 0.0f;
-#pragma unroll
-                for (int w = 0; w < WAVES_N; ++w) s += red[w][tid];
-                p.partial[(long)row * nbn + bn] = s;
-            }
-        }
-    }
-}
 
 // BM x BN block tile, WM x WN per wave (multiples of 32), BKT-wide k tiles, optional LDS double buffering.
 template <int BM, int BN, int WM, int WN, int BKT, bool DBUF>

@@ -1,0 +1,171 @@
+// bf16 MFMA GEMM for gfx950 (CDNA4): C[M,N] = A[M,K] * W[N,K]^T, bf16 operands, fp32 accumulation, fused epilogues.
+//
+// This is the "perf mode" of the encoder GEMMs (BASELINE config 5's reduced-precision encoder):
+// the CLIP towers' QKV / out-proj / MLP contractions with activations and weights rounded to bf16 (RNE) and summed in
+// fp32 on v_mfma_f32_32x32x16_bf16 (16 x the fp32 matrix rate).  The residual stream, LayerNorm statistics, softmax
+// and every epilogue stay fp32.
+//
+// Structure = the LDS-DMA fp32 kernel of gemm.hip in byte terms: A and W tiles go L2 -> LDS with
+// global_load_lds_dwordx4 (lane-linear 1 KiB pieces, bank swizzle applied on the per-lane SOURCE address), double
+// buffered, one barrier per k tile.  A tile row is BKE bf16 = 64 or 128 bytes; one ds_read_b128 fetches the 8
+// consecutive k values a lane feeds to one 32x32x16 MFMA (lane half h supplies k = 16*kk + 8*h .. +7 of both
+// operands).  Every configuration adds the 16-wide k groups in ascending order, so all of them produce bit-identical
+// results and a row's result does not depend on the batch it is part of.
+#include "gemm_epilogue.h"
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
+namespace fern {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WM, int WN, int BKE, int MINW>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_glds_kernel(GemmParams p) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int WAVES_M = BM / WM;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int ROWS = BM + BN;                        // A rows then W rows
+    constexpr int RB = BKE * 2;                          // bytes per tile row (64 or 128)
+    constexpr int C4 = RB / 16;                          // 16-byte chunks per tile row
+    constexpr int RPP = 64 / C4;                         // tile rows per 1 KiB piece
+    constexpr int PIECES = ROWS / RPP;
+    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+    constexpr int PPW = PIECES / NW;
+    constexpr int FSH = RB == 64 ? 2 : 1;                // chunk c of row r lives at position c ^ ((r >> FSH) & FMASK)
+    constexpr int FMASK = C4 - 1;
+    constexpr int TILE = ROWS * RB;                      // bytes per stage
+
+    // one __shared__ object (see gemm.hip: a second one makes hipcc drain the DMA before every first fragment read)
+    __shared__ __attribute__((aligned(1024))) char smem[2 * TILE + WAVES_N * BM * 4];
+    float (*red)[BM] = reinterpret_cast<float (*)[BM]>(smem + 2 * TILE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-aware bijective workgroup -> tile map (n fastest inside an XCD's contiguous run)
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nwg = nbm * nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int bm = swz / nbn, bn = swz % nbn;
+
+    const char* src[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave + NW * j;                       // wave-uniform
+        const int trow = piece * RPP + lane / C4;
+        const int chunk = (lane & FMASK) ^ ((trow >> FSH) & FMASK);
+        if (trow < BM) {
+            int row = bm * BM + trow;
+            row = row < p.M ? row : p.M - 1;
+            src[j] = reinterpret_cast<const char*>(p.Ab + (long)row * p.lda) + chunk * 16;
+        } else {
+            int row = bn * BN + (trow - BM);
+            row = row < p.N ? row : p.N - 1;
+            src[j] = reinterpret_cast<const char*>(p.Wb + (long)row * p.ldw) + chunk * 16;
+        }
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int piece = wave + NW * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long)k0 * 2),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * TILE + piece * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int sw = (l31 >> FSH) & FMASK;
+    auto compute = [&](int buf) {
+        const char* As = smem + buf * TILE;
+        const char* Ws = As + BM * RB;
+#pragma unroll
+        for (int kk = 0; kk < BKE / 16; ++kk) {
+            const int pc = ((2 * kk + lh) ^ sw) * 16;
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (wm * WM + i * 32 + l31) * RB + pc);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Ws + (wn * WN + j * 32 + l31) * RB + pc);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = p.K / BKE;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BKE);
+        compute(kt & 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, red, bm, bn, nbn, wm, wn, l31, lh, tid);
+}
+
+struct TileCfgB { int bm, bn, bk; };
+static const TileCfgB kCfgsB[] = {
+    {128, 128, 32},   // 0: 4 waves of 64x64, 64-byte rows
+    {128, 128, 64},   // 1: 128-byte rows
+    {256, 128, 32},   // 2: 8 waves of 64x64
+    {256, 128, 64},   // 3
+    {64, 128, 32},    // 4
+    {64, 128, 64},    // 5
+    {256, 256, 32},   // 6: 16 waves of 64x64
+    {256, 256, 64},   // 7
+};
+constexpr int kNumCfgsB = 8;
+
+static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
+    const int nb = ((p.M + kCfgsB[c].bm - 1) / kCfgsB[c].bm) * ((p.N + kCfgsB[c].bn - 1) / kCfgsB[c].bn);
+    switch (c) {
+        case 0: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2>), dim3(nb), dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 2>), dim3(nb), dim3(512), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 64, 2>), dim3(nb), dim3(512), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 32, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 5: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 64, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 6: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 64, 64, 32, 1>), dim3(nb), dim3(1024), 0, s, p); break;
+        case 7: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 64, 64, 64, 1>), dim3(nb), dim3(1024), 0, s, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+static int forced_cfg_b() {
+    static int v = [] {
+        const char* e = getenv("FERN_GEMM_BF16_CFG");
+        return e ? atoi(e) : -1;
+    }();
+    return v;
+}
+
+hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    if (p.K <= 0 || (p.K % 32) != 0 || (p.lda & 7) || (p.ldw & 7) || p.aload != ALOAD_PLAIN || epi_is_reduce(p.epi)) return hipErrorInvalidValue;
+    if (!p.Ab || !p.Wb || ((uintptr_t)p.Ab & 15) || ((uintptr_t)p.Wb & 15)) return hipErrorInvalidValue;
+    int c = forced_cfg_b();
+    if (c < 0 || c >= kNumCfgsB || p.K % kCfgsB[c].bk) c = (p.K % 64 == 0) ? 1 : 0;
+    return launch_cfg_b(c, p, s);
+}
+
+}  // namespace fern

@@ -42,10 +42,24 @@ struct GemmParams {
     int img, patch, grid;  // ALOAD_IM2COL: image side, patch side, patches per side; EPI_PATCH_EMBED uses grid*grid
     int conv_h, conv_w, conv_c;   // ALOAD_CONV3
     const float* zeros;           // ALOAD_CONV3: >= 64 bytes of zeros (16-byte aligned)
+    // bf16 operand form (launch_gemm_bf16): A [M, lda] and W [N, ldw] hold bf16 bit patterns, strides in elements
+    const unsigned short* Ab;
+    const unsigned short* Wb;
+    int out_bf16;                 // plain epilogues: store C as bf16 (ldc in elements) instead of fp32
 };
 // Number of column blocks the reduce epilogues write per row (depends on the tile chosen for this shape).
 int gemm_num_col_blocks(int M, int N, int K);
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+// bf16 x bf16 -> fp32-accumulate GEMM (v_mfma_f32_32x32x16_bf16); plain epilogues only, K % 32 == 0, ALOAD_PLAIN
+hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s);
+
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {   // round to nearest even (finite inputs)
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+#endif
 
 // ---- attention (attn.hip) ---------------------------------------------------------------------
 struct AttnParams {
@@ -53,12 +67,16 @@ struct AttnParams {
     long ldq, ldk, ldv, ldo;     // row strides (floats)
     int batch, heads, hd, s_q, s_k, causal;
     float scale;
+    unsigned short* out_b;       // when set: the output is stored as bf16 here (ldo in elements) instead of fp32 `out`
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);   // hipErrorInvalidValue for unsupported shapes
 
 // ---- row-wise / element-wise kernels (elem.hip) -------------------------------------------------
 hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                             long rows, int d, long ldx, long ldy, float eps, hipStream_t s);
+// same statistics, output rounded to bf16 (operand of the bf16 encoder GEMMs)
+hipError_t launch_layernorm_bf16(const float* x, const float* gamma, const float* beta, unsigned short* y, long rows, int d, long ldx,
+                                 long ldy, float eps, hipStream_t s);
 // mode 0: x / max(||x||, eps) (F.normalize); mode 1: x / (||x|| + eps) (VisualSR.l2norm)
 hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s,
                          const float* x2 = nullptr);   // x2: optional addend (normalize(x + x2))

@@ -20,6 +20,8 @@ COMBINER_TARGET, COMBINER_DVR_GLOBAL, COMBINER_DVR_LOCAL, COMBINER_DVR_FINAL = 0
 SR_TARGET, SR_DVR = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
 PART_DVR, PART_TARGET_SR, PART_TARGET_COMBINER, PART_ALL = 1, 2, 4, 7
+PREC_FP32, PREC_BF16 = 0, 1
+_PREC_NAMES = {"fp32": PREC_FP32, "bf16": PREC_BF16}
 PATCH_NUM = 13
 
 
@@ -60,6 +62,16 @@ class FernEngine:
         _lib.check(self.lib.fern_ctx_fork(self._h, C.byref(h)), "fern_ctx_fork")
         child._h = h
         return child
+
+    def set_precision(self, precision) -> None:
+        """Operand precision of the CLIP towers' token-level GEMMs: "fp32" (parity mode, default) or "bf16" (perf mode:
+        bf16 operands, fp32 accumulation -- include/fern.h:fern_precision)."""
+        prec = _PREC_NAMES[precision] if isinstance(precision, str) else int(precision)
+        _lib.check(self.lib.fern_set_precision(self._h, prec), "fern_set_precision")
+
+    @property
+    def precision(self) -> str:
+        return {v: k for k, v in _PREC_NAMES.items()}[self.lib.fern_get_precision(self._h)]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -276,6 +288,24 @@ class FernEngine:
         out = self._empty(m, n)
         _lib.check(self.lib.fern_gemm(self._h, _ptr(a), k, _ptr(w), k, _ptr(bias), _ptr(residual), _ptr(out), n, m, n, k,
                                       int(epilogue), _stream()), "fern_gemm")
+        return out
+
+    def to_bf16(self, x) -> torch.Tensor:
+        """fp32 [R,C] -> bf16 [R,C], round to nearest even (the conversion every bf16 operand of libfern goes through)."""
+        return self.gallery_to_bf16(x)
+
+    def gemm_bf16(self, a, w, bias=None, residual=None, epilogue=EPI_BIAS, out_bf16=False) -> torch.Tensor:
+        """bf16 x bf16 -> fp32-accumulate GEMM; a [M,K] / w [N,K] are bf16 tensors (fp32 inputs are rounded first)."""
+        a = a if a.dtype == torch.bfloat16 else self.to_bf16(a)
+        w = w if w.dtype == torch.bfloat16 else self.to_bf16(w)
+        a, w = a.to(self.device).contiguous(), w.to(self.device).contiguous()
+        m, k = a.shape
+        n = w.shape[0]
+        bias = None if bias is None else self._f32(bias, (n,))
+        residual = None if residual is None else self._f32(residual, (m, n))
+        out = torch.empty(m, n, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=self.device)
+        _lib.check(self.lib.fern_gemm_bf16(self._h, _ptr(a), k, _ptr(w), k, _ptr(bias), _ptr(residual), _ptr(out), n, m, n, k,
+                                           int(epilogue), int(bool(out_bf16)), _stream()), "fern_gemm_bf16")
         return out
 
     def layernorm(self, x, gamma, beta, eps: float, residual=None) -> torch.Tensor:

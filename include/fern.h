@@ -63,6 +63,18 @@ typedef enum {
     FERN_PART_ALL = 7               /* everything ERN owns  -> + fern_index_fuse */
 } fern_fusion_part;
 
+/* Operand precision of the CLIP towers' token-level GEMMs (BASELINE.json config 5 names a reduced-precision encoder;
+ * SURVEY.md 7 step 6 "perf mode").  FP32 is the parity mode (exact fp32 FMA chains on the fp32 MFMA) and the default.
+ * BF16: in every full transformer block of both towers the QKV / out-proj / c_fc / c_proj contractions (and the last ViT
+ * block's K/V projection) read activations and weights rounded to bf16 (RNE) and accumulate in fp32; the residual
+ * stream, LayerNorm statistics, softmax, GELU, patch embedding, class-token chain of the last ViT block, final
+ * projections and the whole fusion / ranking path stay fp32.  Rounding points are fixed by the layer structure, not by
+ * the batch size, so results remain batch-invariant. */
+typedef enum {
+    FERN_PREC_FP32 = 0,
+    FERN_PREC_BF16 = 1
+} fern_precision;
+
 typedef enum {
     FERN_SR_TARGET = 0,            /* ERN.SR_module            (model.py:19) */
     FERN_SR_DVR = 1                /* DVR.SR_module            (fusion_model.py:17) */
@@ -149,6 +161,10 @@ FERN_API int fern_combiner(fern_ctx* ctx, int which, const float* image /*[n,D]*
 /* VisualSR.forward(local_feature) -- fusion_model.py:141-154 */
 FERN_API int fern_visual_sr(fern_ctx* ctx, int which, const float* local /*[n,13,D]*/, float* out /*[n,D]*/,
                    int64_t n, void* stream);
+/* Select the encoder precision for the calls that follow on this context (forks inherit the value at fork time).
+ * No reference counterpart: the reference evaluates in fp32 only (run/test/test_fiq.py:141-149). */
+FERN_API int fern_set_precision(fern_ctx* ctx, int precision /* fern_precision */);
+FERN_API int fern_get_precision(fern_ctx* ctx);
 /* models/others/Combiner_Model.py:6-70 (CLIP4Cir `Combiner`, not called by the reference's own scripts): weights are loaded
  * under the prefix "clip4cir." with that class's key names; image / text / out are [n, 2*clip_feature_dim]. */
 FERN_API int fern_finalize_clip4cir(fern_ctx* ctx);
@@ -203,6 +219,13 @@ FERN_API int fern_topk_merge(fern_ctx* ctx, const float* scores /*[R,B,K]*/, con
 FERN_API int fern_gemm(fern_ctx* ctx, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
               const float* residual, float* C, int64_t ldc, int M, int N, int K, int epilogue,
               void* stream);
+/* bf16 operand form of fern_gemm ("perf mode" of the encoder GEMMs): A [M,lda] and W [N,ldw] hold bf16
+ * bit patterns (fern_gallery_to_bf16 converts any fp32 buffer, round to nearest even), products accumulate in fp32 on
+ * v_mfma_f32_32x32x16_bf16; C is fp32, or bf16 when out_bf16 != 0 (not with the residual epilogue).  K % 32 == 0,
+ * lda/ldw % 8 == 0. */
+FERN_API int fern_gemm_bf16(fern_ctx* ctx, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias,
+                   const float* residual, void* C, int64_t ldc, int M, int N, int K, int epilogue, int out_bf16,
+                   void* stream);
 /* y = LayerNorm(x (+ residual)) * gamma + beta, rows of width d */
 FERN_API int fern_layernorm(fern_ctx* ctx, const float* x, const float* residual, const float* gamma,
                    const float* beta, float* y, int64_t rows, int d, float eps, void* stream);

@@ -26,12 +26,37 @@ def _ln(sd, prefix, x):
     return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
 
 
-def _attention(sd, prefix, x, heads, causal):
-    """modeling_clip.py:272-336: q scaled by hd**-0.5 before QK^T, additive causal mask, softmax, PV."""
+def _r(x, bf16):
+    """Operand rounding of the product's "bf16" encoder precision (include/fern.h:fern_precision): round to nearest even
+    to bfloat16, carried on as fp32 so that products are exact and sums accumulate in fp32, like the MFMA."""
+    return x.bfloat16().float() if bf16 else x
+
+
+def _linear(x, w, b, bf16):
+    return F.linear(_r(x, bf16), _r(w, bf16), b)
+
+
+def _attention(sd, prefix, x, heads, causal, bf16=False, q_rows=None):
+    """modeling_clip.py:272-336: q scaled by hd**-0.5 before QK^T, additive causal mask, softmax, PV.
+
+    ``bf16``: the packed in-projection and the out-projection take bf16 operands.  ``q_rows`` (last ViT block of the
+    product: only the class row is consumed): queries, out-projection and everything after them are evaluated for those
+    rows only and in fp32; K/V still come from every token (bf16 operands when ``bf16``)."""
     b, s, w = x.shape
     hd = w // heads
-    qkv = F.linear(x, sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"])
-    q, k, v = qkv.split(w, dim=-1)
+    wi, bi = sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"]
+    if q_rows is None:
+        qkv = _linear(x, wi, bi, bf16)
+        q, k, v = qkv.split(w, dim=-1)
+    else:
+        k, v = _linear(x, wi[w:], bi[w:], bf16).split(w, dim=-1)
+        q = F.linear(x[:, q_rows], wi[:w], bi[:w])
+        s_q = q.shape[1]
+        q = q.view(b, s_q, heads, hd).transpose(1, 2) * (hd ** -0.5)
+        k = k.view(b, s, heads, hd).transpose(1, 2)
+        v = v.view(b, s, heads, hd).transpose(1, 2)
+        o = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(b, s_q, w)
+        return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
     q = q.view(b, s, heads, hd).transpose(1, 2) * (hd ** -0.5)
     k = k.view(b, s, heads, hd).transpose(1, 2)
     v = v.view(b, s, heads, hd).transpose(1, 2)
@@ -40,14 +65,23 @@ def _attention(sd, prefix, x, heads, causal):
         att = att + torch.full((s, s), float("-inf")).triu(1)
     att = torch.softmax(att, dim=-1)
     o = (att @ v).transpose(1, 2).reshape(b, s, w)
-    return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
+    return _linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"], bf16)
 
 
-def _block(sd, prefix, x, heads, causal):
+def _block(sd, prefix, x, heads, causal, bf16=False):
     """Pre-LN residual block, modeling_clip.py:354-401; MLP :339-351 with exact GELU."""
-    x = x + _attention(sd, prefix + ".attn", _ln(sd, prefix + ".ln_1", x), heads, causal)
-    h = F.gelu(F.linear(_ln(sd, prefix + ".ln_2", x), sd[prefix + ".mlp.c_fc.weight"], sd[prefix + ".mlp.c_fc.bias"]))
-    return x + F.linear(h, sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"])
+    x = x + _attention(sd, prefix + ".attn", _ln(sd, prefix + ".ln_1", x), heads, causal, bf16)
+    h = F.gelu(_linear(_ln(sd, prefix + ".ln_2", x), sd[prefix + ".mlp.c_fc.weight"], sd[prefix + ".mlp.c_fc.bias"], bf16))
+    return x + _linear(h, sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"], bf16)
+
+
+def _block_cls(sd, prefix, x, heads, bf16):
+    """The last ViT block as the product evaluates it under bf16 precision: same arithmetic as ``_block`` restricted to the
+    class row (the only row ln_post reads, modeling_clip.py:876-877) with fp32 operands, except the K/V projection of all
+    tokens, which takes bf16 operands."""
+    c = x[:, :1] + _attention(sd, prefix + ".attn", _ln(sd, prefix + ".ln_1", x), heads, False, bf16, q_rows=slice(0, 1))
+    h = F.gelu(F.linear(_ln(sd, prefix + ".ln_2", c), sd[prefix + ".mlp.c_fc.weight"], sd[prefix + ".mlp.c_fc.bias"]))
+    return c + F.linear(h, sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"])
 
 
 def _bn(sd, prefix, x):
@@ -93,9 +127,15 @@ def encode_image_resnet(sd, cfg, images):
     return F.linear(o, sd[a + "c_proj.weight"], sd[a + "c_proj.bias"])
 
 
-def encode_image(sd, cfg, images):
-    """[b,3,H,W] f32 -> [b,embed_dim] un-normalised (call site utils/utils.py:64)."""
+def encode_image(sd, cfg, images, precision="fp32"):
+    """[b,3,H,W] f32 -> [b,embed_dim] un-normalised (call site utils/utils.py:64).
+
+    ``precision="bf16"`` restates the product's perf mode (no reference counterpart; include/fern.h:fern_precision): the
+    same arithmetic with the operands of the token-level block GEMMs rounded to bfloat16."""
+    bf16 = precision == "bf16"
     if getattr(cfg, "v_arch", "vit") == "resnet":
+        if bf16:
+            raise ValueError("bf16 precision is defined for the transformer towers only")
         return encode_image_resnet(sd, cfg, images)
     w = sd["visual.conv1.weight"]
     x = F.conv2d(images, w, stride=cfg.patch_size)                      # modeling_clip.py:180-196
@@ -103,24 +143,26 @@ def encode_image(sd, cfg, images):
     cls = sd["visual.class_embedding"].expand(x.shape[0], 1, -1)
     x = torch.cat((cls, x), dim=1) + sd["visual.positional_embedding"]  # :197-200
     x = _ln(sd, "visual.ln_pre", x)                                     # :839,866
-    for i in range(cfg.v_layers):
-        x = _block(sd, f"visual.transformer.resblocks.{i}", x, cfg.v_heads, causal=False)
+    for i in range(cfg.v_layers - (1 if bf16 else 0)):
+        x = _block(sd, f"visual.transformer.resblocks.{i}", x, cfg.v_heads, causal=False, bf16=bf16)
+    if bf16:
+        x = _block_cls(sd, f"visual.transformer.resblocks.{cfg.v_layers - 1}", x, cfg.v_heads, bf16)
     pooled = _ln(sd, "visual.ln_post", x[:, 0])                         # :876-877
     return pooled @ sd["visual.proj"]                                   # :977,1076 (bias-free)
 
 
-def text_hidden(sd, cfg, text):
+def text_hidden(sd, cfg, text, precision="fp32"):
     x = sd["token_embedding.weight"][text] + sd["positional_embedding"][: text.shape[1]]   # :204-232
     for i in range(cfg.t_layers):
-        x = _block(sd, f"transformer.resblocks.{i}", x, cfg.t_heads, causal=True)
+        x = _block(sd, f"transformer.resblocks.{i}", x, cfg.t_heads, causal=True, bf16=precision == "bf16")
     return _ln(sd, "ln_final", x)                                       # :750
 
 
-def encode_text(sd, cfg, text, mode="global", visual_emb=None):
+def encode_text(sd, cfg, text, mode="global", visual_emb=None, precision="fp32"):
     """int64 [B,77] -> (global [B,D], seq [B,77,D]) or seq (call sites run/test/test_fiq.py:102-103)."""
     if visual_emb is not None and (visual_emb.dim() != 3 or visual_emb.shape[1] != text.shape[0]):
         raise ValueError("visual_emb must be [patch_num, B, D]")
-    seq = text_hidden(sd, cfg, text) @ sd["text_projection"]            # :978,1027 (bias-free)
+    seq = text_hidden(sd, cfg, text, precision) @ sd["text_projection"]            # :978,1027 (bias-free)
     if mode == "seq":
         return seq
     pooled = seq[torch.arange(text.shape[0]), text.argmax(dim=-1)]      # :755-758 (EOT = largest id)

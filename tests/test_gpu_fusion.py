@@ -200,3 +200,49 @@ def test_modified_resnet_tower_tiny_and_rn50x4():
         g, s = eng.encode_text(toks)
         assert _maxerr(s, rs) < 1e-3 * max(1.0, rs.abs().max().item())
         eng.close()
+
+
+@pytest.mark.parametrize("name,n", [("tiny", 5), ("tiny-hd64", 4), ("ViT-B-16", 3)])
+def test_clip_towers_bf16_precision(name, n):
+    """Perf mode (fern_set_precision(BF16)): bf16 operands on the token-level block GEMMs, fp32 accumulation.
+
+    Checked two ways: (1) against the oracle evaluated with the SAME rounding points (only fp32 summation order and
+    the occasional operand that lands on the other side of a bf16 rounding boundary differ); (2) against the fp32
+    oracle, to state what the mode costs in accuracy (bf16 has 8 mantissa bits: ~4e-3 relative per operand)."""
+    cfg = synth.CLIP_CONFIGS[name]
+    sd_np = synth.clip_state_dict(cfg, seed=11)
+    sd = ofusion.as_torch(sd_np)
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(sd_np)
+    eng.finalize_clip(cfg)
+    imgs = _t(synth.images(n, cfg))
+    toks = _t(synth.captions(n, cfg))
+    fp32_img = eng.encode_image(imgs)
+    eng.set_precision("bf16")
+    assert eng.precision == "bf16"
+    got = eng.encode_image(imgs)
+    g, s = eng.encode_text(toks)
+    # batch invariance survives the mode: a row does not depend on its batch
+    assert torch.equal(eng.encode_image(imgs[1:2]), got[1:2])
+    child = eng.fork()
+    assert child.precision == "bf16" and torch.equal(child.encode_image(imgs), got)
+    child.close()
+    eng.set_precision("fp32")
+    assert torch.equal(eng.encode_image(imgs), fp32_img)          # switching back restores the parity path bit for bit
+
+    ref_b = oclip.encode_image(sd, cfg, imgs, precision="bf16")
+    ref_f = oclip.encode_image(sd, cfg, imgs)
+    rg_b, rs_b = oclip.encode_text(sd, cfg, toks, precision="bf16")
+    rg_f, rs_f = oclip.encode_text(sd, cfg, toks)
+
+    def cos_err(a, b):
+        return (1 - F.cosine_similarity(a.cpu().double().flatten(-1 if a.dim() == 2 else 1), b.double().flatten(-1 if b.dim() == 2 else 1), dim=-1)).abs().max().item()
+
+    # (1) same rounding points: tight
+    assert cos_err(got, ref_b) < 2e-5 and cos_err(g, rg_b) < 2e-5
+    assert _maxerr(got, ref_b) < 5e-3 * max(1.0, ref_b.abs().max().item())
+    assert _maxerr(s, rs_b) < 5e-3 * max(1.0, rs_b.abs().max().item())
+    # (2) cost of the mode against the fp32 statement: features stay within 1e-3 in cosine
+    assert cos_err(got, ref_f) < 1e-3 and cos_err(g, rg_f) < 1e-3
+    assert cos_err(got, ref_f) > 0 and not torch.equal(got, fp32_img)   # the mode really is a different precision
+    eng.close()

@@ -222,3 +222,35 @@ def test_gemm_variants_are_bit_identical(engine):
     full = engine.gemm(a, w, b, epilogue=1).cpu()
     for lo, hi in ((0, 1), (0, 64), (100, 1124), (2990, 3000)):
         assert torch.equal(engine.gemm(a[lo:hi], w, b, epilogue=1).cpu(), full[lo:hi])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(64, 128, 64), (197, 384, 96), (1000, 520, 256), (4096, 768, 768)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("out_bf16", [False, True])
+def test_gemm_bf16(engine, m, n, k, epi, out_bf16):
+    """bf16-operand GEMM against fp64 math on the SAME rounded operands: only the fp32 accumulation order differs."""
+    if epi == 3 and out_bf16:
+        pytest.skip("the residual epilogue keeps the fp32 residual stream")
+    g = torch.Generator().manual_seed(m * 7 + n + k + epi)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * k ** -0.5
+    b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g)
+    ab, wb = a.bfloat16(), w.bfloat16()
+    ref = ab.double() @ wb.double().T + b.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 2:
+        ref = torch.relu(ref)
+    elif epi == 3:
+        ref = ref + r.double()
+    got = engine.gemm_bf16(ab.cuda(), wb.cuda(), b, residual=r if epi == 3 else None, epilogue=epi, out_bf16=out_bf16)
+    assert got.dtype == (torch.bfloat16 if out_bf16 else torch.float32)
+    # the engine's own fp32 -> bf16 conversion is RNE, i.e. torch's
+    assert torch.equal(engine.to_bf16(a).cpu().view(torch.int16), ab.view(torch.int16))
+    if out_bf16:
+        # one bf16 rounding of a value the fp32 accumulation may have moved across a rounding boundary: <= 1 bf16 ulp
+        assert torch.allclose(got.float().cpu().double(), ref, rtol=2 ** -7, atol=1e-3)
+    else:
+        assert torch.allclose(got.cpu().double(), ref, rtol=1e-5, atol=2e-5)

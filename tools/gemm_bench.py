@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--shapes", default="all")
+    ap.add_argument("--bf16", action="store_true", help="bf16-operand kernel (FERN_GEMM_BF16_CFG picks the tile)")
     args = ap.parse_args()
     eng = FernEngine("cuda:0")
     groups = SHAPES if args.shapes == "all" else {args.shapes: SHAPES[args.shapes]}
@@ -34,13 +35,19 @@ def main():
             w = torch.randn(n, k, device="cuda") * k ** -0.5
             b = torch.randn(n, device="cuda")
             r = torch.randn(m, n, device="cuda") if epi == 3 else None
+            if args.bf16:
+                ab, wb = eng.to_bf16(a), eng.to_bf16(w)
+                out_b = epi in (0, 1)
+                run = lambda: eng.gemm_bf16(ab, wb, b, residual=r, epilogue=epi, out_bf16=out_b)  # noqa: E731
+            else:
+                run = lambda: eng.gemm(a, w, b, residual=r, epilogue=epi)  # noqa: E731
             for _ in range(3):
-                eng.gemm(a, w, b, residual=r, epilogue=epi)
+                run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.iters):
-                eng.gemm(a, w, b, residual=r, epilogue=epi)
+                run()
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.iters
