@@ -21,7 +21,8 @@ class ProfStats(C.Structure):
     _fields_ = [("gemm_ms", C.c_double), ("gemm_flops", C.c_double), ("gemm_launches", c_i64),
                 ("attn_ms", C.c_double), ("attn_flops", C.c_double), ("attn_launches", c_i64),
                 ("topk_ms", C.c_double), ("topk_launches", c_i64),
-                ("sweep_ms", C.c_double), ("sweep_bytes", C.c_double), ("sweep_launches", c_i64)]
+                ("sweep_ms", C.c_double), ("sweep_bytes", C.c_double), ("sweep_launches", c_i64),
+                ("gemm_bf16_ms", C.c_double), ("gemm_bf16_flops", C.c_double), ("gemm_bf16_launches", c_i64)]
 
 
 # name -> (restype, argtypes); must list every symbol include/fern.h declares (tests check this)

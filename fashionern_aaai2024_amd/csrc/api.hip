@@ -1296,7 +1296,10 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
         HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
         if (dump) std::fprintf(dump, "%d,%d,%d,%d,%d,%.6f,%.0f\n", r.kind, r.m, r.n, r.k, r.tag, ms, r.work);
         switch (r.kind) {
-            case PROF_GEMM: out->gemm_ms += ms; out->gemm_flops += r.work; out->gemm_launches++; break;
+            case PROF_GEMM:
+                if (r.tag >= 100) { out->gemm_bf16_ms += ms; out->gemm_bf16_flops += r.work; out->gemm_bf16_launches++; }
+                else { out->gemm_ms += ms; out->gemm_flops += r.work; out->gemm_launches++; }
+                break;
             case PROF_ATTN: out->attn_ms += ms; out->attn_flops += r.work; out->attn_launches++; break;
             case PROF_TOPK: out->topk_ms += ms; out->topk_launches++; break;
             default: out->sweep_ms += ms; out->sweep_bytes += r.work; out->sweep_launches++; break;

@@ -21,7 +21,7 @@ namespace fern {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WM, int WN, int BKE, int MINW>
+template <int BM, int BN, int WM, int WN, int BKE, int STAGES, int MINW>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_glds_kernel(GemmParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
@@ -39,8 +39,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
     constexpr int TILE = ROWS * RB;                      // bytes per stage
 
     // one __shared__ object (see gemm.hip: a second one makes hipcc drain the DMA before every first fragment read)
-    __shared__ __attribute__((aligned(1024))) char smem[2 * TILE + WAVES_N * BM * 4];
-    float (*red)[BM] = reinterpret_cast<float (*)[BM]>(smem + 2 * TILE);
+    __shared__ __attribute__((aligned(1024))) char smem[STAGES * TILE + WAVES_N * BM * 4];
+    float (*red)[BM] = reinterpret_cast<float (*)[BM]>(smem + STAGES * TILE);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -109,43 +109,78 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
         }
     };
 
+    // STAGES-deep ring: tiles kt+1 .. kt+STAGES-2 stay in flight while tile kt is consumed (a bf16 tile is only ~256 MFMA
+    // cycles of work per wave, far less than one L2/HBM round trip, so a single tile in flight leaves the loop latency-bound).
+    // Top of iteration kt: wait until this wave's pieces of tile kt have landed (counted vmcnt: younger tiles may still be
+    // in flight), barrier (=> every wave's pieces landed, and every wave is done reading tile kt-1), then refill the slot
+    // of tile kt-1 with tile kt+STAGES-1.
     const int nk = p.K / BKE;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) stage(t, t * BKE);
+    int slot = 0;                                   // ring slot of tile kt
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BKE);
-        compute(kt & 1);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (kt + STAGES - 2 < nk) {                 // steady state: STAGES-2 younger tiles issued after tile kt
+            if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < nk) {
+            int fill = slot + STAGES - 1;
+            fill = fill >= STAGES ? fill - STAGES : fill;
+            stage(fill, (kt + STAGES - 1) * BKE);
+        }
+        compute(slot);
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
-    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, red, bm, bn, nbn, wm, wn, l31, lh, tid);
+    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N, true>(p, acc, red, bm, bn, nbn, wm, wn, l31, lh, tid);
 }
 
 struct TileCfgB { int bm, bn, bk; };
 static const TileCfgB kCfgsB[] = {
-    {128, 128, 32},   // 0: 4 waves of 64x64, 64-byte rows
-    {128, 128, 64},   // 1: 128-byte rows
-    {256, 128, 32},   // 2: 8 waves of 64x64
-    {256, 128, 64},   // 3
-    {64, 128, 32},    // 4
-    {64, 128, 64},    // 5
-    {256, 256, 32},   // 6: 16 waves of 64x64
-    {256, 256, 64},   // 7
+    {128, 128, 32},   // 0: 4 waves of 64x64, 64-byte rows, 2 stages
+    {128, 128, 32},   // 1: 3 stages
+    {128, 128, 32},   // 2: 4 stages
+    {128, 128, 64},   // 3: 128-byte rows, 2 stages
+    {128, 128, 64},   // 4: 3 stages
+    {256, 128, 32},   // 5: 8 waves of 64x64, 3 stages
+    {256, 128, 32},   // 6: 4 stages
+    {256, 128, 64},   // 7: 3 stages
+    {64, 128, 32},    // 8: 4 stages
+    {256, 256, 32},   // 9: 16 waves, 3 stages
+    {64, 128, 32},    // 10: 2 stages
+    {128, 64, 32},    // 11: 2 stages
+    {64, 64, 32},     // 12: 4 waves of 32x32, 2 stages
+    {256, 128, 32},   // 13: 4 waves of 128x64 (fewer LDS fragment reads per MFMA), 3 stages
+    {256, 128, 32},   // 14: as 13, 2 stages
+    {128, 128, 32},   // 15: 2 waves of 128x64, 2 stages
+    {256, 256, 32},   // 16: 4 waves of 128x128, 2 stages
 };
-constexpr int kNumCfgsB = 8;
+constexpr int kNumCfgsB = 17;
 
 static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsB[c].bm - 1) / kCfgsB[c].bm) * ((p.N + kCfgsB[c].bn - 1) / kCfgsB[c].bn);
     switch (c) {
-        case 0: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2>), dim3(nb), dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 2>), dim3(nb), dim3(512), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 64, 2>), dim3(nb), dim3(512), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 32, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 5: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 64, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 6: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 64, 64, 32, 1>), dim3(nb), dim3(1024), 0, s, p); break;
-        case 7: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 64, 64, 64, 1>), dim3(nb), dim3(1024), 0, s, p); break;
+        case 0: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 3, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 4, 2>), dim3(nb), dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 3, 1>), dim3(nb), dim3(256), 0, s, p); break;
+        case 5: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 3, 2>), dim3(nb), dim3(512), 0, s, p); break;
+        case 6: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 4, 2>), dim3(nb), dim3(512), 0, s, p); break;
+        case 7: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 64, 3, 2>), dim3(nb), dim3(512), 0, s, p); break;
+        case 8: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 32, 4, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 9: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 64, 64, 32, 3, 1>), dim3(nb), dim3(1024), 0, s, p); break;
+        case 10: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 11: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 64, 64, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 12: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 64, 32, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 13: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 128, 64, 32, 3, 2>), dim3(nb), dim3(256), 0, s, p); break;
+        case 14: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 128, 64, 32, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
+        case 15: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 128, 64, 32, 2, 2>), dim3(nb), dim3(128), 0, s, p); break;
+        case 16: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 128, 128, 32, 2, 1>), dim3(nb), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -159,12 +194,80 @@ static int forced_cfg_b() {
     return v;
 }
 
+// Per-shape tile selection, as in gemm.hip: every configuration produces bit-identical results, so the choice is purely a
+// speed choice; each new (M, N, K, epilogue) is timed once on scratch outputs (outside stream capture).
+struct ShapeKeyB {
+    int M, N, K, epi, ob;
+    bool operator<(const ShapeKeyB& o) const {
+        if (M != o.M) return M < o.M;
+        if (N != o.N) return N < o.N;
+        if (K != o.K) return K < o.K;
+        if (epi != o.epi) return epi < o.epi;
+        return ob < o.ob;
+    }
+};
+static std::map<ShapeKeyB, int> g_tuned_b;
+static std::mutex g_tuned_b_mu;
+
+static int heuristic_b(int M, int N) {
+    static const int order[] = {9, 5, 0, 10, 12};       // largest tile that still gives every CU >= 2 workgroups' worth of work
+    for (int c : order) {
+        const long nb = (long)((M + kCfgsB[c].bm - 1) / kCfgsB[c].bm) * ((N + kCfgsB[c].bn - 1) / kCfgsB[c].bn);
+        const long per_cu = (long)kCfgsB[c].bm * kCfgsB[c].bn / (128 * 128);   // 128x128-equivalents per workgroup
+        if (nb * per_cu >= 1024) return c;
+    }
+    return 12;
+}
+
+static int tune_shape_b(const GemmParams& p, hipStream_t s) {
+    const int fallback = heuristic_b(p.M, p.N);
+    const char* e = getenv("FERN_GEMM_TUNE");
+    if (e && e[0] == '0') return fallback;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return fallback;
+    float* scratch = nullptr;
+    if (hipMalloc(&scratch, (size_t)p.M * p.ldc * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fallback; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    GemmParams q = p;
+    q.C = scratch;            // the residual input is only read: tuning has no side effects on the caller's buffers
+    int best = fallback;
+    float best_ms = 1e30f;
+    static const int cands[] = {0, 5, 9, 10, 11, 12};
+    for (int c : cands) {
+        if (launch_cfg_b(c, q, s) != hipSuccess) continue;                 // warm
+        (void)hipEventRecord(e0, s);
+        (void)launch_cfg_b(c, q, s);
+        (void)launch_cfg_b(c, q, s);
+        (void)hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(scratch);
+    return best;
+}
+
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (p.K <= 0 || (p.K % 32) != 0 || (p.lda & 7) || (p.ldw & 7) || p.aload != ALOAD_PLAIN || epi_is_reduce(p.epi)) return hipErrorInvalidValue;
     if (!p.Ab || !p.Wb || ((uintptr_t)p.Ab & 15) || ((uintptr_t)p.Wb & 15)) return hipErrorInvalidValue;
     int c = forced_cfg_b();
-    if (c < 0 || c >= kNumCfgsB || p.K % kCfgsB[c].bk) c = (p.K % 64 == 0) ? 1 : 0;
+    if (c < 0 || c >= kNumCfgsB || p.K % kCfgsB[c].bk) {
+        if (2.0 * p.M * (double)p.N * p.K >= 2.5e8) {
+            const ShapeKeyB key{p.M, p.N, p.K, p.epi, p.out_bf16};
+            std::lock_guard<std::mutex> lock(g_tuned_b_mu);
+            auto it = g_tuned_b.find(key);
+            if (it == g_tuned_b.end()) it = g_tuned_b.emplace(key, tune_shape_b(p, s)).first;
+            c = it->second;
+        } else {
+            c = heuristic_b(p.M, p.N);
+        }
+    }
     return launch_cfg_b(c, p, s);
 }
 

@@ -25,45 +25,97 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * cdf2;
 }
 
-// Shared epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-template <int BM, int BN, int WM, int WN, int TM, int TN, int WAVES_N>
+// Plain (element-wise) epilogue of one epilogue kind: the kind is a template parameter so that the switch is taken once per
+// kernel, not once per element, and the tile loops stay small enough to unroll fully (register-indexed accumulators).
+// C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+template <int EPI, bool OUT_BF16, int TM, int TN>
+__device__ __forceinline__ void plain_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int row_w, int col_w, int l31, int lh) {
+    constexpr bool resid = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_RELU;
+    // An element's address = (wave-uniform tile / register-row part, kept in SGPRs) + (lane part: 4 * half rows + column):
+    // one 32-bit VGPR offset serves all 16 loads and stores of a tile (ldc < 2^24 on this path, so the lane part fits an int).
+    const int lrow = 4 * lh;
+    const int loff = lrow * (int)p.ldc + l31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row0 = row_w + i * 32, col0 = col_w + j * 32;       // wave-uniform
+            const int col = col0 + l31;
+            if (col < p.N) {
+                const float bia = p.bias ? p.bias[col] : 0.0f;
+                float sc = 1.0f, sh = 0.0f;
+                if (EPI == EPI_COLAFFINE_TANH) { sc = p.aux0[col]; sh = p.aux1[col]; }
+                if (EPI == EPI_PATCH_EMBED) {
+                    const int g2 = p.grid * p.grid;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + (r & 3) + 8 * (r >> 2) + lrow;
+                        if (row < p.M) {
+                            const long orow = row + row / g2 + 1;
+                            p.C[orow * p.ldc + col] = acc[i][j][r] + bia + p.aux0[(long)((row % g2) + 1) * p.N + col];
+                        }
+                    }
+                } else {
+                    // The residual stream is updated in place (R == C): the compiler has to keep every load behind the
+                    // preceding store, so the 16 residual values of a tile are fetched together BEFORE its first store
+                    // (one memory round trip per tile instead of 16).
+                    const float* Rt = resid ? p.R + (long)row0 * p.ldc + col0 : nullptr;
+                    float add[16];
+                    if (resid) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ru = (r & 3) + 8 * (r >> 2);
+                            add[r] = row0 + ru + lrow < p.M ? Rt[(long)ru * p.ldc + loff] : 0.0f;
+                        }
+                    }
+                    float* Ct = OUT_BF16 ? nullptr : p.C + (long)row0 * p.ldc + col0;
+                    unsigned short* Cb = OUT_BF16 ? reinterpret_cast<unsigned short*>(p.C) + (long)row0 * p.ldc + col0 : nullptr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ru = (r & 3) + 8 * (r >> 2);
+                        if (row0 + ru + lrow < p.M) {
+                            float v = acc[i][j][r] + bia;
+                            if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                            else if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.0f);
+                            else if (EPI == EPI_BIAS_RESIDUAL) v += add[r];
+                            else if (EPI == EPI_BIAS_RESIDUAL_RELU) v = fmaxf(v + add[r], 0.0f);
+                            else if (EPI == EPI_COLAFFINE_TANH) v = tanhf(v * sc + sh);
+                            if (OUT_BF16) Cb[(long)ru * p.ldc + loff] = f32_to_bf16_bits(v);
+                            else Ct[(long)ru * p.ldc + loff] = v;
+                        }
+                    }
+                }
+            }
+            // one 32x32 tile at a time: without this fence the scheduler hoists the address arithmetic and the loads of all
+            // TM x TN tiles to the top and the kernel's register budget (= its occupancy) is set by the epilogue
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// Shared epilogue of the fp32 and bf16 GEMM kernels (ALLOW_BF16_OUT: only the bf16 kernel stores bf16 outputs).
+template <int BM, int BN, int WM, int WN, int TM, int TN, int WAVES_N, bool ALLOW_BF16_OUT = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], float (*red)[BM], int bm, int bn, int nbn,
                                               int wm, int wn, int l31, int lh, int tid) {
     const int row_w = bm * BM + wm * WM;
     const int col_w = bn * BN + wn * WN;
     if (!epi_is_reduce(p.epi)) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = col_w + j * 32 + l31;
-                if (col >= p.N) continue;
-                const float bia = p.bias ? p.bias[col] : 0.0f;
-                float sc = 1.0f, sh = 0.0f;
-                if (p.epi == EPI_COLAFFINE_TANH) { sc = p.aux0[col]; sh = p.aux1[col]; }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row >= p.M) continue;
-                    float v = acc[i][j][r] + bia;
-                    long orow = row;
-                    switch (p.epi) {
-                        case EPI_BIAS_GELU: v = gelu_erf(v); break;
-                        case EPI_BIAS_RELU: v = fmaxf(v, 0.0f); break;
-                        case EPI_BIAS_RESIDUAL: v += p.R[(long)row * p.ldc + col]; break;
-                        case EPI_BIAS_RESIDUAL_RELU: v = fmaxf(v + p.R[(long)row * p.ldc + col], 0.0f); break;
-                        case EPI_COLAFFINE_TANH: v = tanhf(v * sc + sh); break;
-                        case EPI_PATCH_EMBED: {
-                            const int g2 = p.grid * p.grid;
-                            orow = row + row / g2 + 1;
-                            v += p.aux0[(long)((row % g2) + 1) * p.N + col];
-                        } break;
-                        default: break;
-                    }
-                    if (p.out_bf16) reinterpret_cast<unsigned short*>(p.C)[orow * p.ldc + col] = f32_to_bf16_bits(v);
-                    else p.C[orow * p.ldc + col] = v;
-                }
+        if (ALLOW_BF16_OUT && p.out_bf16) {
+            switch (p.epi) {      // bf16 outputs feed the next bf16 GEMM: bias (+ GELU / ReLU) only
+                case EPI_BIAS_GELU: plain_epilogue<EPI_BIAS_GELU, true>(p, acc, row_w, col_w, l31, lh); break;
+                case EPI_BIAS_RELU: plain_epilogue<EPI_BIAS_RELU, true>(p, acc, row_w, col_w, l31, lh); break;
+                default: plain_epilogue<EPI_BIAS, true>(p, acc, row_w, col_w, l31, lh); break;
             }
+            return;
+        }
+        switch (p.epi) {
+            case EPI_BIAS_GELU: plain_epilogue<EPI_BIAS_GELU, false>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_BIAS_RELU: plain_epilogue<EPI_BIAS_RELU, false>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_BIAS_RESIDUAL: plain_epilogue<EPI_BIAS_RESIDUAL, false>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_BIAS_RESIDUAL_RELU: plain_epilogue<EPI_BIAS_RESIDUAL_RELU, false>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_COLAFFINE_TANH: plain_epilogue<EPI_COLAFFINE_TANH, false>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_PATCH_EMBED: plain_epilogue<EPI_PATCH_EMBED, false>(p, acc, row_w, col_w, l31, lh); break;
+            default: plain_epilogue<EPI_BIAS, false>(p, acc, row_w, col_w, l31, lh); break;
+        }
     } else {
         // reduce epilogues: one partial sum per (row, column block); fixed summation order => deterministic
 #pragma unroll

@@ -55,6 +55,12 @@ class ComposedQueryPipeline:
             ev.record(stream)
         return QueryResult(scores, idx, fused, ev)
 
+    def set_precision(self, precision) -> None:
+        """Encoder operand precision of every lane ("fp32" parity mode / "bf16" perf mode, FernEngine.set_precision)."""
+        self.synchronize()
+        for e in self.engines:
+            e.set_precision(precision)
+
     def synchronize(self) -> None:
         for s in self.streams:
             s.synchronize()

@@ -112,6 +112,9 @@ typedef struct {
     double sweep_ms;       /* similarity sweep (scores GEMM inside fern_sim_topk) */
     double sweep_bytes;    /* algorithmic bytes of those sweeps: N*D*4 + B*D*4 + B*N*4 */
     int64_t sweep_launches;
+    double gemm_bf16_ms;   /* bf16-operand GEMM launches (FERN_PREC_BF16 encoder blocks, fern_gemm_bf16): NOT included in gemm_* */
+    double gemm_bf16_flops;
+    int64_t gemm_bf16_launches;
 } fern_prof_stats;
 
 FERN_API int fern_abi_version(void);
