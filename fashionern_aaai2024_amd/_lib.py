@@ -65,6 +65,8 @@ SIGNATURES = {
     "fern_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_void_p]),
     "fern_attention": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "fern_attention_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "fern_prof_enable": (c_int, [c_void_p, c_int]),
     "fern_prof_collect": (c_int, [c_void_p, C.POINTER(ProfStats)]),
 }

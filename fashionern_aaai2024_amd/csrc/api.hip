@@ -862,14 +862,14 @@ static int clip_block(fern_ctx* c, const ClipBlockW& Bk, float* X, float* XN, fl
 // Perf-mode block: the four token-level GEMMs take bf16 operands (LayerNorm / attention / GELU outputs are rounded to bf16
 // as they are written, weights are the bf16 copies) and accumulate in fp32; the residual stream X, the LayerNorm
 // statistics and the attention softmax stay fp32.
-static int clip_block_bf16(fern_ctx* c, const ClipBlockW& Bk, float* X, unsigned short* XNb, float* QKV, unsigned short* ATTb,
+static int clip_block_bf16(fern_ctx* c, const ClipBlockW& Bk, float* X, unsigned short* XNb, unsigned short* QKVb, unsigned short* ATTb,
                            unsigned short* Hb, int batch, int S, int width, int heads, int causal, hipStream_t s) {
     const long R = (long)batch * S;
     const int hd = width / heads;
     HIP_TRY(launch_layernorm_bf16(X, Bk.ln1.g, Bk.ln1.b, XNb, R, width, width, width, 1e-5f, s));
-    FERN_TRY(run_gemm_b(c, gemm_desc_b(XNb, width, Bk.qkv, QKV, 3 * width, (int)R, EPI_BIAS, false), s));
-    AttnParams a{QKV, QKV + width, QKV + 2 * width, nullptr, 3L * width, 3L * width, 3L * width, (long)width,
-                 batch, heads, hd, S, S, causal, 1.0f / std::sqrt((float)hd), ATTb};
+    FERN_TRY(run_gemm_b(c, gemm_desc_b(XNb, width, Bk.qkv, QKVb, 3 * width, (int)R, EPI_BIAS, true), s));
+    AttnParams a{nullptr, nullptr, nullptr, nullptr, 3L * width, 3L * width, 3L * width, (long)width,
+                 batch, heads, hd, S, S, causal, 1.0f / std::sqrt((float)hd), ATTb, QKVb, QKVb + width, QKVb + 2 * width};
     FERN_TRY(run_attention(c, a, s));
     GemmParams po = gemm_desc_b(ATTb, width, Bk.out, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
     po.R = X;
@@ -942,7 +942,8 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
     HIP_TRY(launch_layernorm(X, nullptr, W.ln_pre.g, W.ln_pre.b, X, R, vw, vw, vw, 1e-5f, s));
     for (int l = 0; l + 1 < cf.v_layers; ++l) {
         if (c->precision == FERN_PREC_BF16)     // XN / ATT / H double as the bf16 operand buffers (half filled)
-            FERN_TRY(clip_block_bf16(c, W.vblocks[l], X, reinterpret_cast<unsigned short*>(XN), QKV, reinterpret_cast<unsigned short*>(ATT),
+            FERN_TRY(clip_block_bf16(c, W.vblocks[l], X, reinterpret_cast<unsigned short*>(XN), reinterpret_cast<unsigned short*>(QKV),
+                                     reinterpret_cast<unsigned short*>(ATT),
                                      reinterpret_cast<unsigned short*>(H), b, S, vw, cf.v_heads, 0, s));
         else
             FERN_TRY(clip_block(c, W.vblocks[l], X, XN, QKV, ATT, H, b, S, vw, cf.v_heads, 0, s));
@@ -1068,7 +1069,8 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
     HIP_TRY(launch_text_embed(tokens, W.tok_emb, W.tpos, X, eot, B, T, tw, cf.vocab_size, s));
     for (int l = 0; l < cf.t_layers; ++l) {
         if (c->precision == FERN_PREC_BF16)
-            FERN_TRY(clip_block_bf16(c, W.tblocks[l], X, reinterpret_cast<unsigned short*>(XN), QKV, reinterpret_cast<unsigned short*>(ATT),
+            FERN_TRY(clip_block_bf16(c, W.tblocks[l], X, reinterpret_cast<unsigned short*>(XN), reinterpret_cast<unsigned short*>(QKV),
+                                     reinterpret_cast<unsigned short*>(ATT),
                                      reinterpret_cast<unsigned short*>(H), B, T, tw, cf.t_heads, 1, s));
         else
             FERN_TRY(clip_block(c, W.tblocks[l], X, XN, QKV, ATT, H, B, T, tw, cf.t_heads, 1, s));
@@ -1278,6 +1280,16 @@ extern "C" int fern_attention(fern_ctx* c, const float* q, int64_t ldq, const fl
 // ------------------------------------------------------------------------------------------------
 // profiling
 // ------------------------------------------------------------------------------------------------
+extern "C" int fern_attention_bf16(fern_ctx* c, const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
+                                   uint16_t* out, int64_t ldo, int batch, int heads, int head_dim, int s_q, int s_k, int causal, float scale,
+                                   void* stream) {
+    if (!c || !q || !k || !v || !out) return fail(FERN_ERR_ARG, "fern_attention_bf16: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    AttnParams a{nullptr, nullptr, nullptr, nullptr, (long)ldq, (long)ldk, (long)ldv, (long)ldo, batch, heads, head_dim, s_q, s_k, causal, scale,
+                 out, q, k, v};
+    return run_attention(c, a, (hipStream_t)stream);
+}
+
 extern "C" int fern_prof_enable(fern_ctx* c, int on) {
     if (!c) return fail(FERN_ERR_ARG, "fern_prof_enable: ctx is NULL");
     c->prof_on = on != 0;

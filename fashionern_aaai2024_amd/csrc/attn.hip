@@ -156,6 +156,165 @@ __global__ __launch_bounds__(NW * 64) void attn_f32_kernel(AttnParams p) {
     }
 }
 
+// ---- bf16 operand form ---------------------------------------------------------------------------------------------
+// Same structure on v_mfma_f32_32x32x16_bf16 (perf mode of the CLIP towers): S^T = K Q^T with K as the A operand, so the
+// accumulator has the query on the lane and 16 keys in registers; registers 8s..8s+7, rounded to bf16, ARE the B operand
+// of k-step s of O^T = V^T P^T -- with the k order permuted: element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3).
+// The matching V^T fragment (d on the lane, those 8 keys in the elements) comes from two ds_read_b64_tr_b16 transposing
+// reads of the row-major V image.  K image: rows padded to HDP*2+16 bytes (conflict-free ds_read_b128); V image:
+// [HDP/32][key][32 columns] with 64-byte rows (the 4 x 64-byte block one half-wave transposes covers all 64 banks once).
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int HDP, int NT, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(AttnParams p) {
+    constexpr int KSB = HDP * 2 + 16;    // K row stride in LDS (bytes)
+    constexpr int ROWS = NT * 32;        // padded key count
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    char* Ks = smem_b;                   // [ROWS][KSB]
+    char* Vs = smem_b + ROWS * KSB;      // [HDP/32][ROWS][64 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+    const int hd = p.hd;
+
+    {
+        constexpr int C8 = HDP / 8;      // 16-byte chunks per row
+        const unsigned short* kb = p.kb + (long)b * p.s_k * p.ldk + (long)h * hd;
+        const unsigned short* vb = p.vb + (long)b * p.s_k * p.ldv + (long)h * hd;
+        for (int i = tid; i < ROWS * C8; i += NW * 64) {
+            const int row = i / C8, c = i % C8;
+            bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (row < p.s_k && c * 8 < hd) {
+                kv = *reinterpret_cast<const bf16x8*>(kb + (long)row * p.ldk + c * 8);
+                vv = *reinterpret_cast<const bf16x8*>(vb + (long)row * p.ldv + c * 8);
+            }
+            *reinterpret_cast<bf16x8*>(Ks + row * KSB + c * 16) = kv;
+            *reinterpret_cast<bf16x8*>(Vs + ((c >> 2) * ROWS + row) * 64 + (c & 3) * 16) = vv;
+        }
+    }
+    __syncthreads();
+
+    // transposing-read lane address inside a [4 keys][32 columns] block: lane 4q+p of a 16-lane group -> row q, columns 4p..4p+3
+    const int tr_off = ((lane & 15) >> 2) * 64 + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2 + lh * 4 * 64;
+
+    const int nqt = (p.s_q + 31) / 32;
+    for (int qt = wave; qt < nqt; qt += NW) {
+        const int qi = qt * 32 + l31;
+        const int qrow = qi < p.s_q ? qi : p.s_q - 1;
+        bf16x8 qf[HDP / 16];
+        {
+            const unsigned short* qb = p.qb + ((long)b * p.s_q + qrow) * p.ldq + (long)h * hd;
+#pragma unroll
+            for (int kk = 0; kk < HDP / 16; ++kk) {
+                const int d = kk * 16 + 8 * lh;
+                bf16x8 t = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (d < hd) t = *reinterpret_cast<const bf16x8*>(qb + d);
+                qf[kk] = t;
+            }
+        }
+        f32x16 o[HDP / 32];
+#pragma unroll
+        for (int db = 0; db < HDP / 32; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
+        float m = -INFINITY, sum = 0.0f;
+        const int nt = CAUSAL ? (qt + 1 < NT ? qt + 1 : NT) : NT;
+#pragma unroll 1
+        for (int t = 0; t < nt; ++t) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < HDP / 16; ++kk) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t * 32 + l31) * KSB + (kk * 16 + 8 * lh) * 2);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st, 0, 0, 0);
+            }
+            float mt = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const bool ok = key < p.s_k && (!CAUSAL || key <= qi);
+                st[r] = ok ? st[r] * p.scale : -INFINITY;
+                mt = fmaxf(mt, st[r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m, mt);
+            const float alpha = __expf(m - m_new);
+            float ps = 0.0f;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(st[r] - m_new);
+                ps += e;                                   // the normaliser sums the un-rounded weights
+                pf[r >> 3][r & 7] = (short)f32_to_bf16_bits(e);
+            }
+            sum = sum * alpha + ps;
+            m = m_new;
+#pragma unroll
+            for (int db = 0; db < HDP / 32; ++db) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const char* vblk = Vs + (db * ROWS + t * 32 + 16 * s) * 64 + tr_off;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk + 8 * 64));
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o[db], 0, 0, 0);
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        if (qi < p.s_q) {
+            unsigned short* ob = p.out_b + ((long)b * p.s_q + qi) * p.ldo + (long)h * hd;
+#pragma unroll
+            for (int db = 0; db < HDP / 32; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = db * 32 + 8 * g + 4 * lh;
+                    if (d < hd) {
+                        ushort4 tt;
+                        tt.x = f32_to_bf16_bits(o[db][4 * g] * inv); tt.y = f32_to_bf16_bits(o[db][4 * g + 1] * inv);
+                        tt.z = f32_to_bf16_bits(o[db][4 * g + 2] * inv); tt.w = f32_to_bf16_bits(o[db][4 * g + 3] * inv);
+                        *reinterpret_cast<ushort4*>(ob + d) = tt;
+                    }
+                }
+        }
+    }
+}
+
+template <int HDP, int NT, bool CAUSAL>
+static hipError_t launch_inst_b(const AttnParams& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)NT * 32 * (HDP * 2 + 16 + HDP * 2);
+    static bool attr_set = false;
+    constexpr int NW = NT >= 7 ? 8 : 4;
+    auto kern = attn_bf16_kernel<HDP, NT, CAUSAL, NW>;
+    if (!attr_set && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.batch * p.heads), dim3(NW * 64), lds, s, p);
+    return hipGetLastError();
+}
+
+template <int HDP>
+static hipError_t launch_hd_b(const AttnParams& p, hipStream_t s) {
+    const int nt = (p.s_k + 31) / 32;
+    if (p.causal) {
+        if (nt <= 1) return launch_inst_b<HDP, 1, true>(p, s);
+        if (nt <= 3) return launch_inst_b<HDP, 3, true>(p, s);
+        return hipErrorInvalidValue;
+    }
+    if (nt <= 1) return launch_inst_b<HDP, 1, false>(p, s);
+    if (nt <= 3) return launch_inst_b<HDP, 3, false>(p, s);
+    if (nt <= 7) return launch_inst_b<HDP, 7, false>(p, s);
+    return hipErrorInvalidValue;
+}
+
 template <int HDP, int NT, bool CAUSAL>
 static hipError_t launch_inst(const AttnParams& p, hipStream_t s) {
     constexpr size_t lds = (size_t)NT * 32 * (HDP + 4 + HDP) * sizeof(float);
@@ -188,6 +347,14 @@ static hipError_t launch_hd(const AttnParams& p, hipStream_t s) {
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.batch <= 0 || p.heads <= 0 || p.s_q <= 0 || p.s_k <= 0) return hipErrorInvalidValue;
+    if (p.qb || p.kb || p.vb) {
+        if (!p.qb || !p.kb || !p.vb || !p.out_b || (p.hd & 7) || (p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3)) return hipErrorInvalidValue;
+        if (p.causal && p.s_q != p.s_k) return hipErrorInvalidValue;
+        if (p.hd <= 32) return launch_hd_b<32>(p, s);
+        if (p.hd <= 64) return launch_hd_b<64>(p, s);
+        if (p.hd <= 96) return launch_hd_b<96>(p, s);
+        return hipErrorInvalidValue;
+    }
     if ((p.hd & 3) || (p.ldq & 3) || (p.ldk & 3) || (p.ldv & 3) || (p.ldo & 3)) return hipErrorInvalidValue;
     if (p.causal && p.s_q != p.s_k) return hipErrorInvalidValue;
     if (p.hd <= 32) return launch_hd<32>(p, s);

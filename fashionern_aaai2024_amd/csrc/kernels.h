@@ -68,6 +68,11 @@ struct AttnParams {
     int batch, heads, hd, s_q, s_k, causal;
     float scale;
     unsigned short* out_b;       // when set: the output is stored as bf16 here (ldo in elements) instead of fp32 `out`
+    // bf16 operand form (all three set, with out_b): q/k/v hold bf16 bit patterns, strides in elements; QK^T and PV run on
+    // v_mfma_f32_32x32x16_bf16 with fp32 accumulation, softmax statistics in fp32, P rounded to bf16 for the PV product
+    const unsigned short* qb;
+    const unsigned short* kb;
+    const unsigned short* vb;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);   // hipErrorInvalidValue for unsupported shapes
 

@@ -330,6 +330,23 @@ class FernEngine:
                                            int(bool(causal)), sc, _stream()), "fern_attention")
         return out
 
+    def attention_bf16(self, q, k, v, heads: int, causal=False, scale=None) -> torch.Tensor:
+        """bf16 operand form of `attention`: q/k/v bf16 [B,S,W] (fp32 inputs are rounded first) -> bf16 [B,Sq,W]."""
+        def b16(x):
+            if x.dtype != torch.bfloat16:
+                x3 = self._f32(x)
+                return self.to_bf16(x3.reshape(-1, x3.shape[-1])).reshape(x3.shape)
+            return x.to(self.device).contiguous()
+        q, k, v = b16(q), b16(k), b16(v)
+        b, sq, w = q.shape
+        sk = k.shape[1]
+        hd = w // heads
+        out = torch.empty_like(q)
+        sc = float(scale) if scale is not None else hd ** -0.5
+        _lib.check(self.lib.fern_attention_bf16(self._h, _ptr(q), w, _ptr(k), w, _ptr(v), w, _ptr(out), w, b, heads, hd, sq, sk,
+                                                int(bool(causal)), sc, _stream()), "fern_attention_bf16")
+        return out
+
     # ---- profiling ----------------------------------------------------------------------------
     def prof_enable(self, on: bool) -> None:
         _lib.check(self.lib.fern_prof_enable(self._h, int(on)), "fern_prof_enable")

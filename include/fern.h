@@ -66,9 +66,10 @@ typedef enum {
 /* Operand precision of the CLIP towers' token-level GEMMs (BASELINE.json config 5 names a reduced-precision encoder;
  * SURVEY.md 7 step 6 "perf mode").  FP32 is the parity mode (exact fp32 FMA chains on the fp32 MFMA) and the default.
  * BF16: in every full transformer block of both towers the QKV / out-proj / c_fc / c_proj contractions (and the last ViT
- * block's K/V projection) read activations and weights rounded to bf16 (RNE) and accumulate in fp32; the residual
- * stream, LayerNorm statistics, softmax, GELU, patch embedding, class-token chain of the last ViT block, final
- * projections and the whole fusion / ranking path stay fp32.  Rounding points are fixed by the layer structure, not by
+ * block's K/V projection) read activations and weights rounded to bf16 (RNE) and accumulate in fp32, and the attention
+ * of those blocks runs in the bf16 operand form (fern_attention_bf16: q/k/v and the un-normalised softmax weights
+ * rounded to bf16, fp32 accumulation); the residual stream, LayerNorm / softmax statistics, GELU, patch embedding,
+ * class-token chain of the last ViT block, final projections and the whole fusion / ranking path stay fp32.  Rounding points are fixed by the layer structure, not by
  * the batch size, so results remain batch-invariant. */
 typedef enum {
     FERN_PREC_FP32 = 0,
@@ -236,6 +237,12 @@ FERN_API int fern_layernorm(fern_ctx* ctx, const float* x, const float* residual
 FERN_API int fern_attention(fern_ctx* ctx, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
                    int64_t ldv, float* out, int64_t ldo, int batch, int heads, int head_dim, int s_q,
                    int s_k, int causal, float scale, void* stream);
+/* bf16 operand form (perf mode of the CLIP towers): q/k/v/out hold bf16 bit patterns (strides in elements, % 8 == 0);
+ * QK^T and PV on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, `scale` applied to the fp32 scores, softmax statistics
+ * in fp32, the un-normalised weights rounded to bf16 for the PV product.  head_dim % 8 == 0, <= 96; s_k <= 224. */
+FERN_API int fern_attention_bf16(fern_ctx* ctx, const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v,
+                        int64_t ldv, uint16_t* out, int64_t ldo, int batch, int heads, int head_dim, int s_q, int s_k,
+                        int causal, float scale, void* stream);
 
 /* profiling ----------------------------------------------------------------------------- */
 FERN_API int fern_prof_enable(fern_ctx* ctx, int on);    /* wrap GEMM/attention/top-K launches in HIP events */

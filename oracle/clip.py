@@ -46,8 +46,23 @@ def _attention(sd, prefix, x, heads, causal, bf16=False, q_rows=None):
     hd = w // heads
     wi, bi = sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"]
     if q_rows is None:
-        qkv = _linear(x, wi, bi, bf16)
+        qkv = _r(_linear(x, wi, bi, bf16), bf16)          # bf16 precision: the packed projection is STORED as bf16
         q, k, v = qkv.split(w, dim=-1)
+        if bf16:
+            # bf16 operand attention of the product (include/fern.h:fern_attention_bf16): fp32 scores from bf16 q, k, scaled
+            # after the product; un-normalised weights rounded to bf16 for P V, normaliser from the un-rounded weights;
+            # output stored as bf16.  (The product rounds exp(s - running max) tile by tile; here the row max is used, which
+            # moves individual roundings by at most one bf16 ulp.)
+            q = q.view(b, s, heads, hd).transpose(1, 2)
+            k = k.view(b, s, heads, hd).transpose(1, 2)
+            v = v.view(b, s, heads, hd).transpose(1, 2)
+            att = (q @ k.transpose(-1, -2)) * (hd ** -0.5)
+            if causal:
+                att = att + torch.full((s, s), float("-inf")).triu(1)
+            e = torch.exp(att - att.max(dim=-1, keepdim=True).values)
+            o = (_r(e, True) @ v) / e.sum(dim=-1, keepdim=True)
+            o = _r(o.transpose(1, 2).reshape(b, s, w), True)
+            return _linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"], bf16)
     else:
         k, v = _linear(x, wi[w:], bi[w:], bf16).split(w, dim=-1)
         q = F.linear(x[:, q_rows], wi[:w], bi[:w])

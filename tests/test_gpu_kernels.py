@@ -254,3 +254,24 @@ def test_gemm_bf16(engine, m, n, k, epi, out_bf16):
         assert torch.allclose(got.float().cpu().double(), ref, rtol=2 ** -7, atol=1e-3)
     else:
         assert torch.allclose(got.cpu().double(), ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,heads,hd,sq,sk,causal", [
+    (3, 12, 64, 197, 197, False), (2, 8, 64, 77, 77, True), (2, 4, 32, 50, 50, False), (1, 2, 80, 91, 91, False),
+    (2, 3, 64, 13, 13, False), (1, 2, 96, 33, 33, True), (2, 2, 64, 224, 224, False), (1, 1, 8, 5, 5, False)])
+def test_attention_bf16(engine, b, heads, hd, sq, sk, causal):
+    """bf16 operand attention against fp64 softmax attention on the SAME bf16-rounded q, k, v."""
+    g = torch.Generator().manual_seed(b * 100 + heads * 10 + hd + sq)
+    w = heads * hd
+    q, k, v = (torch.randn(b, s, w, generator=g).bfloat16() for s in (sq, sk, sk))
+    got = engine.attention_bf16(q.cuda(), k.cuda(), v.cuda(), heads, causal=causal)
+    assert got.dtype == torch.bfloat16
+    qd, kd, vd = (t.double().view(b, -1, heads, hd).transpose(1, 2) for t in (q, k, v))
+    att = qd @ kd.transpose(-1, -2) * hd ** -0.5
+    if causal:
+        att = att + torch.full((sq, sk), float("-inf"), dtype=torch.float64).triu(1)
+    ref = (torch.softmax(att, dim=-1) @ vd).transpose(1, 2).reshape(b, sq, w)
+    # error budget: weights rounded to bf16 (2^-9 relative each, averaged over the keys) + one bf16 rounding of the output
+    err = (got.float().cpu().double() - ref).abs().max().item()
+    assert err < 2 ** -7 * max(1.0, ref.abs().max().item()), err
