@@ -26,7 +26,7 @@ from .synth import CLIP_CONFIGS, ClipConfig
 class FernCLIP:
     """CLIP ViT image tower + text tower running as HIP kernels on one MI355X."""
 
-    def __init__(self, model_name: Union[str, ClipConfig] = "ViT-B-16", device="cuda:0", engine=None):
+    def __init__(self, model_name: Union[str, ClipConfig] = "ViT-B-16", device="cuda:0", engine=None, precision: str = "fp32"):
         cfg = model_name if isinstance(model_name, ClipConfig) else CLIP_CONFIGS.get(model_name)
         if cfg is None:
             raise ValueError(f"unknown CLIP model {model_name!r}; known: {sorted(CLIP_CONFIGS)}")
@@ -36,6 +36,18 @@ class FernCLIP:
         self._state: Dict[str, np.ndarray] = {}
         self._ready = False
         self._text_cache = None
+        if precision != "fp32":
+            self.set_precision(precision)
+
+    def set_precision(self, precision: str):
+        """"fp32": parity mode (default, the reference's arithmetic).  "bf16": perf mode of the transformer towers --
+        bf16 operands / fp32 accumulation on the block GEMMs and attention (include/fern.h:fern_precision); no
+        reference counterpart (the reference evaluates in fp32, test_fiq.py:141-149)."""
+        if precision == "bf16" and self.cfg.v_arch == "resnet":
+            raise ValueError("bf16 precision covers the transformer towers; RN50x4's image tower has no bf16 path")
+        self.engine.set_precision(precision)
+        self._text_cache = None
+        return self
 
     # -- nn.Module-like surface used by the reference scripts (test_fiq.py:142-145) ---------------
     def load_state_dict(self, state_dict: Mapping[str, object], strict: bool = True):
@@ -89,10 +101,10 @@ class FernCLIP:
         return s if mode == "seq" else (g, s)
 
 
-def create_model(model_name="ViT-B-16", device="cuda:0", seed: Optional[int] = None, engine=None) -> FernCLIP:
+def create_model(model_name="ViT-B-16", device="cuda:0", seed: Optional[int] = None, engine=None, precision: str = "fp32") -> FernCLIP:
     """Counterpart of ``open_clip.create_model_and_transforms(name, device=)`` (test_fiq.py:141): random-init when
     ``seed`` is given, otherwise weights must follow through ``load_state_dict(saved["CLIP"])``."""
-    m = FernCLIP(model_name, device, engine=engine)
+    m = FernCLIP(model_name, device, engine=engine, precision=precision)
     if seed is not None:
         m.init_random(seed)
     return m

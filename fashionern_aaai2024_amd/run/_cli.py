@@ -96,10 +96,12 @@ def main(kind: str) -> None:
     p.add_argument("--synthetic-gallery", default=2000, type=int)
     p.add_argument("--synthetic-queries", default=256, type=int)
     p.add_argument("--seed", default=42, type=int)
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                   help="encoder operand precision: fp32 = the reference's arithmetic; bf16 = perf mode (ViT / text towers)")
     args = p.parse_args()
     setup_seed(args.seed)
     device = torch.device("cuda")
-    clip_model = create_model(args.clip_model_name, device=device, seed=None if args.clip_path else args.seed)
+    clip_model = create_model(args.clip_model_name, device=device, seed=None if args.clip_path else args.seed, precision=args.precision)
     if args.clip_path:
         clip_model.load_state_dict(torch.load(args.clip_path, map_location="cpu")["CLIP"])
     cfg = clip_model.cfg

@@ -18,6 +18,12 @@ class OracleEngine:
         self.sd = {}
         self.feature_dim = None
         self.clip_cfg = None
+        self.precision = "fp32"
+
+    def set_precision(self, precision):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(precision)
+        self.precision = precision
 
     def close(self):
         pass
@@ -34,10 +40,10 @@ class OracleEngine:
         self.clip_cfg = cfg
 
     def encode_image(self, images):
-        return oclip.encode_image(self.sd, self.clip_cfg, images.float().cpu())
+        return oclip.encode_image(self.sd, self.clip_cfg, images.float().cpu(), precision=self.precision)
 
     def encode_text(self, tokens, want_global=True, want_seq=True):
-        g, s = oclip.encode_text(self.sd, self.clip_cfg, tokens.cpu())
+        g, s = oclip.encode_text(self.sd, self.clip_cfg, tokens.cpu(), precision=self.precision)
         return (g if want_global else None), (s if want_seq else None)
 
     def dvr_fuse(self, ref_global, ref_local, text_global, text_seq):

@@ -161,3 +161,41 @@ def test_cli_driver_runs_on_synthetic_split():
                            cwd=root, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert "Average:" in r.stdout
+
+
+def test_full_pipeline_in_bf16_perf_mode_stays_within_the_score_budget():
+    """The whole FIQ harness with the encoders in bf16 perf mode vs the same run in fp32 parity mode.
+
+    The mode moves the CLIP features by ~1e-5 in cosine (an angle of a few 1e-3 rad), so a cosine SCORE against another
+    unit vector can move by a few 1e-3: the perf mode is NOT inside north_star's 1e-3 score tolerance -- that contract
+    (and exact top-K ordering) belongs to the fp32 mode.  What the perf mode must keep (measured on this split:
+    score deviations <= 2.8e-3, top-50 overlap 0.996, identical recall tuples): scores within 5e-3, top-50 overlap
+    > 0.95, recall@K within two queries."""
+    cfg = synth.CLIP_CONFIGS["tiny-hd64"]
+    d = cfg.embed_dim
+    register_tokenizer("tiny-hd64", sdata.stub_tokenizer)
+    gal = sdata.Gallery(300, d, seed=31, image_size=cfg.image_size)
+    rel = sdata.RelativeDataset(gal, 40, "fiq", seed=32)
+    outs = []
+    for precision in ("fp32", "bf16"):
+        clip = create_model(cfg, device=DEV, seed=9, precision=precision)
+        assert clip.engine.precision == precision
+        model = ERN(clip, d, DEV, engine=clip.engine).init_random(4)
+        feats, names, local = extract_index_features(sdata.ClassicDataset(gal), clip, 13, DEV, d, num_workers=0)
+        pred, _ = test_fiq.generate_fiq_val_predictions(clip, rel, model, names, feats, DEV, d, 16, 0, "tiny-hd64")
+        fused = _common.fuse_index(model, feats, local)
+        s, i = model.engine.sim_topk(pred, fused, 50)
+        rec = test_fiq.compute_fiq_val_metrics(rel, clip, feats, local, names, model, DEV, d, 16, 0, "tiny-hd64")
+        outs.append((pred.cpu(), s.cpu(), i.cpu(), rec))
+    (p0, s0, i0, r0), (p1, s1, i1, r1) = outs
+    assert not torch.equal(p0, p1)                                      # really another precision
+    assert (1 - torch.nn.functional.cosine_similarity(p0, p1, dim=-1)).max() < 1e-4
+    assert (s0[:, 0] - s1[:, 0]).abs().max() < 5e-3
+    overlap = np.mean([len(set(a.tolist()) & set(b.tolist())) / 50 for a, b in zip(i0, i1)])
+    assert overlap > 0.95
+    assert all(abs(a - b) <= 5.0 for a, b in zip(r0, r1))               # recall@K in percent, 40 queries: <= 2 queries apart
+
+
+def test_bf16_precision_is_refused_for_the_resnet_tower():
+    with pytest.raises(ValueError, match="transformer towers"):
+        create_model("tiny-resnet", device=DEV, seed=1, precision="bf16")

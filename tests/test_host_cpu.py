@@ -151,3 +151,31 @@ def test_product_has_no_cpu_fallback_and_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_precision_option_of_the_clip_surface_and_oracle_bf16_restatement():
+    """Host side of the encoder precision switch (FernCLIP.set_precision / create_model(precision=)) on the test-only
+    engine, and a sanity check of the oracle's bf16 restatement itself: same arithmetic with bf16-rounded operands, so
+    it must differ from, and stay close to, the fp32 statement."""
+    from fashionern_aaai2024_amd.clip_model import create_model
+    cfg = synth.CLIP_CONFIGS["tiny"]
+    imgs = torch.from_numpy(synth.images(3, cfg, 3))
+    toks = torch.from_numpy(synth.captions(3, cfg, 3))
+    clip = create_model(cfg, device="cpu", seed=2, engine=OracleEngine())
+    f32_img = clip.encode_image(imgs)
+    f32_g, f32_s = clip.encode_text(toks)
+    clip.set_precision("bf16")
+    assert clip.engine.precision == "bf16"
+    b_img = clip.encode_image(imgs)
+    b_g, b_s = clip.encode_text(toks)          # the text cache must not serve the fp32 result
+    cs = torch.nn.functional.cosine_similarity
+    for a, b in ((f32_img, b_img), (f32_g, b_g)):
+        assert not torch.equal(a, b)
+        assert (1 - cs(a, b, dim=-1)).max().item() < 1e-3
+    assert b_s.shape == f32_s.shape
+    # every row depends only on itself under the restated mode too
+    assert torch.allclose(clip.encode_image(imgs[1:2]), b_img[1:2], atol=1e-5)
+    with pytest.raises(ValueError):
+        create_model("tiny-resnet", device="cpu", seed=1, engine=OracleEngine(), precision="bf16")
+    with pytest.raises(ValueError):
+        clip.engine.set_precision("fp8")
