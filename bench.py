@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--gallery", type=int, default=GALLERY)
     ap.add_argument("--lanes", type=int, default=3, help="64-query batches kept in flight on separate HIP streams")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16", "fp8"], default="fp32",
                     help="encoder operand precision of the TIMED path: fp32 = parity mode (the headline), bf16 = perf mode")
     ap.add_argument("--pmc-mode", action="store_true",
                     help="for `rocprofv3 --pmc`: warm up, emit a marker dispatch, run exactly --steps steps, exit (no JSON)")
@@ -170,10 +170,8 @@ def main():
 
     # ---- encoder perf mode (bf16 operands, fp32 accumulation) on the same workload: reported beside the fp32 headline,
     # never as `value` (north_star's parity bar -- scores within 1e-3, identical ordering -- is an fp32 statement)
-    bf16_info = None
-    if args.precision == "fp32":
-        ref_scores, ref_idx = step().wait()
-        pipe.set_precision("bf16")
+    def reduced_precision_leg(prec, ref_scores, ref_idx):
+        pipe.set_precision(prec)
         for _ in range(max(args.warmup, args.lanes)):
             step()
         barrier()
@@ -181,28 +179,37 @@ def main():
         for _ in range(args.steps):
             out_b = step()
         barrier()
-        bf16_elapsed = time.perf_counter() - t0
+        el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([bf16_elapsed], dtype=torch.float64, device=device)
+            t = torch.tensor([el], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            bf16_elapsed = t.item()
+            el = t.item()
         b_scores, b_idx = out_b.wait()
         eng.prof_enable(True)
         for _ in range(2):
             step_serial()
-        sb16 = eng.prof_collect()
+        sp = eng.prof_collect()
         eng.prof_enable(False)
+        key = "gemm_fp8" if prec == "fp8" else "gemm_bf16"
+        peak = BF16_MFMA_PEAK_TFLOPS      # the non-scaled fp8 MFMA (32x32x16) issues at the bf16 rate
+        tfl = sp[key + "_flops"] / (sp[key + "_ms"] * 1e-3) / 1e12 if sp[key + "_ms"] > 0 else 0.0
         overlap = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(ref_idx.cpu(), b_idx.cpu())) / ref_idx.numel()
-        bf16_tflops = sb16["gemm_bf16_flops"] / (sb16["gemm_bf16_ms"] * 1e-3) / 1e12 if sb16["gemm_bf16_ms"] > 0 else 0.0
-        bf16_info = {"value": world * QUERY_BATCH * args.steps / bf16_elapsed, "unit": "queries/sec",
-                     "ms_per_step": bf16_elapsed / args.steps * 1e3, "dtype": "bf16 operands, f32 accumulate (encoder block GEMMs only)",
-                     "gemm_bf16_tflops": bf16_tflops, "gemm_bf16_peak_tflops": BF16_MFMA_PEAK_TFLOPS,
-                     "gemm_bf16_frac": bf16_tflops / BF16_MFMA_PEAK_TFLOPS, "gemm_bf16_ms_per_step": sb16["gemm_bf16_ms"] / 2,
-                     "gemm_f32_ms_per_step": sb16["gemm_ms"] / 2, "attention_ms_per_step": sb16["attn_ms"] / 2,
-                     "vs_fp32_top1_same": float((ref_idx[:, 0] == b_idx[:, 0]).float().mean().item()),
-                     "vs_fp32_top50_overlap": overlap,
-                     "vs_fp32_max_abs_top1_score_diff": float((ref_scores[:, 0] - b_scores[:, 0]).abs().max().item())}
+        info = {"value": world * QUERY_BATCH * args.steps / el, "unit": "queries/sec", "ms_per_step": el / args.steps * 1e3,
+                "dtype": ("bf16" if prec == "bf16" else "fp8 e4m3fn (per-token / per-channel scales)") +
+                         " operands, f32 accumulate (encoder block GEMMs; attention in bf16 operand form)",
+                "gemm_tflops": tfl, "gemm_peak_tflops": peak, "gemm_frac": tfl / peak, "gemm_ms_per_step": sp[key + "_ms"] / 2,
+                "gemm_f32_ms_per_step": sp["gemm_ms"] / 2, "attention_ms_per_step": sp["attn_ms"] / 2,
+                "vs_fp32_top1_same": float((ref_idx[:, 0] == b_idx[:, 0]).float().mean().item()),
+                "vs_fp32_top50_overlap": overlap,
+                "vs_fp32_max_abs_top1_score_diff": float((ref_scores[:, 0] - b_scores[:, 0]).abs().max().item())}
         pipe.set_precision("fp32")
+        return info
+
+    bf16_info = fp8_info = None
+    if args.precision == "fp32":
+        ref_scores, ref_idx = step().wait()
+        bf16_info = reduced_precision_leg("bf16", ref_scores, ref_idx)
+        fp8_info = reduced_precision_leg("fp8", ref_scores, ref_idx)
 
     # ---- roofline: instrumented passes (events around every kernel class), outside the timed region ----------
     step_serial()
@@ -265,7 +272,7 @@ def main():
         result = {
             "metric": "composed queries/sec", "value": value, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp8": "fp8"}[args.precision], "data": "synthetic",
             "config": {"workload": "FashionIQ ViT-B/16 composed queries: 64-query batch per GPU vs 46k-image fused gallery "
                                    "(BASELINE.json configs[1])",
                        "query_batch_per_gpu": QUERY_BATCH, "gallery_rows": n_gal, "feature_dim": D, "top_k": TOPK,
@@ -286,6 +293,7 @@ def main():
                                            "kernel": "sweep_bf16_kernel: 64 queries x 1M-row bf16 gallery (config 5's similarity mode)",
                                            "sweep_us": bf16_us, "topk_us": sb["topk_ms"] / max(1, sb["topk_launches"]) * 1e3},
             "encoder_bf16": bf16_info,
+            "encoder_fp8": fp8_info,
             "attention": {"achieved_tflops": attn_tflops, "ms_per_step": st["attn_ms"] / prof_steps},
             "lookup_variant": {"value": lookup_qps * world, "unit": "queries/sec",
                                "note": "reference-faithful query path (test_fiq.py:104-107): reference features looked up in the index, "

@@ -22,6 +22,7 @@ class ProfStats(C.Structure):
                 ("attn_ms", C.c_double), ("attn_flops", C.c_double), ("attn_launches", c_i64),
                 ("topk_ms", C.c_double), ("topk_launches", c_i64),
                 ("sweep_ms", C.c_double), ("sweep_bytes", C.c_double), ("sweep_launches", c_i64),
+                ("gemm_fp8_ms", C.c_double), ("gemm_fp8_flops", C.c_double), ("gemm_fp8_launches", c_i64),
                 ("gemm_bf16_ms", C.c_double), ("gemm_bf16_flops", C.c_double), ("gemm_bf16_launches", c_i64)]
 
 
@@ -62,6 +63,9 @@ SIGNATURES = {
     "fern_get_precision": (c_int, [c_void_p]),
     "fern_gemm_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
                                c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fern_quantize_rows_fp8": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),
+    "fern_gemm_fp8": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
+                              c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fern_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_void_p]),
     "fern_attention": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),

@@ -48,7 +48,8 @@ struct HostTensor {
     size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
 };
 
-struct LinearW { const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0; const unsigned short* wb = nullptr; /* bf16 copy of w (encoder blocks) */ };
+struct LinearW { const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0; const unsigned short* wb = nullptr; /* bf16 copy of w (encoder blocks) */
+                 const unsigned char* w8 = nullptr; const float* sw = nullptr; /* fp8 copy + per-output-channel scales */ };
 struct LNW { const float* g = nullptr; const float* b = nullptr; };
 struct CombinerW { LinearW text, image, hidden; const float* w2 = nullptr; const float* b2 = nullptr; };
 struct SRW {
@@ -188,9 +189,18 @@ static GemmParams gemm_desc_b(const unsigned short* A, long lda, const LinearW& 
     p.M = M; p.N = L.out; p.K = L.in; p.epi = epi; p.aload = ALOAD_PLAIN; p.out_bf16 = out_bf16 ? 1 : 0;
     return p;
 }
+// fp8-operand GEMM: A8 [M, K] e4m3fn with per-row scales sa, the layer's fp8 weight copy with per-channel scales
+static GemmParams gemm_desc_f8(const unsigned char* A8, const float* sa, long lda, const LinearW& L, void* C, long ldc, int M, int epi,
+                               bool out_bf16) {
+    GemmParams p{};
+    p.Ab = reinterpret_cast<const unsigned short*>(A8); p.lda = lda; p.Wb = reinterpret_cast<const unsigned short*>(L.w8); p.ldw = L.in;
+    p.bias = L.b; p.C = reinterpret_cast<float*>(C); p.ldc = ldc; p.M = M; p.N = L.out; p.K = L.in; p.epi = epi; p.aload = ALOAD_PLAIN;
+    p.out_bf16 = out_bf16 ? 1 : 0; p.fp8 = 1; p.scale_a = sa; p.scale_w = L.sw;
+    return p;
+}
 static int run_gemm_b(fern_ctx* c, const GemmParams& p, hipStream_t s) {
     int slot;
-    FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, 100 + p.epi));
+    FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, (p.fp8 ? 200 : 100) + p.epi));
     HIP_TRY(launch_gemm_bf16(p, s));
     return prof_close(c, slot, s);
 }
@@ -449,6 +459,21 @@ static int make_bf16(fern_ctx* c, LinearW* L) {
     return FERN_OK;
 }
 
+// fp8 (e4m3fn) device copy with one scale per output channel (row of the [out, in] matrix)
+static int make_fp8(fern_ctx* c, LinearW* L) {
+    if (L->in % 64 || L->in > 4096) return FERN_OK;      // shape outside the fp8 GEMM: the layer keeps bf16 / fp32 only
+    unsigned char* d = nullptr;
+    float* sw = nullptr;
+    HIP_TRY(hipMalloc(&d, (size_t)L->out * L->in));
+    c->owned.push_back(d);
+    HIP_TRY(hipMalloc(&sw, (size_t)L->out * sizeof(float)));
+    c->owned.push_back(sw);
+    HIP_TRY(launch_quantize_rows_fp8(nullptr, L->w, L->in, d, L->in, sw, L->out, L->in, nullptr));
+    L->w8 = d;
+    L->sw = sw;
+    return FERN_OK;
+}
+
 static int up_clip_block(fern_ctx* c, const std::string& p, int width, int mlp, ClipBlockW* B) {
     FERN_TRY(up_ln(c, p + ".ln_1", width, &B->ln1));
     FERN_TRY(up_key(c, p + ".attn.in_proj_weight", {3 * width, width}, &B->qkv.w));
@@ -461,7 +486,11 @@ static int up_clip_block(fern_ctx* c, const std::string& p, int width, int mlp, 
     FERN_TRY(make_bf16(c, &B->qkv));
     FERN_TRY(make_bf16(c, &B->out));
     FERN_TRY(make_bf16(c, &B->fc));
-    return make_bf16(c, &B->proj);
+    FERN_TRY(make_bf16(c, &B->proj));
+    FERN_TRY(make_fp8(c, &B->qkv));
+    FERN_TRY(make_fp8(c, &B->out));
+    FERN_TRY(make_fp8(c, &B->fc));
+    return make_fp8(c, &B->proj);
 }
 
 // conv (no bias) + BatchNorm(eval) -> [cout_pad][kh*kw*cin_pad] weights in (ky, kx, ci) order (or the original (ci, ky, kx)
@@ -579,7 +608,14 @@ extern "C" int fern_finalize_clip(fern_ctx* c, const fern_clip_config* cfg) {
 
 extern "C" int fern_set_precision(fern_ctx* c, int precision) {
     if (!c) return fail(FERN_ERR_ARG, "fern_set_precision: ctx is NULL");
-    if (precision != FERN_PREC_FP32 && precision != FERN_PREC_BF16) return fail(FERN_ERR_ARG, "fern_set_precision: unknown precision");
+    if (precision != FERN_PREC_FP32 && precision != FERN_PREC_BF16 && precision != FERN_PREC_FP8)
+        return fail(FERN_ERR_ARG, "fern_set_precision: unknown precision");
+    if (precision == FERN_PREC_FP8 && c->clip.ready) {
+        for (const auto* blocks : {&c->clip.vblocks, &c->clip.tblocks})
+            for (const auto& b : *blocks)
+                if (!b.qkv.w8 || !b.out.w8 || !b.fc.w8 || !b.proj.w8)
+                    return fail(FERN_ERR_ARG, "fern_set_precision: fp8 needs tower widths and MLP widths that are multiples of 64 (<= 4096)");
+    }
     c->precision = precision;
     return FERN_OK;
 }
@@ -881,6 +917,32 @@ static int clip_block_bf16(fern_ctx* c, const ClipBlockW& Bk, float* X, unsigned
     return run_gemm_b(c, p2, s);
 }
 
+// fp8 block (BASELINE config 5: "fp8 MFMA encoder path"): the four token-level GEMMs take e4m3fn operands with per-token
+// activation scales and per-output-channel weight scales, folded back in the fp32 epilogue.  LayerNorm quantises as it
+// writes; the attention and GELU outputs are written as bf16 (a row's maximum is not known inside those kernels) and
+// quantised by a row pass.  Attention itself runs in the bf16 operand form; everything else as in the bf16 block.
+static int clip_block_fp8(fern_ctx* c, const ClipBlockW& Bk, float* X, unsigned char* XN8, float* SA, unsigned short* QKVb,
+                          unsigned short* ATTb, unsigned char* ATT8, unsigned short* Hb, unsigned char* H8, int batch, int S, int width,
+                          int heads, int causal, hipStream_t s) {
+    const long R = (long)batch * S;
+    const int hd = width / heads, mlp = Bk.fc.out;
+    HIP_TRY(launch_layernorm_fp8(X, Bk.ln1.g, Bk.ln1.b, XN8, SA, R, width, width, width, 1e-5f, s));
+    FERN_TRY(run_gemm_b(c, gemm_desc_f8(XN8, SA, width, Bk.qkv, QKVb, 3 * width, (int)R, EPI_BIAS, true), s));
+    AttnParams a{nullptr, nullptr, nullptr, nullptr, 3L * width, 3L * width, 3L * width, (long)width,
+                 batch, heads, hd, S, S, causal, 1.0f / std::sqrt((float)hd), ATTb, QKVb, QKVb + width, QKVb + 2 * width};
+    FERN_TRY(run_attention(c, a, s));
+    HIP_TRY(launch_quantize_rows_fp8(ATTb, nullptr, width, ATT8, width, SA, R, width, s));
+    GemmParams po = gemm_desc_f8(ATT8, SA, width, Bk.out, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
+    po.R = X;
+    FERN_TRY(run_gemm_b(c, po, s));
+    HIP_TRY(launch_layernorm_fp8(X, Bk.ln2.g, Bk.ln2.b, XN8, SA, R, width, width, width, 1e-5f, s));
+    FERN_TRY(run_gemm_b(c, gemm_desc_f8(XN8, SA, width, Bk.fc, Hb, mlp, (int)R, EPI_BIAS_GELU, true), s));
+    HIP_TRY(launch_quantize_rows_fp8(Hb, nullptr, mlp, H8, mlp, SA, R, mlp, s));
+    GemmParams p2 = gemm_desc_f8(H8, SA, mlp, Bk.proj, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
+    p2.R = X;
+    return run_gemm_b(c, p2, s);
+}
+
 // Last ViT block: only the class token is consumed afterwards (ln_post on token 0, modeling_clip.py:876-877), so
 // K/V are projected for every token but Q, the attention output, out_proj and the MLP run for the class rows only.
 // Bit-identical to the full block on the rows that are read.
@@ -889,8 +951,17 @@ static int clip_block_cls_only(fern_ctx* c, const ClipBlockW& Bk, const float* X
                                int heads, hipStream_t s) {
     const long R = (long)batch * S;
     const int hd = width / heads;
-    LinearW kv{Bk.qkv.w + (size_t)width * width, Bk.qkv.b + width, 2 * width, width, Bk.qkv.wb + (size_t)width * width};
-    if (c->precision == FERN_PREC_BF16) {
+    LinearW kv{Bk.qkv.w + (size_t)width * width, Bk.qkv.b + width, 2 * width, width, Bk.qkv.wb + (size_t)width * width,
+               Bk.qkv.w8 ? Bk.qkv.w8 + (size_t)width * width : nullptr, Bk.qkv.sw ? Bk.qkv.sw + width : nullptr};
+    if (c->precision == FERN_PREC_FP8) {
+        // fp8 mode: quantised K/V projection of all tokens (fp32 output); the class-row chain below stays fp32
+        unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
+        float* SA = XN + ((size_t)R * width / 4 + 63) / 64 * 64;       // scales live behind the fp8 rows inside XN
+        HIP_TRY(launch_layernorm_fp8(X, Bk.ln1.g, Bk.ln1.b, XN8, SA, R, width, width, width, 1e-5f, s));
+        FERN_TRY(run_gemm_b(c, gemm_desc_f8(XN8, SA, width, kv, QKV + width, 3 * width, (int)R, EPI_BIAS, false), s));
+        HIP_TRY(launch_gather_rows(X, width, T1, width, batch, width, 1, S, 0, nullptr, s));
+        HIP_TRY(launch_layernorm(T1, nullptr, Bk.ln1.g, Bk.ln1.b, T0, batch, width, width, width, 1e-5f, s));
+    } else if (c->precision == FERN_PREC_BF16) {
         // perf mode: the token-level K/V projection takes bf16 operands; the class-row chain below stays fp32
         unsigned short* XNb = reinterpret_cast<unsigned short*>(XN);
         HIP_TRY(launch_layernorm_bf16(X, Bk.ln1.g, Bk.ln1.b, XNb, R, width, width, width, 1e-5f, s));
@@ -941,7 +1012,13 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
     HIP_TRY(launch_vit_cls(W.cls, W.vpos, X, b, S, vw, s));
     HIP_TRY(launch_layernorm(X, nullptr, W.ln_pre.g, W.ln_pre.b, X, R, vw, vw, vw, 1e-5f, s));
     for (int l = 0; l + 1 < cf.v_layers; ++l) {
-        if (c->precision == FERN_PREC_BF16)     // XN / ATT / H double as the bf16 operand buffers (half filled)
+        if (c->precision == FERN_PREC_FP8) {    // XN: fp8 rows + scales; ATT / H: bf16 output in the first half, its fp8 copy behind it
+            unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
+            FERN_TRY(clip_block_fp8(c, W.vblocks[l], X, XN8, XN + ((size_t)R * vw / 4 + 63) / 64 * 64, reinterpret_cast<unsigned short*>(QKV),
+                                    reinterpret_cast<unsigned short*>(ATT), reinterpret_cast<unsigned char*>(ATT) + (size_t)R * vw * 2,
+                                    reinterpret_cast<unsigned short*>(H), reinterpret_cast<unsigned char*>(H) + (size_t)R * cf.v_mlp * 2,
+                                    b, S, vw, cf.v_heads, 0, s));
+        } else if (c->precision == FERN_PREC_BF16)     // XN / ATT / H double as the bf16 operand buffers (half filled)
             FERN_TRY(clip_block_bf16(c, W.vblocks[l], X, reinterpret_cast<unsigned short*>(XN), reinterpret_cast<unsigned short*>(QKV),
                                      reinterpret_cast<unsigned short*>(ATT),
                                      reinterpret_cast<unsigned short*>(H), b, S, vw, cf.v_heads, 0, s));
@@ -1068,7 +1145,13 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
     FERN_TRY(ws_get(c, (size_t)B, &eot));
     HIP_TRY(launch_text_embed(tokens, W.tok_emb, W.tpos, X, eot, B, T, tw, cf.vocab_size, s));
     for (int l = 0; l < cf.t_layers; ++l) {
-        if (c->precision == FERN_PREC_BF16)
+        if (c->precision == FERN_PREC_FP8) {
+            unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
+            FERN_TRY(clip_block_fp8(c, W.tblocks[l], X, XN8, XN + ((size_t)R * tw / 4 + 63) / 64 * 64, reinterpret_cast<unsigned short*>(QKV),
+                                    reinterpret_cast<unsigned short*>(ATT), reinterpret_cast<unsigned char*>(ATT) + (size_t)R * tw * 2,
+                                    reinterpret_cast<unsigned short*>(H), reinterpret_cast<unsigned char*>(H) + (size_t)R * cf.t_mlp * 2,
+                                    B, T, tw, cf.t_heads, 1, s));
+        } else if (c->precision == FERN_PREC_BF16)
             FERN_TRY(clip_block_bf16(c, W.tblocks[l], X, reinterpret_cast<unsigned short*>(XN), reinterpret_cast<unsigned short*>(QKV),
                                      reinterpret_cast<unsigned short*>(ATT),
                                      reinterpret_cast<unsigned short*>(H), B, T, tw, cf.t_heads, 1, s));
@@ -1261,6 +1344,34 @@ extern "C" int fern_gemm_bf16(fern_ctx* c, const uint16_t* A, int64_t lda, const
     return prof_close(c, slot, (hipStream_t)stream);
 }
 
+extern "C" int fern_quantize_rows_fp8(fern_ctx* c, const void* x, int x_is_bf16, int64_t ldx, uint8_t* y, int64_t ldy, float* scale, int64_t rows,
+                                      int d, void* stream) {
+    if (!c || rows < 0 || (rows && (!x || !y || !scale))) return fail(FERN_ERR_ARG, "fern_quantize_rows_fp8: bad argument");
+    if (d <= 0 || d % 8 || d > 4096 || ldx % 8 || ldy % 8) return fail(FERN_ERR_ARG, "fern_quantize_rows_fp8: need d % 8 == 0, d <= 4096, ld % 8 == 0");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_quantize_rows_fp8(x_is_bf16 ? static_cast<const unsigned short*>(x) : nullptr, x_is_bf16 ? nullptr : static_cast<const float*>(x),
+                                     ldx, y, ldy, scale, rows, d, (hipStream_t)stream));
+    return FERN_OK;
+}
+
+extern "C" int fern_gemm_fp8(fern_ctx* c, const uint8_t* A, int64_t lda, const float* scale_a, const uint8_t* W, int64_t ldw, const float* scale_w,
+                             const float* bias, const float* residual, void* C, int64_t ldc, int M, int N, int K, int epilogue, int out_bf16,
+                             void* stream) {
+    if (!c || M < 0 || N < 0 || K <= 0) return fail(FERN_ERR_ARG, "fern_gemm_fp8: bad argument");
+    if (M == 0 || N == 0) return FERN_OK;
+    if (!A || !W || !C || !scale_a || !scale_w) return fail(FERN_ERR_ARG, "fern_gemm_fp8: NULL argument");
+    if (epilogue != FERN_EPI_BIAS && epilogue != FERN_EPI_BIAS_GELU && epilogue != FERN_EPI_BIAS_RESIDUAL)
+        return fail(FERN_ERR_ARG, "fern_gemm_fp8: epilogue must be BIAS, BIAS_GELU or BIAS_RESIDUAL");
+    if (epilogue == FERN_EPI_BIAS_RESIDUAL && (!residual || out_bf16)) return fail(FERN_ERR_ARG, "fern_gemm_fp8: the residual epilogue needs a residual and fp32 output");
+    if (K % 64 || lda % 16 || ldw % 16) return fail(FERN_ERR_ARG, "fern_gemm_fp8: K % 64, lda % 16 and ldw % 16 must be 0");
+    HIP_TRY(hipSetDevice(c->device));
+    GemmParams p{};
+    p.Ab = reinterpret_cast<const unsigned short*>(A); p.lda = lda; p.Wb = reinterpret_cast<const unsigned short*>(W); p.ldw = ldw;
+    p.bias = bias; p.R = residual; p.C = reinterpret_cast<float*>(C); p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epilogue;
+    p.aload = ALOAD_PLAIN; p.out_bf16 = out_bf16 ? 1 : 0; p.fp8 = 1; p.scale_a = scale_a; p.scale_w = scale_w;
+    return run_gemm_b(c, p, (hipStream_t)stream);
+}
+
 extern "C" int fern_layernorm(fern_ctx* c, const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                               int64_t rows, int d, float eps, void* stream) {
     if (!c || !x || !gamma || !beta || !y || rows < 0) return fail(FERN_ERR_ARG, "fern_layernorm: bad argument");
@@ -1309,7 +1420,8 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
         if (dump) std::fprintf(dump, "%d,%d,%d,%d,%d,%.6f,%.0f\n", r.kind, r.m, r.n, r.k, r.tag, ms, r.work);
         switch (r.kind) {
             case PROF_GEMM:
-                if (r.tag >= 100) { out->gemm_bf16_ms += ms; out->gemm_bf16_flops += r.work; out->gemm_bf16_launches++; }
+                if (r.tag >= 200) { out->gemm_fp8_ms += ms; out->gemm_fp8_flops += r.work; out->gemm_fp8_launches++; }
+                else if (r.tag >= 100) { out->gemm_bf16_ms += ms; out->gemm_bf16_flops += r.work; out->gemm_bf16_launches++; }
                 else { out->gemm_ms += ms; out->gemm_flops += r.work; out->gemm_launches++; }
                 break;
             case PROF_ATTN: out->attn_ms += ms; out->attn_flops += r.work; out->attn_launches++; break;

@@ -112,6 +112,84 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* x, con
     }
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// LayerNorm fused with per-row fp8 (e4m3fn) quantisation: scale = max|y| / 448, y8 = fp8(y / scale)
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* x, const float* gamma, const float* beta, unsigned char* y,
+                                                            float* scale, long rows, int d, long ldx, long ldy, float eps) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    RowRegs r;
+    row_load(r, x + row * ldx, d, lane);
+    row_layernorm(r, gamma, beta, d, lane, eps);
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) am = fmaxf(am, fmaxf(fmaxf(fabsf(r.v[i][0]), fabsf(r.v[i][1])), fmaxf(fabsf(r.v[i][2]), fabsf(r.v[i][3]))));
+    }
+    am = wave_max(am);
+    const float sc = am > 0.f ? am * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+    unsigned char* yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) *reinterpret_cast<unsigned*>(yr + c) = pack4_fp8(r.v[i][0] * inv, r.v[i][1] * inv, r.v[i][2] * inv, r.v[i][3] * inv);
+    }
+}
+
+// Per-row fp8 quantisation of a bf16 or fp32 matrix (one wave per row, rows up to 8 * 512 = 4096 wide, d % 8 == 0):
+// scale = max|x| / 448, y8 = fp8(x / scale).  Used for the attention / GELU outputs (bf16) and the weight matrices (fp32).
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const unsigned short* xb, const float* xf, long ldx, unsigned char* y, long ldy,
+                                                                float* scale, long rows, int d) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[8][8];
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = (i * 64 + lane) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        if (c < d) {
+            if (xb) {
+                const uint4 t = *reinterpret_cast<const uint4*>(xb + row * ldx + c);
+                const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[i][2 * e] = __uint_as_float(w[e] << 16); v[i][2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xf + row * ldx + c), b = *reinterpret_cast<const f32x4*>(xf + row * ldx + c + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = b[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(v[i][e]));
+        }
+    }
+    am = wave_max(am);
+    const float sc = am > 0.f ? am * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < d) {
+            uint2 o;
+            o.x = pack4_fp8(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv);
+            o.y = pack4_fp8(v[i][4] * inv, v[i][5] * inv, v[i][6] * inv, v[i][7] * inv);
+            *reinterpret_cast<uint2*>(y + row * ldy + c) = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* x, const float* x2, long ldx, float* y, long ldy, long rows, int d,
                                                      float eps, int mode) {
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -392,6 +470,20 @@ hipError_t launch_layernorm_bf16(const float* x, const float* gamma, const float
     if (rows <= 0) return hipSuccess;
     if (bad_width(d) || (ldx & 3) || (ldy & 3)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(layernorm_bf16_kernel, row_grid(rows), dim3(256), 0, s, x, gamma, beta, y, rows, d, ldx, ldy, eps);
+    return hipGetLastError();
+}
+hipError_t launch_layernorm_fp8(const float* x, const float* gamma, const float* beta, unsigned char* y, float* scale, long rows, int d,
+                                long ldx, long ldy, float eps, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (bad_width(d) || (ldx & 3) || (ldy & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_fp8_kernel, row_grid(rows), dim3(256), 0, s, x, gamma, beta, y, scale, rows, d, ldx, ldy, eps);
+    return hipGetLastError();
+}
+hipError_t launch_quantize_rows_fp8(const unsigned short* x_bf16, const float* x_f32, long ldx, unsigned char* y, long ldy, float* scale,
+                                    long rows, int d, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if ((x_bf16 == nullptr) == (x_f32 == nullptr) || d <= 0 || (d & 7) || d > 4096 || (ldx & 7) || (ldy & 7)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel, row_grid(rows), dim3(256), 0, s, x_bf16, x_f32, ldx, y, ldy, scale, rows, d);
     return hipGetLastError();
 }
 hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s,

@@ -20,15 +20,20 @@
 namespace fern {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef long i64x2 __attribute__((ext_vector_type(2)));
 
-template <int BM, int BN, int WM, int WN, int BKE, int STAGES, int MINW>
+// FP8: the operands are OCP e4m3fn bytes and the MFMA is v_mfma_f32_32x32x16_fp8_fp8 (same rate as bf16, half the bytes):
+// a BKE-element tile row is then BKE bytes, one ds_read_b128 holds the fragments of TWO consecutive MFMA k-steps (low /
+// high 8 bytes), and the tile loop runs half as many iterations for the same K.
+template <int BM, int BN, int WM, int WN, int BKE, int STAGES, int MINW, bool FP8 = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_glds_kernel(GemmParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int ROWS = BM + BN;                        // A rows then W rows
-    constexpr int RB = BKE * 2;                          // bytes per tile row (64 or 128)
+    constexpr int ES = FP8 ? 1 : 2;                      // operand element size (bytes)
+    constexpr int RB = BKE * ES;                         // bytes per tile row (64 or 128)
     constexpr int C4 = RB / 16;                          // 16-byte chunks per tile row
     constexpr int RPP = 64 / C4;                         // tile rows per 1 KiB piece
     constexpr int PIECES = ROWS / RPP;
@@ -65,18 +70,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
         if (trow < BM) {
             int row = bm * BM + trow;
             row = row < p.M ? row : p.M - 1;
-            src[j] = reinterpret_cast<const char*>(p.Ab + (long)row * p.lda) + chunk * 16;
+            src[j] = reinterpret_cast<const char*>(p.Ab) + (long)row * p.lda * ES + chunk * 16;
         } else {
             int row = bn * BN + (trow - BM);
             row = row < p.N ? row : p.N - 1;
-            src[j] = reinterpret_cast<const char*>(p.Wb + (long)row * p.ldw) + chunk * 16;
+            src[j] = reinterpret_cast<const char*>(p.Wb) + (long)row * p.ldw * ES + chunk * 16;
         }
     }
     auto stage = [&](int buf, int k0) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int piece = wave + NW * j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long)k0 * 2),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long)k0 * ES),
                                              (__attribute__((address_space(3))) void*)(smem + buf * TILE + piece * 1024), 16, 0, 0);
         }
     };
@@ -94,18 +99,32 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
         const char* As = smem + buf * TILE;
         const char* Ws = As + BM * RB;
 #pragma unroll
-        for (int kk = 0; kk < BKE / 16; ++kk) {
+        for (int kk = 0; kk < RB / 32; ++kk) {                  // one 16-byte chunk per lane half and step
             const int pc = ((2 * kk + lh) ^ sw) * 16;
             bf16x8 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (wm * WM + i * 32 + l31) * RB + pc);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Ws + (wn * WN + j * 32 + l31) * RB + pc);
+            if (FP8) {
+                // the 16 bytes are k = 32kk + 16h .. +15 of this lane's row: bytes 0-7 feed one 32x32x16 step, 8-15 the next
+                // (both operands use the same k grouping, so the sum is the plain dot product)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const i64x2 a2 = __builtin_bit_cast(i64x2, af[i]), b2 = __builtin_bit_cast(i64x2, bf[j]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a2[e], b2[e], acc[i][j], 0, 0, 0);
+                        }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -186,6 +205,23 @@ static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// fp8 tile family (k tile = 64 elements = 64-byte rows, 2 stages): same block shapes as the bf16 candidates
+static const TileCfgB kCfgsF8[] = {{128, 128, 64}, {256, 128, 64}, {256, 256, 64}, {64, 128, 64}, {128, 64, 64}, {64, 64, 64}};
+constexpr int kNumCfgsF8 = 6;
+static hipError_t launch_cfg_f8(int c, const GemmParams& p, hipStream_t s) {
+    const int nb = ((p.M + kCfgsF8[c].bm - 1) / kCfgsF8[c].bm) * ((p.N + kCfgsF8[c].bn - 1) / kCfgsF8[c].bn);
+    switch (c) {
+        case 0: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 64, 3, 2, true>), dim3(nb), dim3(512), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 64, 64, 64, 3, 1, true>), dim3(nb), dim3(1024), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 64, 64, 32, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+        case 5: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 64, 32, 32, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 static int forced_cfg_b() {
     static int v = [] {
         const char* e = getenv("FERN_GEMM_BF16_CFG");
@@ -197,7 +233,7 @@ static int forced_cfg_b() {
 // Per-shape tile selection, as in gemm.hip: every configuration produces bit-identical results, so the choice is purely a
 // speed choice; each new (M, N, K, epilogue) is timed once on scratch outputs (outside stream capture).
 struct ShapeKeyB {
-    int M, N, K, epi, ob;
+    int M, N, K, epi, ob;      // ob: bit 0 = bf16 output, bit 1 = fp8 operands
     bool operator<(const ShapeKeyB& o) const {
         if (M != o.M) return M < o.M;
         if (N != o.N) return N < o.N;
@@ -220,7 +256,9 @@ static int heuristic_b(int M, int N) {
 }
 
 static int tune_shape_b(const GemmParams& p, hipStream_t s) {
-    const int fallback = heuristic_b(p.M, p.N);
+    const bool f8 = p.fp8 != 0;
+    auto launch = f8 ? launch_cfg_f8 : launch_cfg_b;
+    const int fallback = f8 ? 0 : heuristic_b(p.M, p.N);
     const char* e = getenv("FERN_GEMM_TUNE");
     if (e && e[0] == '0') return fallback;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -234,12 +272,14 @@ static int tune_shape_b(const GemmParams& p, hipStream_t s) {
     q.C = scratch;            // the residual input is only read: tuning has no side effects on the caller's buffers
     int best = fallback;
     float best_ms = 1e30f;
-    static const int cands[] = {0, 5, 9, 10, 11, 12};
-    for (int c : cands) {
-        if (launch_cfg_b(c, q, s) != hipSuccess) continue;                 // warm
+    static const int cands_b[] = {0, 5, 9, 10, 11, 12};
+    static const int cands_f8[] = {0, 1, 2, 3, 4, 5};
+    for (int ci = 0; ci < 6; ++ci) {
+        const int c = f8 ? cands_f8[ci] : cands_b[ci];
+        if (launch(c, q, s) != hipSuccess) continue;                       // warm
         (void)hipEventRecord(e0, s);
-        (void)launch_cfg_b(c, q, s);
-        (void)launch_cfg_b(c, q, s);
+        (void)launch(c, q, s);
+        (void)launch(c, q, s);
         (void)hipEventRecord(e1, s);
         if (hipEventSynchronize(e1) != hipSuccess) continue;
         float ms = 0.f;
@@ -254,8 +294,25 @@ static int tune_shape_b(const GemmParams& p, hipStream_t s) {
 
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
-    if (p.K <= 0 || (p.K % 32) != 0 || (p.lda & 7) || (p.ldw & 7) || p.aload != ALOAD_PLAIN || epi_is_reduce(p.epi)) return hipErrorInvalidValue;
+    const int kq = p.fp8 ? 64 : 32, aq = p.fp8 ? 15 : 7;
+    if (p.K <= 0 || (p.K % kq) != 0 || (p.lda & aq) || (p.ldw & aq) || p.aload != ALOAD_PLAIN || epi_is_reduce(p.epi)) return hipErrorInvalidValue;
     if (!p.Ab || !p.Wb || ((uintptr_t)p.Ab & 15) || ((uintptr_t)p.Wb & 15)) return hipErrorInvalidValue;
+    if ((p.scale_a == nullptr) != (p.scale_w == nullptr)) return hipErrorInvalidValue;
+    if (p.fp8) {
+        static int forced = [] { const char* e = getenv("FERN_GEMM_FP8_CFG"); return e ? atoi(e) : -1; }();
+        int c = forced;
+        if (c < 0 || c >= kNumCfgsF8) {
+            c = 0;
+            if (2.0 * p.M * (double)p.N * p.K >= 2.5e8) {
+                const ShapeKeyB key{p.M, p.N, p.K, p.epi, p.out_bf16 | 2};
+                std::lock_guard<std::mutex> lock(g_tuned_b_mu);
+                auto it = g_tuned_b.find(key);
+                if (it == g_tuned_b.end()) it = g_tuned_b.emplace(key, tune_shape_b(p, s)).first;
+                c = it->second;
+            }
+        }
+        return launch_cfg_f8(c, p, s);
+    }
     int c = forced_cfg_b();
     if (c < 0 || c >= kNumCfgsB || p.K % kCfgsB[c].bk) {
         if (2.0 * p.M * (double)p.N * p.K >= 2.5e8) {

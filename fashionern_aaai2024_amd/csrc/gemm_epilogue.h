@@ -28,7 +28,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // Plain (element-wise) epilogue of one epilogue kind: the kind is a template parameter so that the switch is taken once per
 // kernel, not once per element, and the tile loops stay small enough to unroll fully (register-indexed accumulators).
 // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-template <int EPI, bool OUT_BF16, int TM, int TN>
+template <int EPI, bool OUT_BF16, bool SCALED, int TM, int TN>
 __device__ __forceinline__ void plain_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int row_w, int col_w, int l31, int lh) {
     constexpr bool resid = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_RELU;
     // An element's address = (wave-uniform tile / register-row part, kept in SGPRs) + (lane part: 4 * half rows + column):
@@ -43,6 +43,8 @@ __device__ __forceinline__ void plain_epilogue(const GemmParams& p, f32x16 (&acc
             const int col = col0 + l31;
             if (col < p.N) {
                 const float bia = p.bias ? p.bias[col] : 0.0f;
+                const float qw = SCALED ? p.scale_w[col] : 1.0f;          // fp8 operands: per-output-channel weight scale
+                const float* qa = SCALED ? p.scale_a + row0 : nullptr;    // ... and per-row activation scales
                 float sc = 1.0f, sh = 0.0f;
                 if (EPI == EPI_COLAFFINE_TANH) { sc = p.aux0[col]; sh = p.aux1[col]; }
                 if (EPI == EPI_PATCH_EMBED) {
@@ -74,7 +76,7 @@ __device__ __forceinline__ void plain_epilogue(const GemmParams& p, f32x16 (&acc
                     for (int r = 0; r < 16; ++r) {
                         const int ru = (r & 3) + 8 * (r >> 2);
                         if (row0 + ru + lrow < p.M) {
-                            float v = acc[i][j][r] + bia;
+                            float v = SCALED ? acc[i][j][r] * (qa[ru + lrow] * qw) + bia : acc[i][j][r] + bia;
                             if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
                             else if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.0f);
                             else if (EPI == EPI_BIAS_RESIDUAL) v += add[r];
@@ -99,22 +101,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     const int row_w = bm * BM + wm * WM;
     const int col_w = bn * BN + wn * WN;
     if (!epi_is_reduce(p.epi)) {
+        if (ALLOW_BF16_OUT && p.scale_a) {      // fp8 operands: scales folded back here; bias / GELU / residual forms
+            if (p.out_bf16) {
+                if (p.epi == EPI_BIAS_GELU) plain_epilogue<EPI_BIAS_GELU, true, true>(p, acc, row_w, col_w, l31, lh);
+                else plain_epilogue<EPI_BIAS, true, true>(p, acc, row_w, col_w, l31, lh);
+            } else {
+                if (p.epi == EPI_BIAS_RESIDUAL) plain_epilogue<EPI_BIAS_RESIDUAL, false, true>(p, acc, row_w, col_w, l31, lh);
+                else if (p.epi == EPI_BIAS_GELU) plain_epilogue<EPI_BIAS_GELU, false, true>(p, acc, row_w, col_w, l31, lh);
+                else plain_epilogue<EPI_BIAS, false, true>(p, acc, row_w, col_w, l31, lh);
+            }
+            return;
+        }
         if (ALLOW_BF16_OUT && p.out_bf16) {
             switch (p.epi) {      // bf16 outputs feed the next bf16 GEMM: bias (+ GELU / ReLU) only
-                case EPI_BIAS_GELU: plain_epilogue<EPI_BIAS_GELU, true>(p, acc, row_w, col_w, l31, lh); break;
-                case EPI_BIAS_RELU: plain_epilogue<EPI_BIAS_RELU, true>(p, acc, row_w, col_w, l31, lh); break;
-                default: plain_epilogue<EPI_BIAS, true>(p, acc, row_w, col_w, l31, lh); break;
+                case EPI_BIAS_GELU: plain_epilogue<EPI_BIAS_GELU, true, false>(p, acc, row_w, col_w, l31, lh); break;
+                case EPI_BIAS_RELU: plain_epilogue<EPI_BIAS_RELU, true, false>(p, acc, row_w, col_w, l31, lh); break;
+                default: plain_epilogue<EPI_BIAS, true, false>(p, acc, row_w, col_w, l31, lh); break;
             }
             return;
         }
         switch (p.epi) {
-            case EPI_BIAS_GELU: plain_epilogue<EPI_BIAS_GELU, false>(p, acc, row_w, col_w, l31, lh); break;
-            case EPI_BIAS_RELU: plain_epilogue<EPI_BIAS_RELU, false>(p, acc, row_w, col_w, l31, lh); break;
-            case EPI_BIAS_RESIDUAL: plain_epilogue<EPI_BIAS_RESIDUAL, false>(p, acc, row_w, col_w, l31, lh); break;
-            case EPI_BIAS_RESIDUAL_RELU: plain_epilogue<EPI_BIAS_RESIDUAL_RELU, false>(p, acc, row_w, col_w, l31, lh); break;
-            case EPI_COLAFFINE_TANH: plain_epilogue<EPI_COLAFFINE_TANH, false>(p, acc, row_w, col_w, l31, lh); break;
-            case EPI_PATCH_EMBED: plain_epilogue<EPI_PATCH_EMBED, false>(p, acc, row_w, col_w, l31, lh); break;
-            default: plain_epilogue<EPI_BIAS, false>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_BIAS_GELU: plain_epilogue<EPI_BIAS_GELU, false, false>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_BIAS_RELU: plain_epilogue<EPI_BIAS_RELU, false, false>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_BIAS_RESIDUAL: plain_epilogue<EPI_BIAS_RESIDUAL, false, false>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_BIAS_RESIDUAL_RELU: plain_epilogue<EPI_BIAS_RESIDUAL_RELU, false, false>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_COLAFFINE_TANH: plain_epilogue<EPI_COLAFFINE_TANH, false, false>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_PATCH_EMBED: plain_epilogue<EPI_PATCH_EMBED, false, false>(p, acc, row_w, col_w, l31, lh); break;
+            default: plain_epilogue<EPI_BIAS, false, false>(p, acc, row_w, col_w, l31, lh); break;
         }
     } else {
         // reduce epilogues: one partial sum per (row, column block); fixed summation order => deterministic

@@ -46,6 +46,11 @@ struct GemmParams {
     const unsigned short* Ab;
     const unsigned short* Wb;
     int out_bf16;                 // plain epilogues: store C as bf16 (ldc in elements) instead of fp32
+    // fp8 (OCP e4m3fn) operand form: Ab / Wb point at fp8 bytes (strides in elements = bytes), K % 64 == 0; the quantisation
+    // scales are folded back in the epilogue: C = acc * scale_a[row] * scale_w[col] (+ bias ...)
+    int fp8;
+    const float* scale_a;         // [M] per-row (token) activation scales, or null
+    const float* scale_w;         // [N] per-output-channel weight scales, or null
 };
 // Number of column blocks the reduce epilogues write per row (depends on the tile chosen for this shape).
 int gemm_num_col_blocks(int M, int N, int K);
@@ -54,6 +59,12 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s);
 
 #ifdef __HIPCC__
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+// four floats -> four OCP e4m3fn bytes (v_cvt_pk_fp8_f32: round to nearest even; inputs are pre-scaled into [-448, 448])
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+}
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {   // round to nearest even (finite inputs)
     unsigned u = __float_as_uint(f);
     u += 0x7fffu + ((u >> 16) & 1u);
@@ -82,6 +93,12 @@ hipError_t launch_layernorm(const float* x, const float* res, const float* gamma
 // same statistics, output rounded to bf16 (operand of the bf16 encoder GEMMs)
 hipError_t launch_layernorm_bf16(const float* x, const float* gamma, const float* beta, unsigned short* y, long rows, int d, long ldx,
                                  long ldy, float eps, hipStream_t s);
+// fp8 (e4m3fn) quantisation with one scale per row: scale[r] = max|row| / 448 (1 for an all-zero row), y = fp8(x / scale[r]).
+// LayerNorm fused form, bf16-row form (attention / GELU outputs), fp32-row form (weights, [N, K]: one scale per output channel).
+hipError_t launch_layernorm_fp8(const float* x, const float* gamma, const float* beta, unsigned char* y, float* scale, long rows, int d,
+                                long ldx, long ldy, float eps, hipStream_t s);
+hipError_t launch_quantize_rows_fp8(const unsigned short* x_bf16, const float* x_f32, long ldx, unsigned char* y, long ldy, float* scale,
+                                    long rows, int d, hipStream_t s);
 // mode 0: x / max(||x||, eps) (F.normalize); mode 1: x / (||x|| + eps) (VisualSR.l2norm)
 hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s,
                          const float* x2 = nullptr);   // x2: optional addend (normalize(x + x2))

@@ -20,8 +20,8 @@ COMBINER_TARGET, COMBINER_DVR_GLOBAL, COMBINER_DVR_LOCAL, COMBINER_DVR_FINAL = 0
 SR_TARGET, SR_DVR = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
 PART_DVR, PART_TARGET_SR, PART_TARGET_COMBINER, PART_ALL = 1, 2, 4, 7
-PREC_FP32, PREC_BF16 = 0, 1
-_PREC_NAMES = {"fp32": PREC_FP32, "bf16": PREC_BF16}
+PREC_FP32, PREC_BF16, PREC_FP8 = 0, 1, 2
+_PREC_NAMES = {"fp32": PREC_FP32, "bf16": PREC_BF16, "fp8": PREC_FP8}
 PATCH_NUM = 13
 
 
@@ -306,6 +306,26 @@ class FernEngine:
         out = torch.empty(m, n, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=self.device)
         _lib.check(self.lib.fern_gemm_bf16(self._h, _ptr(a), k, _ptr(w), k, _ptr(bias), _ptr(residual), _ptr(out), n, m, n, k,
                                            int(epilogue), int(bool(out_bf16)), _stream()), "fern_gemm_bf16")
+        return out
+
+    def quantize_rows_fp8(self, x):
+        """[R,C] fp32 or bf16 -> (fp8 e4m3fn bytes [R,C] as uint8, per-row scales [R]); scale = max|row| / 448."""
+        x = x.to(self.device).contiguous() if x.dtype == torch.bfloat16 else self._f32(x)
+        rows, d = x.shape
+        y = torch.empty(rows, d, dtype=torch.uint8, device=self.device)
+        sc = self._empty(rows)
+        _lib.check(self.lib.fern_quantize_rows_fp8(self._h, _ptr(x), int(x.dtype == torch.bfloat16), d, _ptr(y), d, _ptr(sc), rows, d,
+                                                   _stream()), "fern_quantize_rows_fp8")
+        return y, sc
+
+    def gemm_fp8(self, a8, sa, w8, sw, bias=None, residual=None, epilogue=EPI_BIAS, out_bf16=False) -> torch.Tensor:
+        m, k = a8.shape
+        n = w8.shape[0]
+        bias = None if bias is None else self._f32(bias, (n,))
+        residual = None if residual is None else self._f32(residual, (m, n))
+        out = torch.empty(m, n, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=self.device)
+        _lib.check(self.lib.fern_gemm_fp8(self._h, _ptr(a8), k, _ptr(sa), _ptr(w8), k, _ptr(sw), _ptr(bias), _ptr(residual), _ptr(out), n,
+                                          m, n, k, int(epilogue), int(bool(out_bf16)), _stream()), "fern_gemm_fp8")
         return out
 
     def layernorm(self, x, gamma, beta, eps: float, residual=None) -> torch.Tensor:

@@ -96,8 +96,8 @@ def main(kind: str) -> None:
     p.add_argument("--synthetic-gallery", default=2000, type=int)
     p.add_argument("--synthetic-queries", default=256, type=int)
     p.add_argument("--seed", default=42, type=int)
-    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                   help="encoder operand precision: fp32 = the reference's arithmetic; bf16 = perf mode (ViT / text towers)")
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp8"],
+                   help="encoder operand precision: fp32 = the reference's arithmetic; bf16 / fp8 = perf modes (ViT / text towers)")
     args = p.parse_args()
     setup_seed(args.seed)
     device = torch.device("cuda")

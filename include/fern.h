@@ -73,7 +73,12 @@ typedef enum {
  * the batch size, so results remain batch-invariant. */
 typedef enum {
     FERN_PREC_FP32 = 0,
-    FERN_PREC_BF16 = 1
+    FERN_PREC_BF16 = 1,
+    /* BASELINE.json config 5 ("fp8 MFMA encoder path"): as BF16, but the four token-level GEMMs of a block (and the last ViT
+     * block's K/V projection) take OCP e4m3fn operands on v_mfma_f32_32x32x16_fp8_fp8: one dynamic scale per token row
+     * (max|row| / 448, computed where the row is produced) and one static scale per output channel of the weight, both
+     * folded back in the fp32 epilogue; attention stays in the bf16 operand form.  Needs tower / MLP widths % 64 == 0. */
+    FERN_PREC_FP8 = 2
 } fern_precision;
 
 typedef enum {
@@ -113,6 +118,9 @@ typedef struct {
     double sweep_ms;       /* similarity sweep (scores GEMM inside fern_sim_topk) */
     double sweep_bytes;    /* algorithmic bytes of those sweeps: N*D*4 + B*D*4 + B*N*4 */
     int64_t sweep_launches;
+    double gemm_fp8_ms;    /* fp8-operand GEMM launches (FERN_PREC_FP8, fern_gemm_fp8): not included in gemm_* / gemm_bf16_* */
+    double gemm_fp8_flops;
+    int64_t gemm_fp8_launches;
     double gemm_bf16_ms;   /* bf16-operand GEMM launches (FERN_PREC_BF16 encoder blocks, fern_gemm_bf16): NOT included in gemm_* */
     double gemm_bf16_flops;
     int64_t gemm_bf16_launches;
@@ -230,6 +238,16 @@ FERN_API int fern_gemm(fern_ctx* ctx, const float* A, int64_t lda, const float* 
 FERN_API int fern_gemm_bf16(fern_ctx* ctx, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias,
                    const float* residual, void* C, int64_t ldc, int M, int N, int K, int epilogue, int out_bf16,
                    void* stream);
+/* fp8 (OCP e4m3fn) operand form: A [M,lda] / W [N,ldw] bytes with per-row scales (fern_quantize_rows_fp8 produces both:
+ * scale[r] = max|row r| / 448, or 1 for a zero row; y = fp8(x / scale[r]), round to nearest even);
+ * C = (sum_k A8 W8) * scale_a[row] * scale_w[col] + bias (+ GELU | + residual), fp32 accumulation on
+ * v_mfma_f32_32x32x16_fp8_fp8.  K % 64 == 0, lda/ldw % 16 == 0; `x` of the quantiser is bf16 when x_is_bf16 else fp32,
+ * d % 8 == 0, d <= 4096. */
+FERN_API int fern_quantize_rows_fp8(fern_ctx* ctx, const void* x, int x_is_bf16, int64_t ldx, uint8_t* y, int64_t ldy, float* scale,
+                           int64_t rows, int d, void* stream);
+FERN_API int fern_gemm_fp8(fern_ctx* ctx, const uint8_t* A, int64_t lda, const float* scale_a, const uint8_t* W, int64_t ldw,
+                  const float* scale_w, const float* bias, const float* residual, void* C, int64_t ldc, int M, int N, int K,
+                  int epilogue, int out_bf16, void* stream);
 /* y = LayerNorm(x (+ residual)) * gamma + beta, rows of width d */
 FERN_API int fern_layernorm(fern_ctx* ctx, const float* x, const float* residual, const float* gamma,
                    const float* beta, float* y, int64_t rows, int d, float eps, void* stream);

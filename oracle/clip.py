@@ -26,29 +26,50 @@ def _ln(sd, prefix, x):
     return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
 
 
-def _r(x, bf16):
-    """Operand rounding of the product's "bf16" encoder precision (include/fern.h:fern_precision): round to nearest even
+def _r(x, reduced):
+    """Operand rounding of the product's reduced encoder precisions (include/fern.h:fern_precision): round to nearest even
     to bfloat16, carried on as fp32 so that products are exact and sums accumulate in fp32, like the MFMA."""
-    return x.bfloat16().float() if bf16 else x
+    return x.bfloat16().float() if reduced else x
 
 
-def _linear(x, w, b, bf16):
-    return F.linear(_r(x, bf16), _r(w, bf16), b)
+_INV448 = torch.tensor(1.0 / 448.0, dtype=torch.float32)
 
 
-def _attention(sd, prefix, x, heads, causal, bf16=False, q_rows=None):
+def _q8(x):
+    """Per-row fp8 quantisation as the product does it (csrc/elem.hip:quantize_rows_fp8_kernel): scale = max|row| * (1/448)
+    (1 for a zero row), q = e4m3fn(x * (1 / scale)), round to nearest even.  Returns (q as fp32, scale)."""
+    am = x.abs().amax(dim=-1, keepdim=True)
+    sc = torch.where(am > 0, am * _INV448, torch.ones_like(am))
+    q = (x * (1.0 / sc)).to(torch.float8_e4m3fn).float()
+    return q, sc
+
+
+def _linear(x, w, b, prec):
+    """prec None / "fp32": plain; "bf16": bf16-rounded operands; "fp8": e4m3fn operands with per-token and per-output-channel
+    scales folded back after the fp32-accumulated product (the product's epilogue: acc * (sa * sw) + bias)."""
+    if prec == "fp8":
+        qa, sa = _q8(x)
+        qw, sw = _q8(w)
+        y = (qa @ qw.transpose(-1, -2)) * (sa * sw.transpose(-1, -2))
+        return y if b is None else y + b
+    return F.linear(_r(x, prec == "bf16"), _r(w, prec == "bf16"), b)
+
+
+def _attention(sd, prefix, x, heads, causal, prec=None, q_rows=None):
     """modeling_clip.py:272-336: q scaled by hd**-0.5 before QK^T, additive causal mask, softmax, PV.
 
-    ``bf16``: the packed in-projection and the out-projection take bf16 operands.  ``q_rows`` (last ViT block of the
-    product: only the class row is consumed): queries, out-projection and everything after them are evaluated for those
-    rows only and in fp32; K/V still come from every token (bf16 operands when ``bf16``)."""
+    ``prec`` "bf16" / "fp8": the packed in-projection and the out-projection take reduced-precision operands and the
+    attention itself runs in the product's bf16 operand form.  ``q_rows`` (last ViT block of the product: only the class row
+    is consumed): queries, out-projection and everything after them are evaluated for those rows only and in fp32; K/V
+    still come from every token (reduced-precision operands, fp32 result)."""
     b, s, w = x.shape
     hd = w // heads
+    reduced = prec in ("bf16", "fp8")
     wi, bi = sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"]
     if q_rows is None:
-        qkv = _r(_linear(x, wi, bi, bf16), bf16)          # bf16 precision: the packed projection is STORED as bf16
+        qkv = _r(_linear(x, wi, bi, prec), reduced)       # reduced precision: the packed projection is STORED as bf16
         q, k, v = qkv.split(w, dim=-1)
-        if bf16:
+        if reduced:
             # bf16 operand attention of the product (include/fern.h:fern_attention_bf16): fp32 scores from bf16 q, k, scaled
             # after the product; un-normalised weights rounded to bf16 for P V, normaliser from the un-rounded weights;
             # output stored as bf16.  (The product rounds exp(s - running max) tile by tile; here the row max is used, which
@@ -62,9 +83,9 @@ def _attention(sd, prefix, x, heads, causal, bf16=False, q_rows=None):
             e = torch.exp(att - att.max(dim=-1, keepdim=True).values)
             o = (_r(e, True) @ v) / e.sum(dim=-1, keepdim=True)
             o = _r(o.transpose(1, 2).reshape(b, s, w), True)
-            return _linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"], bf16)
+            return _linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"], prec)
     else:
-        k, v = _linear(x, wi[w:], bi[w:], bf16).split(w, dim=-1)
+        k, v = _linear(x, wi[w:], bi[w:], prec).split(w, dim=-1)
         q = F.linear(x[:, q_rows], wi[:w], bi[:w])
         s_q = q.shape[1]
         q = q.view(b, s_q, heads, hd).transpose(1, 2) * (hd ** -0.5)
@@ -80,21 +101,22 @@ def _attention(sd, prefix, x, heads, causal, bf16=False, q_rows=None):
         att = att + torch.full((s, s), float("-inf")).triu(1)
     att = torch.softmax(att, dim=-1)
     o = (att @ v).transpose(1, 2).reshape(b, s, w)
-    return _linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"], bf16)
+    return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
 
 
-def _block(sd, prefix, x, heads, causal, bf16=False):
+def _block(sd, prefix, x, heads, causal, prec=None):
     """Pre-LN residual block, modeling_clip.py:354-401; MLP :339-351 with exact GELU."""
-    x = x + _attention(sd, prefix + ".attn", _ln(sd, prefix + ".ln_1", x), heads, causal, bf16)
-    h = F.gelu(_linear(_ln(sd, prefix + ".ln_2", x), sd[prefix + ".mlp.c_fc.weight"], sd[prefix + ".mlp.c_fc.bias"], bf16))
-    return x + _linear(h, sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"], bf16)
+    reduced = prec in ("bf16", "fp8")
+    x = x + _attention(sd, prefix + ".attn", _ln(sd, prefix + ".ln_1", x), heads, causal, prec)
+    h = F.gelu(_linear(_ln(sd, prefix + ".ln_2", x), sd[prefix + ".mlp.c_fc.weight"], sd[prefix + ".mlp.c_fc.bias"], prec))
+    return x + _linear(_r(h, reduced), sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"], prec)   # h is stored as bf16
 
 
-def _block_cls(sd, prefix, x, heads, bf16):
-    """The last ViT block as the product evaluates it under bf16 precision: same arithmetic as ``_block`` restricted to the
-    class row (the only row ln_post reads, modeling_clip.py:876-877) with fp32 operands, except the K/V projection of all
-    tokens, which takes bf16 operands."""
-    c = x[:, :1] + _attention(sd, prefix + ".attn", _ln(sd, prefix + ".ln_1", x), heads, False, bf16, q_rows=slice(0, 1))
+def _block_cls(sd, prefix, x, heads, prec):
+    """The last ViT block as the product evaluates it under a reduced precision: same arithmetic as ``_block`` restricted
+    to the class row (the only row ln_post reads, modeling_clip.py:876-877) with fp32 operands, except the K/V projection
+    of all tokens, which takes the reduced-precision operands."""
+    c = x[:, :1] + _attention(sd, prefix + ".attn", _ln(sd, prefix + ".ln_1", x), heads, False, prec, q_rows=slice(0, 1))
     h = F.gelu(F.linear(_ln(sd, prefix + ".ln_2", c), sd[prefix + ".mlp.c_fc.weight"], sd[prefix + ".mlp.c_fc.bias"]))
     return c + F.linear(h, sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"])
 
@@ -145,12 +167,16 @@ def encode_image_resnet(sd, cfg, images):
 def encode_image(sd, cfg, images, precision="fp32"):
     """[b,3,H,W] f32 -> [b,embed_dim] un-normalised (call site utils/utils.py:64).
 
-    ``precision="bf16"`` restates the product's perf mode (no reference counterpart; include/fern.h:fern_precision): the
-    same arithmetic with the operands of the token-level block GEMMs rounded to bfloat16."""
-    bf16 = precision == "bf16"
+    ``precision="bf16"`` / ``"fp8"`` restate the product's reduced-precision modes (no reference counterpart;
+    include/fern.h:fern_precision): the same arithmetic with the operands of the token-level block GEMMs rounded to
+    bfloat16, or quantised to e4m3fn with per-token / per-channel scales."""
+    if precision not in ("fp32", "bf16", "fp8"):
+        raise ValueError(precision)
+    bf16 = precision != "fp32"
+    prec = None if precision == "fp32" else precision
     if getattr(cfg, "v_arch", "vit") == "resnet":
         if bf16:
-            raise ValueError("bf16 precision is defined for the transformer towers only")
+            raise ValueError("reduced precisions are defined for the transformer towers only")
         return encode_image_resnet(sd, cfg, images)
     w = sd["visual.conv1.weight"]
     x = F.conv2d(images, w, stride=cfg.patch_size)                      # modeling_clip.py:180-196
@@ -159,9 +185,9 @@ def encode_image(sd, cfg, images, precision="fp32"):
     x = torch.cat((cls, x), dim=1) + sd["visual.positional_embedding"]  # :197-200
     x = _ln(sd, "visual.ln_pre", x)                                     # :839,866
     for i in range(cfg.v_layers - (1 if bf16 else 0)):
-        x = _block(sd, f"visual.transformer.resblocks.{i}", x, cfg.v_heads, causal=False, bf16=bf16)
+        x = _block(sd, f"visual.transformer.resblocks.{i}", x, cfg.v_heads, causal=False, prec=prec)
     if bf16:
-        x = _block_cls(sd, f"visual.transformer.resblocks.{cfg.v_layers - 1}", x, cfg.v_heads, bf16)
+        x = _block_cls(sd, f"visual.transformer.resblocks.{cfg.v_layers - 1}", x, cfg.v_heads, prec)
     pooled = _ln(sd, "visual.ln_post", x[:, 0])                         # :876-877
     return pooled @ sd["visual.proj"]                                   # :977,1076 (bias-free)
 
@@ -169,7 +195,7 @@ def encode_image(sd, cfg, images, precision="fp32"):
 def text_hidden(sd, cfg, text, precision="fp32"):
     x = sd["token_embedding.weight"][text] + sd["positional_embedding"][: text.shape[1]]   # :204-232
     for i in range(cfg.t_layers):
-        x = _block(sd, f"transformer.resblocks.{i}", x, cfg.t_heads, causal=True, bf16=precision == "bf16")
+        x = _block(sd, f"transformer.resblocks.{i}", x, cfg.t_heads, causal=True, prec=None if precision == "fp32" else precision)
     return _ln(sd, "ln_final", x)                                       # :750
 
 

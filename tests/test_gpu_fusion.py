@@ -246,3 +246,55 @@ def test_clip_towers_bf16_precision(name, n):
     assert cos_err(got, ref_f) < 1e-3 and cos_err(g, rg_f) < 1e-3
     assert cos_err(got, ref_f) > 0 and not torch.equal(got, fp32_img)   # the mode really is a different precision
     eng.close()
+
+
+@pytest.mark.parametrize("name,n", [("tiny-hd64", 4), ("ViT-B-16", 3)])
+def test_clip_towers_fp8_precision(name, n):
+    """BASELINE config 5's "fp8 MFMA encoder path" (fern_set_precision(FP8)): e4m3fn operands with per-token / per-channel
+    scales on the token-level block GEMMs.  The kernels themselves are pinned in test_gpu_kernels.py (bit-exact quantiser,
+    GEMM against exact arithmetic on the same bytes).  End to end: (1) vs the oracle restating the same quantisation points
+    -- tiny arithmetic differences move values across e4m3 rounding boundaries (3 mantissa bits: one flipped element is a
+    6 % change of it) and the flips compound over 11 layers, so the agreement is loose (measured 1.4e-4 ... 1.3e-3 in
+    cosine) but the product must sit closer to its restatement than to fp32; (2) vs the fp32 oracle: the cost of the mode,
+    reported not hidden -- cosine error of the features 1.3e-3 ... 4.2e-3 (bf16 mode: 1e-5)."""
+    cfg = synth.CLIP_CONFIGS[name]
+    sd_np = synth.clip_state_dict(cfg, seed=11)
+    sd = ofusion.as_torch(sd_np)
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(sd_np)
+    eng.finalize_clip(cfg)
+    imgs = _t(synth.images(n, cfg))
+    toks = _t(synth.captions(n, cfg))
+    fp32_img = eng.encode_image(imgs)
+    eng.set_precision("fp8")
+    assert eng.precision == "fp8"
+    got = eng.encode_image(imgs)
+    g, s = eng.encode_text(toks)
+    assert torch.equal(eng.encode_image(imgs[1:2]), got[1:2])          # per-token scales: still batch-invariant
+    eng.set_precision("fp32")
+    assert torch.equal(eng.encode_image(imgs), fp32_img)
+
+    ref_q = oclip.encode_image(sd, cfg, imgs, precision="fp8")
+    ref_f = oclip.encode_image(sd, cfg, imgs)
+    rg_q, _ = oclip.encode_text(sd, cfg, toks, precision="fp8")
+    rg_f, _ = oclip.encode_text(sd, cfg, toks)
+
+    def cos_err(a, b):
+        return (1 - F.cosine_similarity(a.cpu().double(), b.double(), dim=-1)).abs().max().item()
+
+    assert cos_err(got, ref_q) < 2e-3 and cos_err(g, rg_q) < 2e-3      # same quantisation points
+    assert cos_err(got, ref_q) < cos_err(got, ref_f) and cos_err(g, rg_q) < cos_err(g, rg_f)
+    assert cos_err(got, ref_f) < 1e-2 and cos_err(g, rg_f) < 1e-2      # the price of fp8, well above bf16's 1e-5
+    assert cos_err(got, ref_f) > 1e-5
+    eng.close()
+
+
+def test_fp8_precision_needs_widths_that_are_multiples_of_64():
+    cfg = synth.CLIP_CONFIGS["tiny"]
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(synth.clip_state_dict(cfg, seed=1))
+    eng.finalize_clip(cfg)
+    if cfg.v_width % 64 or cfg.t_width % 64 or cfg.v_mlp % 64 or cfg.t_mlp % 64:
+        with pytest.raises(FernError, match="multiples of 64"):
+            eng.set_precision("fp8")
+    eng.close()

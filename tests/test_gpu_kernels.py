@@ -275,3 +275,59 @@ def test_attention_bf16(engine, b, heads, hd, sq, sk, causal):
     # error budget: weights rounded to bf16 (2^-9 relative each, averaged over the keys) + one bf16 rounding of the output
     err = (got.float().cpu().double() - ref).abs().max().item()
     assert err < 2 ** -7 * max(1.0, ref.abs().max().item()), err
+
+
+def _q8_ref(x):
+    """torch statement of the product's per-row e4m3fn quantiser (same operation order: scale = max * (1/448), q = x * (1/scale))."""
+    am = x.abs().amax(dim=-1, keepdim=True)
+    sc = torch.where(am > 0, am * torch.tensor(1.0 / 448.0, dtype=torch.float32), torch.ones_like(am))
+    return (x * (1.0 / sc)).to(torch.float8_e4m3fn), sc.squeeze(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,d,bf16", [(5, 64, False), (197, 768, True), (64, 3072, True), (33, 4096, False), (1000, 512, True)])
+def test_quantize_rows_fp8_is_bit_exact(engine, rows, d, bf16):
+    g = torch.Generator().manual_seed(rows + d)
+    x = torch.randn(rows, d, generator=g) * torch.logspace(-3, 3, rows).unsqueeze(1)     # rows of very different magnitude
+    x[rows // 2] = 0                                                                     # an all-zero row keeps scale 1
+    if bf16:
+        x = x.bfloat16()
+    y, sc = engine.quantize_rows_fp8(x.cuda())
+    q_ref, sc_ref = _q8_ref(x.float())
+    assert torch.equal(sc.cpu(), sc_ref)
+    assert torch.equal(y.cpu(), q_ref.view(torch.uint8))          # same e4m3fn bytes as torch's round-to-nearest-even cast
+    assert sc[rows // 2].item() == 1.0 and int(y[rows // 2].max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(64, 128, 64), (197, 384, 192), (1000, 520, 256), (4096, 768, 768)])
+@pytest.mark.parametrize("epi,out_bf16", [(0, False), (0, True), (1, True), (3, False)])
+def test_gemm_fp8(engine, m, n, k, epi, out_bf16):
+    """fp8-operand GEMM against fp64 math on the SAME quantised operands and scales."""
+    g = torch.Generator().manual_seed(m + n + k + epi)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * k ** -0.5
+    b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g)
+    a8, sa = engine.quantize_rows_fp8(a)
+    w8, sw = engine.quantize_rows_fp8(w)
+    qa, qw = a8.cpu().view(torch.float8_e4m3fn).double(), w8.cpu().view(torch.float8_e4m3fn).double()
+    ref = (qa @ qw.T) * (sa.cpu().double().unsqueeze(1) * sw.cpu().double().unsqueeze(0)) + b.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 3:
+        ref = ref + r.double()
+    got = engine.gemm_fp8(a8, sa, w8, sw, b, residual=r if epi == 3 else None, epilogue=epi, out_bf16=out_bf16)
+    if out_bf16:
+        assert got.dtype == torch.bfloat16 and torch.allclose(got.float().cpu().double(), ref, rtol=2 ** -7, atol=1e-3)
+    else:
+        # v_mfma_f32_32x32x16_fp8_fp8 is exact on integer data (checked below) but does not sum its 16 products as a plain
+        # fp32 FMA chain: on random operands it sits ~1.4e-5 (rms, relative) from the exact sum, independent of K
+        assert (got.cpu().double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    if epi == 0 and not out_bf16:
+        ai = torch.randint(-4, 5, (m, k), generator=g).float()
+        wi = torch.randint(-4, 5, (n, k), generator=g).float()
+        ones_m, ones_n = torch.ones(m, device="cuda"), torch.ones(n, device="cuda")
+        gi = engine.gemm_fp8(ai.to(torch.float8_e4m3fn).view(torch.uint8).cuda(), ones_m, wi.to(torch.float8_e4m3fn).view(torch.uint8).cuda(),
+                             ones_n, None)
+        assert torch.equal(gi.cpu(), ai @ wi.T)

@@ -178,4 +178,4 @@ def test_precision_option_of_the_clip_surface_and_oracle_bf16_restatement():
     with pytest.raises(ValueError):
         create_model("tiny-resnet", device="cpu", seed=1, engine=OracleEngine(), precision="bf16")
     with pytest.raises(ValueError):
-        clip.engine.set_precision("fp8")
+        clip.engine.set_precision("int4")
