@@ -250,3 +250,36 @@ def test_bf16_sweep_exact_ties_and_one_million_rows():
     rows = bb[i_c[:4].flatten().long().cuda()].float().cpu().view(4, 50, 512)
     got = (qq[:4].bfloat16().float().cpu().unsqueeze(1) * rows).sum(-1)
     assert (got - s_c[:4]).abs().max().item() < 2e-6
+
+
+def test_c5_fp8_encoder_with_bf16_similarity_end_to_end():
+    """BASELINE configs[4] as one path on one GPU's share: ViT-B/16 towers in fp8 mode -> fp32 fusion -> 1M-row bf16 gallery
+    sweep + top-50 (the 8-GPU form shards the gallery build and replicates this step; tests/test_distributed_cpu.py).
+    The ranking is checked exactly against the oracle ON THE FEATURES THE fp8 ENCODER PRODUCED (same bf16 rounding of both
+    operands); the encoder's own deviation is what test_clip_towers_fp8_precision bounds."""
+    cfg = synth.CLIP_CONFIGS["ViT-B-16"]
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(synth.clip_state_dict(cfg, seed=3))
+    eng.finalize_clip(cfg)
+    eng.load_tensors(synth.fusion_state_dict(512, seed=21))
+    eng.finalize_fusion(512)
+    eng.set_precision("fp8")
+    b = 8
+    imgs = torch.from_numpy(synth.images(b, cfg, 5))
+    toks = torch.from_numpy(synth.captions(b, cfg, 5))
+    loc = torch.from_numpy(synth.local_feats(b, 512, 5))
+    ref = eng.encode_image(imgs)
+    tg, ts = eng.encode_text(toks)
+    fused = eng.dvr_fuse(ref, loc, tg, ts)
+    assert torch.isfinite(fused).all() and (fused.norm(dim=-1) - 1).abs().max().item() < 1e-5
+    n = 1_000_000
+    g = torch.from_numpy(synth.unit_rows(125_000, 512, tag="c5e")).cuda().repeat(8, 1)
+    g[125_000:] += torch.linspace(0, 1e-3, n - 125_000, device="cuda")[:, None]
+    gb = eng.gallery_to_bf16(g)
+    s, i = eng.sim_topk_bf16(fused, gb, 50)
+    rs, ri = _bf16_ref(fused.cpu(), gb.float().cpu(), 50)
+    assert (s.cpu() - rs).abs().max().item() < 2e-6
+    full = fused.cpu().bfloat16().float() @ gb.float().cpu().T
+    for row, col in zip(*np.nonzero((i.cpu() != ri).numpy())):
+        assert abs(full[row, i[row, col].item()].item() - full[row, ri[row, col]].item()) < 2e-6
+    eng.close()
