@@ -59,6 +59,7 @@ SIGNATURES = {
     "fern_topk_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fern_gemm": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
                           c_int, c_int, c_int, c_int, c_void_p]),
+    "fern_batch_classification_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fern_set_precision": (c_int, [c_void_p, c_int]),
     "fern_get_precision": (c_int, [c_void_p]),
     "fern_gemm_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,

@@ -764,6 +764,25 @@ extern "C" int fern_element_wise_sum(fern_ctx* c, const float* image, const floa
     return FERN_OK;
 }
 
+// losses/loss.py:10-14 BatchBasedClassificationLoss.forward: cross_entropy(100 * predicted @ target.T, arange(B)), forward value
+extern "C" int fern_batch_classification_loss(fern_ctx* c, const float* predicted, const float* target, int B, int D, float* out_loss,
+                                              void* stream) {
+    if (!c || B < 1 || D < 1 || !predicted || !target || !out_loss) return fail(FERN_ERR_ARG, "fern_batch_classification_loss: bad argument");
+    if (D % 16) return fail(FERN_ERR_ARG, "fern_batch_classification_loss: D must be a multiple of 16");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    FERN_TRY(ws_begin(c, s));
+    const long ld = (B + 3) & ~3L;
+    float *logits, *rows;
+    FERN_TRY(ws_get(c, (size_t)B * ld, &logits));
+    FERN_TRY(ws_get(c, (size_t)B, &rows));
+    GemmParams p{};
+    p.A = predicted; p.lda = D; p.W = target; p.ldw = D; p.C = logits; p.ldc = ld; p.M = B; p.N = B; p.K = D; p.epi = EPI_BIAS; p.aload = ALOAD_PLAIN;
+    FERN_TRY(run_gemm(c, p, s));
+    HIP_TRY(launch_ce_diag_mean(logits, ld, B, 100.0f, rows, out_loss, s));
+    return FERN_OK;
+}
+
 extern "C" int fern_l2_normalize(fern_ctx* c, const float* x, float* out, int64_t n, int d, void* stream) {
     if (!c || n < 0 || (n && (!x || !out))) return fail(FERN_ERR_ARG, "fern_l2_normalize: bad argument");
     HIP_TRY(hipSetDevice(c->device));

@@ -18,6 +18,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
 // A row of width d (d % 4 == 0, d <= 1024) held as up to MAXV float4 per lane: element c = (i*64 + lane)*4.
 struct RowRegs {
     f32x4 v[MAXV];
@@ -112,12 +118,6 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* x, con
     }
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
 // LayerNorm fused with per-row fp8 (e4m3fn) quantisation: scale = max|y| / 448, y8 = fp8(y / scale)
 __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* x, const float* gamma, const float* beta, unsigned char* y,
                                                             float* scale, long rows, int d, long ldx, long ldy, float eps) {
@@ -208,6 +208,28 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* x, const float
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) r.v[i] = r.v[i] / den;
     row_store(r, y + row * ldy, d, lane);
+}
+
+// Cross-entropy of `scale * logits[row, :]` against label = row (losses/loss.py:10-14): log-sum-exp minus the diagonal logit.
+__global__ __launch_bounds__(256) void ce_diag_rows_kernel(const float* logits, long ld, int n, float scale, float* row_loss) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float* x = logits + row * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < n; c += 64) m = fmaxf(m, x[c] * scale);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < n; c += 64) sum += expf(x[c] * scale - m);
+    sum = wave_sum(sum);
+    if (lane == 0) row_loss[row] = (m + logf(sum)) - x[row] * scale;
+}
+// out[0] = mean(v[0..n)) in a fixed summation order (one wave)
+__global__ __launch_bounds__(64) void mean_scalar_kernel(const float* v, int n, float* out) {
+    float s = 0.f;
+    for (int c = threadIdx.x; c < n; c += 64) s += v[c];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = s / (float)n;
 }
 
 // y[row] = mean_{p<P} x[row*group_stride + row_add + p]
@@ -498,6 +520,12 @@ hipError_t launch_mean_rows(const float* x, long ldx, float* y, long ldy, long n
     if (n <= 0) return hipSuccess;
     if (bad_width(d) || (ldx & 3) || (ldy & 3)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mean_rows_kernel, row_grid(n), dim3(256), 0, s, x, ldx, y, ldy, n, P, d, group_stride, row_add);
+    return hipGetLastError();
+}
+hipError_t launch_ce_diag_mean(const float* logits, long ld, int n, float scale, float* row_loss, float* out, hipStream_t s) {
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ce_diag_rows_kernel, row_grid(n), dim3(256), 0, s, logits, ld, n, scale, row_loss);
+    hipLaunchKernelGGL(mean_scalar_kernel, dim3(1), dim3(64), 0, s, row_loss, n, out);
     return hipGetLastError();
 }
 hipError_t launch_gather_rows(const float* x, long ldx, float* y, long ldy, long n, int d, int group, long group_stride, long row_add,

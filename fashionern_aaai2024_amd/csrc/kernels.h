@@ -106,6 +106,8 @@ hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows
 hipError_t launch_mean_rows(const float* x, long ldx, float* y, long ldy, long n, int P, int d, long group_stride, long row_add,
                             hipStream_t s);
 // y[i, :] = x[(i / group)*group_stride + (i % group) + (idx ? idx[i] : row_add), :]
+// out[0] = mean_r( logsumexp_c(scale * logits[r, c]) - scale * logits[r, r] ), r, c < n; row_loss: [n] scratch
+hipError_t launch_ce_diag_mean(const float* logits, long ld, int n, float scale, float* row_loss, float* out, hipStream_t s);
 hipError_t launch_gather_rows(const float* x, long ldx, float* y, long ldy, long n, int d, int group, long group_stride, long row_add,
                               const int* idx, hipStream_t s);
 // BERT embeddings of the fusion encoder: X[b,s] = LN(cat(cls, local, seq)[b,s] + type[s >= P+1] + pos[s]) (eps 1e-12)

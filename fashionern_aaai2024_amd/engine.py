@@ -290,6 +290,15 @@ class FernEngine:
                                       int(epilogue), _stream()), "fern_gemm")
         return out
 
+    def batch_classification_loss(self, predicted, target) -> torch.Tensor:
+        """losses/loss.py:10-14: cross_entropy(100 * predicted @ target.T, arange(B)); returns a 0-dim device tensor."""
+        p = self._f32(predicted)
+        t = self._f32(target, tuple(p.shape))
+        out = self._empty(1)
+        _lib.check(self.lib.fern_batch_classification_loss(self._h, _ptr(p), _ptr(t), p.shape[0], p.shape[1], _ptr(out), _stream()),
+                   "fern_batch_classification_loss")
+        return out[0]
+
     def to_bf16(self, x) -> torch.Tensor:
         """fp32 [R,C] -> bf16 [R,C], round to nearest even (the conversion every bf16 operand of libfern goes through)."""
         return self.gallery_to_bf16(x)

@@ -181,6 +181,12 @@ FERN_API int fern_get_precision(fern_ctx* ctx);
  * under the prefix "clip4cir." with that class's key names; image / text / out are [n, 2*clip_feature_dim]. */
 FERN_API int fern_finalize_clip4cir(fern_ctx* ctx);
 FERN_API int fern_combiner_clip4cir(fern_ctx* ctx, const float* image, const float* text, float* out, int64_t n, void* stream);
+/* losses/loss.py:10-14 BatchBasedClassificationLoss.forward(predicted [B,D], target [B,D]) =
+ * cross_entropy(100 * predicted @ target.T, labels = arange(B)), mean over the batch: forward VALUE only (the training
+ * loop and its backward are outside this path; ERN's default mode, models/model.py:71-75, produces the two inputs).
+ * out_loss: one float on the device.  D % 16 == 0. */
+FERN_API int fern_batch_classification_loss(fern_ctx* ctx, const float* predicted, const float* target, int B, int D, float* out_loss,
+                                   void* stream);
 /* utils.element_wise_sum(image_features, text_features) = F.normalize(image + text) -- utils/utils.py:133-140 */
 FERN_API int fern_element_wise_sum(fern_ctx* ctx, const float* image, const float* text, float* out, int64_t n, int d, void* stream);
 /* F.normalize(x, dim=-1) -- run/test/test_fiq.py:45 */

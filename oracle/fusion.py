@@ -153,3 +153,9 @@ def combiner_clip4cir(sd, prefix, image_features, text_features):
 def element_wise_sum(image_features, text_features):
     """utils.element_wise_sum -- /root/reference/utils/utils.py:133-140."""
     return F.normalize(image_features + text_features, dim=-1)
+
+
+def batch_classification_loss(predicted, target):
+    """BatchBasedClassificationLoss.forward -- /root/reference/losses/loss.py:10-14."""
+    logits = 100 * predicted @ target.T
+    return F.cross_entropy(logits, torch.arange(predicted.shape[0]))

@@ -61,6 +61,9 @@ class OracleEngine:
     def visual_sr(self, which, local):
         return ofusion.visual_sr(self.sd, _SR[which], local.float().cpu())
 
+    def batch_classification_loss(self, predicted, target):
+        return ofusion.batch_classification_loss(predicted.float().cpu(), target.float().cpu())
+
     def l2_normalize(self, x):
         return F.normalize(x.float().cpu(), dim=-1)
 

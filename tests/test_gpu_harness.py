@@ -199,3 +199,26 @@ def test_full_pipeline_in_bf16_perf_mode_stays_within_the_score_budget():
 def test_bf16_precision_is_refused_for_the_resnet_tower():
     with pytest.raises(ValueError, match="transformer towers"):
         create_model("tiny-resnet", device=DEV, seed=1, precision="bf16")
+
+
+def test_batch_classification_loss_and_train_mode_match_the_reference():
+    """losses/loss.py:10-14 and ERN's default ("train") mode (models/model.py:71-75) on the HIP engine, against the values
+    the imported reference produced (tests/golden/loss.npz)."""
+    from fashionern_aaai2024_amd.losses import BatchBasedClassificationLoss
+    z = np.load(os.path.join(GOLD, "loss.npz"))
+    d = 128
+    clip = sdata.StubCLIP(d).eval().to(DEV)
+    model = ERN(clip, d, DEV)
+    model.load_state_dict(synth.fusion_state_dict(d, seed=11))
+    crit = BatchBasedClassificationLoss(model.engine)
+    for key in [k for k in z.files if k.startswith("loss_")]:
+        _, b, dd = key.split("_")
+        got = crit(torch.from_numpy(z[f"pred_{b}_{dd}"]), torch.from_numpy(z[f"tar_{b}_{dd}"]))
+        # logits are 100 x cosines: an fp32 rounding of a logit is ~1e-5, so is the loss
+        assert abs(got.item() - float(z[key])) < 2e-4 * max(1.0, abs(float(z[key]))), key
+    t = lambda k: torch.from_numpy(z["train_in_" + k])  # noqa: E731
+    fusion, target = model(ref_feats=t("ref"), ref_local_feats=t("loc"), text_feats=t("tg"), text_seq_feats=t("ts"),
+                           tar_feats=t("tar"), tar_local_feats=t("tloc"))
+    assert (fusion.cpu() - torch.from_numpy(z["train_fusion"])).abs().max() < 5e-5
+    assert (target.cpu() - torch.from_numpy(z["train_target"])).abs().max() < 5e-5
+    assert abs(crit(fusion, target).item() - float(z["train_loss"])) < 5e-3

@@ -126,3 +126,19 @@ def test_adjacent_surface_oracle_matches_reference(fusion_gold, cdim):
     im, tx = t(synth.global_feats(5, 2 * cdim, INPUT_SEED, "c4i")), t(synth.global_feats(5, 2 * cdim, INPUT_SEED, "c4t"))
     assert np.abs(ofusion.combiner_clip4cir(sd, "", im, tx).numpy() - fusion_gold[f"clip4cir_c{cdim}"]).max() < 1e-6
     assert np.abs(ofusion.element_wise_sum(im, tx).numpy() - fusion_gold[f"ews_c{cdim}"]).max() < 1e-7
+
+
+def test_loss_and_train_mode_against_the_reference():
+    """losses/loss.py BatchBasedClassificationLoss and ERN's default ("train") mode, fixtures from the imported reference."""
+    z = np.load(os.path.join(GOLD, "loss.npz"))
+    for key in [k for k in z.files if k.startswith("loss_")]:
+        _, b, d = key.split("_")
+        got = ofusion.batch_classification_loss(torch.from_numpy(z[f"pred_{b}_{d}"]), torch.from_numpy(z[f"tar_{b}_{d}"]))
+        assert abs(got.item() - float(z[key])) < 1e-5 * max(1.0, abs(float(z[key])))
+    sd = ofusion.as_torch(synth.fusion_state_dict(128, seed=11))
+    t = lambda k: torch.from_numpy(z["train_in_" + k])  # noqa: E731
+    fusion = ofusion.dvr_fuse(sd, t("loc"), t("ts"), t("ref"), t("tg"))
+    target = ofusion.index_fuse(sd, t("tar"), t("tloc"))
+    assert (fusion - torch.from_numpy(z["train_fusion"])).abs().max() < 2e-5
+    assert (target - torch.from_numpy(z["train_target"])).abs().max() < 2e-5
+    assert abs(ofusion.batch_classification_loss(fusion, target).item() - float(z["train_loss"])) < 1e-3

@@ -9,6 +9,7 @@ the HIP path.
   fusion.npz   <- models.model.ERN (mode="test"/"index") and its sub-modules, D in {128, 512, 640}
   clip.npz     <- models/others/modeling_clip.py (the in-tree statement of CLIP arithmetic), executed
                   under the installed transformers package so its relative imports resolve
+  loss.npz     <- losses.loss.BatchBasedClassificationLoss and ERN mode="train" (forward values only)
   harness.json/.npz <- run/test/test_{fiq,cirr,200k,shoes,val}.py compute_*_val_metrics and
                   utils.utils.extract_index_features on in-memory synthetic datasets with a stub CLIP
 
@@ -252,9 +253,52 @@ def harness_goldens():
     np.savez_compressed(os.path.join(OUT, "harness.npz"), **arrays)
 
 
+def loss_goldens():
+    """losses/loss.py:10-14 on unit-norm feature pairs of several batch sizes / widths, and the value it takes on the
+    (fusion, target) pair ERN's default mode returns (models/model.py:71-75) -- forward values only."""
+    from losses.loss import BatchBasedClassificationLoss
+    from models.model import ERN
+
+    class Stub(torch.nn.Module):
+        def encode_image(self, x):
+            return x
+
+        def encode_text(self, x, mode="global", visual_emb=None):
+            return x
+
+    crit = BatchBasedClassificationLoss()
+    out = {}
+    for b, d in ((4, 128), (32, 512), (33, 640), (1, 64), (200, 512)):
+        g = torch.Generator().manual_seed(1000 + b + d)
+        p = torch.nn.functional.normalize(torch.randn(b, d, generator=g), dim=-1)
+        q = torch.nn.functional.normalize(p + 0.5 * torch.randn(b, d, generator=g), dim=-1)
+        out[f"pred_{b}_{d}"], out[f"tar_{b}_{d}"] = p.numpy(), q.numpy()
+        out[f"loss_{b}_{d}"] = crit(p, q).detach().numpy()
+    d, b = 128, 6
+    sd = synth.fusion_state_dict(d, seed=FUSION_SEED)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ERN(Stub(), d, torch.device("cpu")).eval().float()
+    model.load_state_dict(as_torch(sd), strict=True)
+    ref = t(synth.global_feats(b, d, INPUT_SEED, "lref"))
+    loc = t(synth.local_feats(b, d, INPUT_SEED, "lloc"))
+    tg = t(synth.global_feats(b, d, INPUT_SEED, "ltg"))
+    ts = t(synth._normal(INPUT_SEED, f"ltseq/{d}", (b, 77, d)))
+    tar = torch.nn.functional.normalize(t(synth.global_feats(b, d, INPUT_SEED, "ltar")), dim=-1)
+    tloc = t(synth.local_feats(b, d, INPUT_SEED, "ltloc"))
+    with torch.no_grad():
+        fusion, target = model(ref_feats=ref, ref_local_feats=loc, text_feats=tg, text_seq_feats=ts, tar_feats=tar, tar_local_feats=tloc)
+        out["train_loss"] = crit(fusion, target).numpy()
+    out["train_fusion"], out["train_target"] = fusion.numpy(), target.numpy()
+    for k, v in (("ref", ref), ("loc", loc), ("tg", tg), ("ts", ts), ("tar", tar), ("tloc", tloc)):
+        out["train_in_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+    print("loss.npz:", {k: float(v) for k, v in out.items() if k.startswith("loss_") or k == "train_loss"})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    fusion_goldens()
-    clip_goldens()
-    harness_goldens()
+    only = sys.argv[1:]
+    for name, fn in (("fusion", fusion_goldens), ("clip", clip_goldens), ("harness", harness_goldens), ("loss", loss_goldens)):
+        if not only or name in only:
+            fn()
