@@ -25,14 +25,68 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * cdf2;
 }
 
+// One 32x32 accumulator tile.  GUARD = false: the tile lies fully inside the matrix (wave-uniform test by the caller), so
+// there is no per-element predicate at all -- the 16 residual / scale loads issue back to back behind ONE wait, and so do
+// the 16 stores.  (With a predicate per element every load sits in its own exec-masked block and the compiler waits for
+// it -- and for every store before it -- on the spot: 16 serial memory round trips per tile.)
+template <int EPI, bool OUT_BF16, bool SCALED, bool GUARD>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16& acc, int row0, int col0, int l31, int lrow, int loff) {
+    constexpr bool resid = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_RELU;
+    const int col = col0 + l31;
+    if (GUARD && col >= p.N) return;
+    const float bia = p.bias ? p.bias[col] : 0.0f;
+    const float qw = SCALED ? p.scale_w[col] : 1.0f;          // fp8 operands: per-output-channel weight scale
+    const float* qa = SCALED ? p.scale_a + row0 : nullptr;    // ... and per-row activation scales
+    float sc = 1.0f, sh = 0.0f;
+    if (EPI == EPI_COLAFFINE_TANH) { sc = p.aux0[col]; sh = p.aux1[col]; }
+    if (EPI == EPI_PATCH_EMBED) {
+        const int g2 = p.grid * p.grid;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + lrow;
+            if (!GUARD || row < p.M) {
+                const long orow = row + row / g2 + 1;
+                p.C[orow * p.ldc + col] = acc[r] + bia + p.aux0[(long)((row % g2) + 1) * p.N + col];
+            }
+        }
+        return;
+    }
+    // The residual stream is updated in place (R == C): the compiler keeps every load behind the preceding store, so the
+    // memory addends of a tile are fetched together BEFORE its first store.
+    const float* Rt = resid ? p.R + (long)row0 * p.ldc + col0 : nullptr;
+    float add[16], qs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ru = (r & 3) + 8 * (r >> 2);
+        const bool ok = !GUARD || row0 + ru + lrow < p.M;
+        if (resid) add[r] = ok ? Rt[(long)ru * p.ldc + loff] : 0.0f;
+        if (SCALED) qs[r] = ok ? qa[ru + lrow] * qw : 0.0f;
+    }
+    float* Ct = OUT_BF16 ? nullptr : p.C + (long)row0 * p.ldc + col0;
+    unsigned short* Cb = OUT_BF16 ? reinterpret_cast<unsigned short*>(p.C) + (long)row0 * p.ldc + col0 : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ru = (r & 3) + 8 * (r >> 2);
+        if (!GUARD || row0 + ru + lrow < p.M) {
+            float v = SCALED ? acc[r] * qs[r] + bia : acc[r] + bia;
+            if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+            else if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.0f);
+            else if (EPI == EPI_BIAS_RESIDUAL) v += add[r];
+            else if (EPI == EPI_BIAS_RESIDUAL_RELU) v = fmaxf(v + add[r], 0.0f);
+            else if (EPI == EPI_COLAFFINE_TANH) v = tanhf(v * sc + sh);
+            if (OUT_BF16) Cb[(long)ru * p.ldc + loff] = f32_to_bf16_bits(v);
+            else Ct[(long)ru * p.ldc + loff] = v;
+        }
+    }
+}
+
 // Plain (element-wise) epilogue of one epilogue kind: the kind is a template parameter so that the switch is taken once per
 // kernel, not once per element, and the tile loops stay small enough to unroll fully (register-indexed accumulators).
 // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+// An element's address = (wave-uniform tile / register-row part, kept in SGPRs) + (lane part: 4 * half rows + column):
+// one 32-bit VGPR offset serves all 16 loads and stores of a tile (ldc < 2^24 on this path, so the lane part fits an int).
 template <int EPI, bool OUT_BF16, bool SCALED, int TM, int TN>
 __device__ __forceinline__ void plain_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int row_w, int col_w, int l31, int lh) {
-    constexpr bool resid = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_RELU;
-    // An element's address = (wave-uniform tile / register-row part, kept in SGPRs) + (lane part: 4 * half rows + column):
-    // one 32-bit VGPR offset serves all 16 loads and stores of a tile (ldc < 2^24 on this path, so the lane part fits an int).
     const int lrow = 4 * lh;
     const int loff = lrow * (int)p.ldc + l31;
 #pragma unroll
@@ -40,54 +94,8 @@ __device__ __forceinline__ void plain_epilogue(const GemmParams& p, f32x16 (&acc
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int row0 = row_w + i * 32, col0 = col_w + j * 32;       // wave-uniform
-            const int col = col0 + l31;
-            if (col < p.N) {
-                const float bia = p.bias ? p.bias[col] : 0.0f;
-                const float qw = SCALED ? p.scale_w[col] : 1.0f;          // fp8 operands: per-output-channel weight scale
-                const float* qa = SCALED ? p.scale_a + row0 : nullptr;    // ... and per-row activation scales
-                float sc = 1.0f, sh = 0.0f;
-                if (EPI == EPI_COLAFFINE_TANH) { sc = p.aux0[col]; sh = p.aux1[col]; }
-                if (EPI == EPI_PATCH_EMBED) {
-                    const int g2 = p.grid * p.grid;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = row0 + (r & 3) + 8 * (r >> 2) + lrow;
-                        if (row < p.M) {
-                            const long orow = row + row / g2 + 1;
-                            p.C[orow * p.ldc + col] = acc[i][j][r] + bia + p.aux0[(long)((row % g2) + 1) * p.N + col];
-                        }
-                    }
-                } else {
-                    // The residual stream is updated in place (R == C): the compiler has to keep every load behind the
-                    // preceding store, so the 16 residual values of a tile are fetched together BEFORE its first store
-                    // (one memory round trip per tile instead of 16).
-                    const float* Rt = resid ? p.R + (long)row0 * p.ldc + col0 : nullptr;
-                    float add[16];
-                    if (resid) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int ru = (r & 3) + 8 * (r >> 2);
-                            add[r] = row0 + ru + lrow < p.M ? Rt[(long)ru * p.ldc + loff] : 0.0f;
-                        }
-                    }
-                    float* Ct = OUT_BF16 ? nullptr : p.C + (long)row0 * p.ldc + col0;
-                    unsigned short* Cb = OUT_BF16 ? reinterpret_cast<unsigned short*>(p.C) + (long)row0 * p.ldc + col0 : nullptr;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ru = (r & 3) + 8 * (r >> 2);
-                        if (row0 + ru + lrow < p.M) {
-                            float v = SCALED ? acc[i][j][r] * (qa[ru + lrow] * qw) + bia : acc[i][j][r] + bia;
-                            if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
-                            else if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.0f);
-                            else if (EPI == EPI_BIAS_RESIDUAL) v += add[r];
-                            else if (EPI == EPI_BIAS_RESIDUAL_RELU) v = fmaxf(v + add[r], 0.0f);
-                            else if (EPI == EPI_COLAFFINE_TANH) v = tanhf(v * sc + sh);
-                            if (OUT_BF16) Cb[(long)ru * p.ldc + loff] = f32_to_bf16_bits(v);
-                            else Ct[(long)ru * p.ldc + loff] = v;
-                        }
-                    }
-                }
-            }
+            if (row0 + 32 <= p.M && col0 + 32 <= p.N) epilogue_tile<EPI, OUT_BF16, SCALED, false>(p, acc[i][j], row0, col0, l31, lrow, loff);
+            else if (row0 < p.M && col0 < p.N) epilogue_tile<EPI, OUT_BF16, SCALED, true>(p, acc[i][j], row0, col0, l31, lrow, loff);
             // one 32x32 tile at a time: without this fence the scheduler hoists the address arithmetic and the loads of all
             // TM x TN tiles to the top and the kernel's register budget (= its occupancy) is set by the epilogue
             __builtin_amdgcn_sched_barrier(0);
