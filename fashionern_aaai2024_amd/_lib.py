@@ -64,6 +64,9 @@ SIGNATURES = {
     "fern_get_precision": (c_int, [c_void_p]),
     "fern_gemm_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
                                c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fern_split_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "fern_gemm_bf16x3": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
+                                 c_int, c_int, c_int, c_int, c_void_p]),
     "fern_quantize_rows_fp8": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),
     "fern_gemm_fp8": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
                               c_int, c_int, c_int, c_int, c_int, c_void_p]),

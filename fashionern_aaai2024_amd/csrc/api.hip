@@ -1363,6 +1363,31 @@ extern "C" int fern_gemm_bf16(fern_ctx* c, const uint16_t* A, int64_t lda, const
     return prof_close(c, slot, (hipStream_t)stream);
 }
 
+extern "C" int fern_split_bf16x3(fern_ctx* c, const float* x, uint16_t* y, int64_t n, void* stream) {
+    if (!c || n < 0 || (n && (!x || !y)) || n % 4) return fail(FERN_ERR_ARG, "fern_split_bf16x3: bad argument (n % 4 == 0)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_split_bf16x3(x, y, n, n, (hipStream_t)stream));
+    return FERN_OK;
+}
+
+extern "C" int fern_gemm_bf16x3(fern_ctx* c, const uint16_t* A3, int64_t lda, const uint16_t* W3, int64_t ldw, const float* bias,
+                                const float* residual, float* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream) {
+    if (!c || M < 0 || N < 0 || K <= 0) return fail(FERN_ERR_ARG, "fern_gemm_bf16x3: bad argument");
+    if (M == 0 || N == 0) return FERN_OK;
+    if (!A3 || !W3 || !C) return fail(FERN_ERR_ARG, "fern_gemm_bf16x3: NULL argument");
+    if (epilogue < FERN_EPI_BIAS || epilogue > FERN_EPI_BIAS_RESIDUAL) return fail(FERN_ERR_ARG, "fern_gemm_bf16x3: unknown epilogue");
+    if (epilogue == FERN_EPI_BIAS_RESIDUAL && !residual) return fail(FERN_ERR_ARG, "fern_gemm_bf16x3: residual is NULL");
+    if (K % 32 || lda % 8 || ldw % 8) return fail(FERN_ERR_ARG, "fern_gemm_bf16x3: K % 32, lda % 8 and ldw % 8 must be 0");
+    HIP_TRY(hipSetDevice(c->device));
+    GemmParams p{};
+    p.Ab = A3; p.lda = lda; p.a_plane = (long)M * lda; p.Wb = W3; p.ldw = ldw; p.w_plane = (long)N * ldw; p.planes = 3;
+    p.bias = bias; p.R = residual; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aload = ALOAD_PLAIN;
+    int slot;
+    FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * M * (double)N * K, (hipStream_t)stream, &slot, M, N, K, 300 + epilogue));
+    HIP_TRY(launch_gemm_bf16(p, (hipStream_t)stream));
+    return prof_close(c, slot, (hipStream_t)stream);
+}
+
 extern "C" int fern_quantize_rows_fp8(fern_ctx* c, const void* x, int x_is_bf16, int64_t ldx, uint8_t* y, int64_t ldy, float* scale, int64_t rows,
                                       int d, void* stream) {
     if (!c || rows < 0 || (rows && (!x || !y || !scale))) return fail(FERN_ERR_ARG, "fern_quantize_rows_fp8: bad argument");

@@ -49,6 +49,8 @@ struct GemmParams {
     // fp8 (OCP e4m3fn) operand form: Ab / Wb point at fp8 bytes (strides in elements = bytes), K % 64 == 0; the quantisation
     // scales are folded back in the epilogue: C = acc * scale_a[row] * scale_w[col] (+ bias ...)
     int fp8;
+    int planes;                   // 3: bf16x3 operands (three bf16 planes per operand, plane strides below, in elements); else 1
+    long a_plane, w_plane;
     const float* scale_a;         // [M] per-row (token) activation scales, or null
     const float* scale_w;         // [N] per-output-channel weight scales, or null
 };
@@ -146,6 +148,8 @@ hipError_t launch_u8_to_chw(const unsigned char* src, long src_ld, int x0, int y
 
 // ---- bf16 gallery sweep (sweep_bf16.hip) ---------------------------------------------------------------------------
 hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStream_t s);
+// x [n] fp32 -> three bf16 planes y[0..n), y[plane..), y[2 plane..): x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)
+hipError_t launch_split_bf16x3(const float* x, unsigned short* y, long n, long plane, hipStream_t s);
 // scores[q, n] = Q[q] . G[n] for q < B <= 64, bf16 gallery [N, D] (D % 64 == 0), fp32 accumulate, scores row stride ld
 hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, hipStream_t s);
 

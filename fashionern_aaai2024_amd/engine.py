@@ -317,6 +317,26 @@ class FernEngine:
                                            int(epilogue), int(bool(out_bf16)), _stream()), "fern_gemm_bf16")
         return out
 
+    def split_bf16x3(self, x) -> torch.Tensor:
+        """fp32 [R,C] -> bf16 [3,R,C]: x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)."""
+        x = self._f32(x)
+        out = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.fern_split_bf16x3(self._h, _ptr(x), _ptr(out), x.numel(), _stream()), "fern_split_bf16x3")
+        return out
+
+    def gemm_bf16x3(self, a3, w3, bias=None, residual=None, epilogue=EPI_BIAS) -> torch.Tensor:
+        """fp32-grade GEMM from bf16x3 operands; a3 [3,M,K] / w3 [3,N,K] from `split_bf16x3` (fp32 inputs are split first)."""
+        a3 = a3 if a3.dtype == torch.bfloat16 else self.split_bf16x3(a3)
+        w3 = w3 if w3.dtype == torch.bfloat16 else self.split_bf16x3(w3)
+        _, m, k = a3.shape
+        n = w3.shape[1]
+        bias = None if bias is None else self._f32(bias, (n,))
+        residual = None if residual is None else self._f32(residual, (m, n))
+        out = self._empty(m, n)
+        _lib.check(self.lib.fern_gemm_bf16x3(self._h, _ptr(a3), k, _ptr(w3), k, _ptr(bias), _ptr(residual), _ptr(out), n, m, n, k,
+                                             int(epilogue), _stream()), "fern_gemm_bf16x3")
+        return out
+
     def quantize_rows_fp8(self, x):
         """[R,C] fp32 or bf16 -> (fp8 e4m3fn bytes [R,C] as uint8, per-row scales [R]); scale = max|row| / 448."""
         x = x.to(self.device).contiguous() if x.dtype == torch.bfloat16 else self._f32(x)

@@ -244,6 +244,14 @@ FERN_API int fern_gemm(fern_ctx* ctx, const float* A, int64_t lda, const float* 
 FERN_API int fern_gemm_bf16(fern_ctx* ctx, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias,
                    const float* residual, void* C, int64_t ldc, int M, int N, int K, int epilogue, int out_bf16,
                    void* stream);
+/* bf16x3 operand form: fp32-grade products from bf16 MFMAs.  fern_split_bf16x3 writes an fp32 buffer of n elements as three
+ * bf16 planes y[0..n), y[n..2n), y[2n..3n): x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (their sum is x to 2^-27).
+ * fern_gemm_bf16x3 takes A3 [3][M,lda] and W3 [3][N,ldw] in that layout and accumulates the six products a_i b_j with
+ * i + j <= 2 in fp32: the dropped terms are below 2^-25 |a||b|, under one fp32 rounding of the product, so the result is
+ * an fp32 dot product in a different summation order (not bit-identical to fern_gemm).  K % 32 == 0, lda/ldw % 8 == 0. */
+FERN_API int fern_split_bf16x3(fern_ctx* ctx, const float* x, uint16_t* y, int64_t n, void* stream);
+FERN_API int fern_gemm_bf16x3(fern_ctx* ctx, const uint16_t* A3, int64_t lda, const uint16_t* W3, int64_t ldw, const float* bias,
+                     const float* residual, float* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream);
 /* fp8 (OCP e4m3fn) operand form: A [M,lda] / W [N,ldw] bytes with per-row scales (fern_quantize_rows_fp8 produces both:
  * scale[r] = max|row r| / 448, or 1 for a zero row; y = fp8(x / scale[r]), round to nearest even);
  * C = (sum_k A8 W8) * scale_a[row] * scale_w[col] + bias (+ GELU | + residual), fp32 accumulation on

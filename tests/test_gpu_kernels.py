@@ -331,3 +331,30 @@ def test_gemm_fp8(engine, m, n, k, epi, out_bf16):
         gi = engine.gemm_fp8(ai.to(torch.float8_e4m3fn).view(torch.uint8).cuda(), ones_m, wi.to(torch.float8_e4m3fn).view(torch.uint8).cuda(),
                              ones_n, None)
         assert torch.equal(gi.cpu(), ai @ wi.T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(64, 128, 64), (197, 384, 96), (1000, 520, 256), (4096, 768, 768)])
+@pytest.mark.parametrize("epi", [0, 1, 3])
+def test_gemm_bf16x3_is_fp32_grade(engine, m, n, k, epi):
+    """bf16x3 GEMM (three bf16 planes per operand, six exact partial products, fp32 accumulation) against fp64 math on the
+    ORIGINAL fp32 operands, at the tolerance of the fp32 MFMA GEMM test -- and no further from the truth than that kernel."""
+    g = torch.Generator().manual_seed(m * 3 + n + k + epi)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * k ** -0.5
+    b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g)
+    a3 = engine.split_bf16x3(a)
+    s = a3.float().cpu()
+    assert (s[0] + s[1] + s[2] - a).abs().max().item() <= 2 ** -24 * a.abs().max().item()       # the planes re-assemble x
+    assert torch.equal(s[0], a.bfloat16().float())
+    ref = a.double() @ w.double().T + b.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 3:
+        ref = ref + r.double()
+    got = engine.gemm_bf16x3(a, w, b, residual=r if epi == 3 else None, epilogue=epi).cpu().double()
+    f32 = engine.gemm(a, w, b, residual=r if epi == 3 else None, epilogue=epi).cpu().double()
+    assert torch.allclose(got, ref, rtol=1e-5, atol=2e-5)
+    err_x3, err_f32 = (got - ref).abs().max().item(), (f32 - ref).abs().max().item()
+    assert err_x3 < 4 * err_f32 + 1e-7, (err_x3, err_f32)
