@@ -302,28 +302,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
 struct TileCfg { int bm, bn, bk; float eff; };
 // order matters only for ties; eff = relative main-loop efficiency used by the shape heuristic
 static const TileCfg kCfgs[] = {
-    {128, 128, 32, 1.00f},   // 0: 4 waves of 64x64
+    {128, 128, 32, 1.00f},   // 0: register-staged, 4 waves of 64x64
     {64, 128, 32, 0.93f},    // 1
     {128, 64, 32, 0.93f},    // 2
     {64, 64, 32, 0.86f},     // 3
-    {128, 128, 32, 1.00f},   // 4: as 0, LDS double-buffered (experimental)
-    {128, 128, 64, 1.00f},   // 5: as 0, 64-wide k tiles (experimental)
-    {256, 128, 32, 1.00f},   // 6: 8 waves of 64x64 (experimental)
-    {256, 128, 32, 1.00f},   // 7: as 6, double-buffered (experimental)
+    {0, 0, 0, 0.f}, {0, 0, 0, 0.f}, {0, 0, 0, 0.f}, {0, 0, 0, 0.f},   // 4-7: retired A/B variants (LDS double
+                             // buffering, 64-wide k tiles and 256x128 8-wave tiles of the register-staged kernel gained nothing)
     {128, 128, 16, 1.00f},   // 8: LDS-DMA staging, 16-wide k tiles, double buffered
     {64, 128, 16, 0.93f},    // 9
     {128, 64, 16, 0.93f},    // 10
     {64, 64, 16, 0.86f},     // 11
-    {128, 128, 32, 1.00f},   // 12: LDS-DMA, 32-wide k tiles, 2 workgroups per CU (experimental)
-    {256, 128, 16, 1.00f},   // 13: LDS-DMA, 8 waves (experimental)
-    {128, 128, 16, 1.00f},   // 14: as 8, copy drained before the MFMAs (A/B)
-    {128, 128, 16, 1.00f},   // 15: as 8, wait/barrier pinned after all MFMAs (A/B)
-    {64, 64, 16, 0.86f},     // 16: ONE wave per workgroup (64x64 tile): no inter-wave barrier at all (experimental)
-    {128, 128, 16, 1.00f},   // 17: 8 waves of 64x32 (more resident waves per SIMD; experimental)
-    {128, 128, 16, 1.00f},   // 18: 8 waves of 32x64 (experimental)
 };
 constexpr int kNumAuto = 4;      // configs the heuristic may pick
-constexpr int kNumCfgs = 19;
+constexpr int kNumCfgs = 12;
 
 static int forced_cfg() {
     static int v = [] {
@@ -355,7 +346,7 @@ static int choose_cfg(int M, int N, int K, bool reduce = false) {
         const int base = (f >= 8 || (f < 0 && M >= 1024) || (K & 31)) ? 8 : 0;
         return best_of(M, N, base, base + 2);
     }
-    if (f >= 0 && f < kNumCfgs && K % kCfgs[f].bk == 0) return f;
+    if (f >= 0 && f < kNumCfgs && kCfgs[f].bk && K % kCfgs[f].bk == 0) return f;
     if (f >= 100) return best_of(M, N, 8, 12);
     return (M >= 1024 || (K & 31)) ? best_of(M, N, 8, 12) : best_of(M, N, 0, kNumAuto);   // K % 32 != 0: only the 16-wide k tiles fit
 }
@@ -382,21 +373,11 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
         case 1: hipLaunchKernelGGL((gemm_f32_kernel<64, 128, 32, 64, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL((gemm_f32_kernel<128, 64, 64, 32, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
         case 3: hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, 32, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 64, 64, 32, true>), dim3(nb), dim3(256), 0, s, p); break;
-        case 5: hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 64, 64, 64, false>), dim3(nb), dim3(256), 0, s, p); break;
-        case 6: hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 64, 64, 32, false>), dim3(nb), dim3(512), 0, s, p); break;
-        case 7: hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 64, 64, 32, true>), dim3(nb), dim3(512), 0, s, p); break;
         case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
         case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
         case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
         case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 12: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 32, 2>), dim3(nb), dim3(256), 0, s, p); break;
-        case 13: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 64, 64, 16, 2>), dim3(nb), dim3(512), 0, s, p); break;
-        case 14: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4, false, 1>), dim3(nb), dim3(256), 0, s, p); break;
-        case 15: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4, false, 2>), dim3(nb), dim3(256), 0, s, p); break;
-        case 16: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 64, 64, 16, 4>), dim3(nb), dim3(64), 0, s, p); break;
-        case 17: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 32, 16, 6>), dim3(nb), dim3(512), 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 32, 64, 16, 6>), dim3(nb), dim3(512), 0, s, p); break;
+        default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

@@ -189,47 +189,27 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
 }
 
 struct TileCfgB { int bm, bn, bk; };
+// The tuner's candidates.  Retired after A/B runs on MI355X: 128-byte rows (64-element k tiles), 4-stage rings
+// and 128x64 / 128x128 per-wave tiles -- fewer resident workgroups cost more than the deeper prefetch or the saved LDS reads gain.
 static const TileCfgB kCfgsB[] = {
-    {128, 128, 32},   // 0: 4 waves of 64x64, 64-byte rows, 2 stages
-    {128, 128, 32},   // 1: 3 stages
-    {128, 128, 32},   // 2: 4 stages
-    {128, 128, 64},   // 3: 128-byte rows, 2 stages
-    {128, 128, 64},   // 4: 3 stages
-    {256, 128, 32},   // 5: 8 waves of 64x64, 3 stages
-    {256, 128, 32},   // 6: 4 stages
-    {256, 128, 64},   // 7: 3 stages
-    {64, 128, 32},    // 8: 4 stages
-    {256, 256, 32},   // 9: 16 waves, 3 stages
-    {64, 128, 32},    // 10: 2 stages
-    {128, 64, 32},    // 11: 2 stages
-    {64, 64, 32},     // 12: 4 waves of 32x32, 2 stages
-    {256, 128, 32},   // 13: 4 waves of 128x64 (fewer LDS fragment reads per MFMA), 3 stages
-    {256, 128, 32},   // 14: as 13, 2 stages
-    {128, 128, 32},   // 15: 2 waves of 128x64, 2 stages
-    {256, 256, 32},   // 16: 4 waves of 128x128, 2 stages
+    {128, 128, 32},   // 0: 4 waves of 64x64, 64-byte rows, 2 stages, 4 workgroups per CU
+    {256, 128, 32},   // 1: 8 waves of 64x64, 3 stages
+    {256, 256, 32},   // 2: 16 waves of 64x64, 3 stages
+    {64, 128, 32},    // 3: 4 waves of 32x64, 2 stages
+    {128, 64, 32},    // 4: 4 waves of 64x32, 2 stages
+    {64, 64, 32},     // 5: 4 waves of 32x32, 2 stages
 };
-constexpr int kNumCfgsB = 17;
+constexpr int kNumCfgsB = 6;
 
 static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsB[c].bm - 1) / kCfgsB[c].bm) * ((p.N + kCfgsB[c].bn - 1) / kCfgsB[c].bn);
     switch (c) {
         case 0: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 3, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 4, 2>), dim3(nb), dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 3, 1>), dim3(nb), dim3(256), 0, s, p); break;
-        case 5: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 3, 2>), dim3(nb), dim3(512), 0, s, p); break;
-        case 6: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 4, 2>), dim3(nb), dim3(512), 0, s, p); break;
-        case 7: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 64, 3, 2>), dim3(nb), dim3(512), 0, s, p); break;
-        case 8: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 32, 4, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 9: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 64, 64, 32, 3, 1>), dim3(nb), dim3(1024), 0, s, p); break;
-        case 10: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 11: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 64, 64, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 12: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 64, 32, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 13: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 128, 64, 32, 3, 2>), dim3(nb), dim3(256), 0, s, p); break;
-        case 14: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 128, 64, 32, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
-        case 15: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 128, 64, 32, 2, 2>), dim3(nb), dim3(128), 0, s, p); break;
-        case 16: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 128, 128, 32, 2, 1>), dim3(nb), dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 3, 2>), dim3(nb), dim3(512), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 64, 64, 32, 3, 1>), dim3(nb), dim3(1024), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 64, 64, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 5: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 64, 32, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -254,27 +234,15 @@ static hipError_t launch_cfg_f8(int c, const GemmParams& p, hipStream_t s) {
 
 // bf16x3 tile family (three planes per operand: 3x the LDS of the plain kernel per stage)
 static const TileCfgB kCfgsX3[] = {
-    {128, 128, 32},   // 0: 4 waves of 64x64, 3 stages, 1 workgroup per CU
-    {128, 128, 32},   // 1: 2 stages
-    {128, 64, 32},    // 2: 4 waves of 64x32, 2 stages, 2 per CU
-    {64, 128, 32},    // 3: 4 waves of 32x64, 2 stages
-    {64, 64, 32},     // 4: 4 waves of 32x32, 2 stages, 3 per CU
-    {256, 128, 32},   // 5: 8 waves of 64x64, 2 stages
-    {64, 64, 32},     // 6: 3 stages
-    {128, 64, 32},    // 7: 3 stages
+    {256, 128, 32},   // 0: 8 waves of 64x64, 2 stages (144 KB of LDS: one workgroup per CU)
+    {128, 64, 32},    // 1: 4 waves of 64x32, 2 stages, 2 per CU (small problems)
 };
-constexpr int kNumCfgsX3 = 8;
+constexpr int kNumCfgsX3 = 2;
 static hipError_t launch_cfg_x3(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsX3[c].bm - 1) / kCfgsX3[c].bm) * ((p.N + kCfgsX3[c].bn - 1) / kCfgsX3[c].bn);
     switch (c) {
-        case 0: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 3, 1, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 2, 1, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 64, 64, 32, 32, 2, 2, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 32, 2, 2, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 64, 32, 32, 32, 2, 3, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 5: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 2, 1, false, 3>), dim3(nb), dim3(512), 0, s, p); break;
-        case 6: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 64, 32, 32, 32, 3, 2, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 7: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 64, 64, 32, 32, 3, 1, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 0: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 2, 1, false, 3>), dim3(nb), dim3(512), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 64, 64, 32, 32, 2, 2, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -304,13 +272,13 @@ static std::map<ShapeKeyB, int> g_tuned_b;
 static std::mutex g_tuned_b_mu;
 
 static int heuristic_b(int M, int N) {
-    static const int order[] = {9, 5, 0, 10, 12};       // largest tile that still gives every CU >= 2 workgroups' worth of work
+    static const int order[] = {2, 1, 0, 3, 5};       // largest tile that still gives every CU >= 2 workgroups' worth of work
     for (int c : order) {
         const long nb = (long)((M + kCfgsB[c].bm - 1) / kCfgsB[c].bm) * ((N + kCfgsB[c].bn - 1) / kCfgsB[c].bn);
         const long per_cu = (long)kCfgsB[c].bm * kCfgsB[c].bn / (128 * 128);   // 128x128-equivalents per workgroup
         if (nb * per_cu >= 1024) return c;
     }
-    return 12;
+    return 5;
 }
 
 static int tune_shape_b(const GemmParams& p, hipStream_t s) {
@@ -330,7 +298,7 @@ static int tune_shape_b(const GemmParams& p, hipStream_t s) {
     q.C = scratch;            // the residual input is only read: tuning has no side effects on the caller's buffers
     int best = fallback;
     float best_ms = 1e30f;
-    static const int cands_b[] = {0, 5, 9, 10, 11, 12};
+    static const int cands_b[] = {0, 1, 2, 3, 4, 5};
     static const int cands_f8[] = {0, 1, 2, 3, 4, 5};
     for (int ci = 0; ci < 6; ++ci) {
         const int c = f8 ? cands_f8[ci] : cands_b[ci];
@@ -360,7 +328,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
         if (p.fp8 || p.out_bf16) return hipErrorInvalidValue;
         static int forced = [] { const char* e = getenv("FERN_GEMM_X3_CFG"); return e ? atoi(e) : -1; }();
         int c = forced;
-        if (c < 0 || c >= kNumCfgsX3) c = 0;
+        if (c < 0 || c >= kNumCfgsX3) c = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) >= 256 ? 0 : 1;
         return launch_cfg_x3(c, p, s);
     }
     if (p.fp8) {

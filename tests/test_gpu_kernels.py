@@ -358,3 +358,36 @@ def test_gemm_bf16x3_is_fp32_grade(engine, m, n, k, epi):
     assert torch.allclose(got, ref, rtol=1e-5, atol=2e-5)
     err_x3, err_f32 = (got - ref).abs().max().item(), (f32 - ref).abs().max().item()
     assert err_x3 < 4 * err_f32 + 1e-7, (err_x3, err_f32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("var,cfg", [("FERN_GEMM_BF16_CFG", c) for c in range(6)] + [("FERN_GEMM_FP8_CFG", c) for c in range(6)] +
+                         [("FERN_GEMM_X3_CFG", c) for c in range(2)])
+def test_every_reduced_precision_gemm_tile_variant(var, cfg):
+    """The bf16 / fp8 / bf16x3 launchers pick (or tune) a tile per shape; each variant is also forced over its shape suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    key = {"FERN_GEMM_BF16_CFG": "test_gemm_bf16 and not x3", "FERN_GEMM_FP8_CFG": "test_gemm_fp8", "FERN_GEMM_X3_CFG": "test_gemm_bf16x3"}[var]
+    env = dict(os.environ, **{var: str(cfg)})
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "-m", "gpu", "-q", "-x", "-k", key, "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_reduced_precision_gemms_are_batch_invariant(engine):
+    """Every tile shape of the bf16 / fp8 kernels sums the k groups in the same order: a row's bits do not depend on M."""
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(3000, 768, generator=g)
+    w = torch.randn(768, 768, generator=g) * 768 ** -0.5
+    b = torch.randn(768, generator=g)
+    ab, wb = engine.to_bf16(a), engine.to_bf16(w)
+    full = engine.gemm_bf16(ab, wb, b, epilogue=1, out_bf16=True).cpu()
+    a8, sa = engine.quantize_rows_fp8(a)
+    w8, sw = engine.quantize_rows_fp8(w)
+    full8 = engine.gemm_fp8(a8, sa, w8, sw, b, epilogue=0).cpu()
+    for lo, hi in ((0, 1), (0, 64), (100, 1124), (2990, 3000)):
+        assert torch.equal(engine.gemm_bf16(ab[lo:hi].contiguous(), wb, b, epilogue=1, out_bf16=True).cpu(), full[lo:hi])
+        assert torch.equal(engine.gemm_fp8(a8[lo:hi].contiguous(), sa[lo:hi].contiguous(), w8, sw, b, epilogue=0).cpu(), full8[lo:hi])
