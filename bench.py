@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=3, help="64-query batches kept in flight on separate HIP streams")
     ap.add_argument("--precision", choices=["fp32", "bf16", "fp8"], default="fp32",
                     help="encoder operand precision of the TIMED path: fp32 = parity mode (the headline), bf16 = perf mode")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the secondary legs (reduced-precision modes, lookup variant, 1M-row bf16 sweep, encode rate): the GEMM "
+                         "dispatches of the run are then the headline step's, for comparing rocprofv3 averages with `roofline`")
     ap.add_argument("--pmc-mode", action="store_true",
                     help="for `rocprofv3 --pmc`: warm up, emit a marker dispatch, run exactly --steps steps, exit (no JSON)")
     args = ap.parse_args()
@@ -206,7 +209,7 @@ def main():
         return info
 
     bf16_info = fp8_info = None
-    if args.precision == "fp32":
+    if args.precision == "fp32" and not args.headline_only:
         ref_scores, ref_idx = step().wait()
         bf16_info = reduced_precision_leg("bf16", ref_scores, ref_idx)
         fp8_info = reduced_precision_leg("fp8", ref_scores, ref_idx)
@@ -220,16 +223,21 @@ def main():
         step_serial()
     st = eng.prof_collect()
     eng.prof_enable(False)
-    gemm_tflops = st["gemm_flops"] / (st["gemm_ms"] * 1e-3) / 1e12 if st["gemm_ms"] > 0 else 0.0
+    gkey = {"fp32": "gemm", "bf16": "gemm_bf16", "fp8": "gemm_fp8"}[args.precision]      # the dominant GEMM family of this run
+    gemm_tflops = st[gkey + "_flops"] / (st[gkey + "_ms"] * 1e-3) / 1e12 if st[gkey + "_ms"] > 0 else 0.0
+    gemm_peak = F32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
     sweep_gbs = st["sweep_bytes"] / (st["sweep_ms"] * 1e-3) / 1e9 if st["sweep_ms"] > 0 else 0.0
     attn_tflops = st["attn_flops"] / (st["attn_ms"] * 1e-3) / 1e12 if st["attn_ms"] > 0 else 0.0
+    enc_ips = lookup_qps = bf16_us = bf16_gbs = bf16_topk_us = None
+    secondary = not args.headline_only
     # encoder throughput for the gallery side (bounded sample)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(3):
+    for _ in range(3 if secondary else 0):
         eng.encode_image(images)
     torch.cuda.synchronize()
-    enc_ips = 3 * QUERY_BATCH / (time.perf_counter() - t0)
+    if secondary:
+        enc_ips = 3 * QUERY_BATCH / (time.perf_counter() - t0)
 
     # reference-faithful query variant (run/test/test_fiq.py:104-107): the reference image feature is LOOKED UP in the raw
     # gallery index instead of being encoded per query -> text tower + fusion + rank only
@@ -240,32 +248,33 @@ def main():
         qf = eng.dvr_fuse(g_raw[ref_rows], loc, tg, ts)
         return eng.sim_topk(qf, gallery, TOPK)
 
-    for _ in range(3):
-        step_lookup()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_lookup()
-    torch.cuda.synchronize()
-    lookup_qps = QUERY_BATCH * args.steps / (time.perf_counter() - t0)
+    if secondary:
+        for _ in range(3):
+            step_lookup()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_lookup()
+        torch.cuda.synchronize()
+        lookup_qps = QUERY_BATCH * args.steps / (time.perf_counter() - t0)
 
-    # HBM-bound variant of the sweep (BASELINE config 5 "bf16 similarity"): 1M-row bf16 gallery, same 64 queries
-    big_n = 1_000_000
-    gal_big = torch.nn.functional.normalize(torch.randn(big_n, D, device=device, generator=torch.Generator(device=device).manual_seed(3)), dim=-1)
-    gal_bf16 = eng.gallery_to_bf16(gal_big)
-    del gal_big
-    qq = step_serial()      # warm
-    q_unit = torch.nn.functional.normalize(torch.randn(QUERY_BATCH, D, device=device), dim=-1)
-    for _ in range(2):
-        eng.sim_topk_bf16(q_unit, gal_bf16, TOPK)
-    eng.prof_enable(True)
-    for _ in range(5):
-        eng.sim_topk_bf16(q_unit, gal_bf16, TOPK)
-    sb = eng.prof_collect()
-    eng.prof_enable(False)
-    bf16_us = sb["sweep_ms"] / max(1, sb["sweep_launches"]) * 1e3
-    bf16_gbs = sb["sweep_bytes"] / max(1, sb["sweep_launches"]) / (bf16_us * 1e-6) / 1e9 if bf16_us > 0 else 0.0
-    del gal_bf16
+        # HBM-bound variant of the sweep (BASELINE config 5 "bf16 similarity"): 1M-row bf16 gallery, same 64 queries
+        big_n = 1_000_000
+        gal_big = torch.nn.functional.normalize(torch.randn(big_n, D, device=device, generator=torch.Generator(device=device).manual_seed(3)), dim=-1)
+        gal_bf16 = eng.gallery_to_bf16(gal_big)
+        del gal_big
+        q_unit = torch.nn.functional.normalize(torch.randn(QUERY_BATCH, D, device=device), dim=-1)
+        for _ in range(2):
+            eng.sim_topk_bf16(q_unit, gal_bf16, TOPK)
+        eng.prof_enable(True)
+        for _ in range(5):
+            eng.sim_topk_bf16(q_unit, gal_bf16, TOPK)
+        sb = eng.prof_collect()
+        eng.prof_enable(False)
+        bf16_us = sb["sweep_ms"] / max(1, sb["sweep_launches"]) * 1e3
+        bf16_gbs = sb["sweep_bytes"] / max(1, sb["sweep_launches"]) / (bf16_us * 1e-6) / 1e9 if bf16_us > 0 else 0.0
+        bf16_topk_us = sb["topk_ms"] / max(1, sb["topk_launches"]) * 1e3
+        del gal_bf16
 
     result = None
     if rank == 0:
@@ -278,31 +287,33 @@ def main():
                        "query_batch_per_gpu": QUERY_BATCH, "gallery_rows": n_gal, "feature_dim": D, "top_k": TOPK,
                        "image": "3x224x224", "tokens": 77, "patch_feats": 13, "batches_in_flight": args.lanes,
                        "parallelism": f"dp{world} queries, gallery sharded for the build then all-gathered (RCCL)"},
-            "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "gemm_f32_kernel (fp32 MFMA GEMM, all tile variants)",
-                         "gemm_ms_per_step": st["gemm_ms"] / prof_steps, "gemm_gflop_per_step": st["gemm_flops"] / prof_steps / 1e9,
-                         "gemm_launches_per_step": st["gemm_launches"] / prof_steps},
+            "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": gemm_peak, "unit": "TFLOP/s",
+                         "frac": gemm_tflops / gemm_peak, "traffic": None,
+                         "kernel": {"fp32": "gemm_f32_glds_kernel / gemm_f32_kernel (fp32 MFMA GEMM, all tile variants)",
+                                    "bf16": "gemm_bf16_glds_kernel (bf16 MFMA GEMM of the encoder blocks)",
+                                    "fp8": "gemm_bf16_glds_kernel<FP8> (fp8 MFMA GEMM of the encoder blocks)"}[args.precision],
+                         "gemm_ms_per_step": st[gkey + "_ms"] / prof_steps, "gemm_gflop_per_step": st[gkey + "_flops"] / prof_steps / 1e9,
+                         "gemm_launches_per_step": st[gkey + "_launches"] / prof_steps},
             "roofline_sim_sweep": {"bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": None,
                                    "kernel": "gemm_f32_kernel as the cosine sweep inside fern_sim_topk",
                                    "sweep_us": st["sweep_ms"] / max(1, st["sweep_launches"]) * 1e3,
                                    "topk_us": st["topk_ms"] / max(1, st["topk_launches"]) * 1e3},
-            "roofline_sim_sweep_bf16_1M": {"bound": "hbm", "achieved": bf16_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline_sim_sweep_bf16_1M": None if bf16_gbs is None else {"bound": "hbm", "achieved": bf16_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": bf16_gbs / HBM_PEAK_GBS, "traffic": None,
                                            "kernel": "sweep_bf16_kernel: 64 queries x 1M-row bf16 gallery (config 5's similarity mode)",
-                                           "sweep_us": bf16_us, "topk_us": sb["topk_ms"] / max(1, sb["topk_launches"]) * 1e3},
+                                           "sweep_us": bf16_us, "topk_us": bf16_topk_us},
             "encoder_bf16": bf16_info,
             "encoder_fp8": fp8_info,
             "attention": {"achieved_tflops": attn_tflops, "ms_per_step": st["attn_ms"] / prof_steps},
-            "lookup_variant": {"value": lookup_qps * world, "unit": "queries/sec",
+            "lookup_variant": None if lookup_qps is None else {"value": lookup_qps * world, "unit": "queries/sec",
                                "note": "reference-faithful query path (test_fiq.py:104-107): reference features looked up in the index, "
                                        "no per-query image encode; one stream"},
             "gallery_build": {"index_fuse_all_gather_s": gallery_build_s, "rows_per_s": n_gal / gallery_build_s,
                               "encode_images_per_s_per_gpu": enc_ips},
         }
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(traffic_file):      # HBM bytes per launch from a separate `rocprofv3 --pmc` pass of this command
+        if os.path.exists(traffic_file) and args.precision == "fp32":      # HBM bytes per launch from a separate `rocprofv3 --pmc` pass of this command
             tr = json.load(open(traffic_file))
             result["roofline"]["traffic"] = tr.get("gemm", {}).get("hbm_bytes_per_launch")
             result["roofline"]["traffic_source"] = tr.get("source")
