@@ -338,22 +338,17 @@ static int best_of(int M, int N, int first, int last) {
 // Heuristic (used as is for the reduce epilogues and as the fallback of the tuner): large problems stream their tiles
 // with LDS-DMA (configs 8-11: more resident waves, no ds_write pass); small-M problems are latency-bound per block and
 // do better with the register-prefetched 32-wide k tiles (configs 0-3).
-static int choose_cfg(int M, int N, int K, bool reduce = false) {
+static int choose_cfg(int M, int N, int K) {
     const int f = forced_cfg();
-    if (reduce) {
-        // Reduce epilogues sum over columns: only the 128-column-block / 64-column-wave shapes are used (configs 0/1 and
-        // 8/9) so that the column summation order -- and with it every output row -- is independent of M (batch-invariant).
-        const int base = (f >= 8 || (f < 0 && M >= 1024) || (K & 31)) ? 8 : 0;
-        return best_of(M, N, base, base + 2);
-    }
     if (f >= 0 && f < kNumCfgs && kCfgs[f].bk && K % kCfgs[f].bk == 0) return f;
     if (f >= 100) return best_of(M, N, 8, 12);
     return (M >= 1024 || (K & 31)) ? best_of(M, N, 8, 12) : best_of(M, N, 0, kNumAuto);   // K % 32 != 0: only the 16-wide k tiles fit
 }
 
+// Partial sums per row written by the reduce epilogues: one per 32-column group, whatever tile configuration runs.
 int gemm_num_col_blocks(int M, int N, int K) {
-    const int c = choose_cfg(M, N, K, true);
-    return (N + kCfgs[c].bn - 1) / kCfgs[c].bn;
+    (void)M; (void)K;
+    return (N + 31) / 32;
 }
 
 static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
@@ -384,9 +379,9 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
 
 // ---- per-shape tile selection -------------------------------------------------------------------------------------
 // Every configuration accumulates each output element over k in the same order (k pairs (8g+e, 8g+4+e), g ascending),
-// so all of them produce bit-identical results: the choice is purely a speed choice.  Plain (non-reduce) epilogues of
-// large problems are tuned once per shape by timing the candidates on scratch outputs; reduce epilogues keep the
-// heuristic because their partial-sum layout depends on the column-block count the caller sized its buffer for.
+// so all of them produce bit-identical results: the choice is purely a speed choice.  Large problems are tuned once per
+// shape by timing the candidates on scratch outputs -- the reduce epilogues too: their partial sums are laid out per
+// 32-column group, independent of the tile configuration.
 struct ShapeKey {
     int M, N, K, epi, aload;
     bool operator<(const ShapeKey& o) const {
@@ -409,18 +404,21 @@ static bool tuning_enabled() {
 }
 
 static int tune_shape(const GemmParams& p, hipStream_t s) {
-    const int fallback = choose_cfg(p.M, p.N, p.K, false);
+    const int fallback = choose_cfg(p.M, p.N, p.K);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return fallback;
     long out_rows = p.M;
     if (p.epi == EPI_PATCH_EMBED) out_rows = p.M + p.M / (p.grid * p.grid) + 2;
+    const bool reduce = epi_is_reduce(p.epi);
+    const size_t scratch_floats = reduce ? (size_t)p.M * ((p.N + 31) / 32) : (size_t)out_rows * p.ldc;
     float* scratch = nullptr;
-    if (hipMalloc(&scratch, (size_t)out_rows * p.ldc * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fallback; }
+    if (hipMalloc(&scratch, scratch_floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fallback; }
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     GemmParams q = p;
-    q.C = scratch;            // residual input (p.R) is only read: tuning has no side effects on the caller's buffers
+    if (reduce) q.partial = scratch;
+    else q.C = scratch;       // residual input (p.R) is only read: tuning has no side effects on the caller's buffers
     int best = fallback;
     float best_ms = 1e30f;
     static const int cands[] = {0, 1, 2, 3, 8, 9, 10, 11};
@@ -450,8 +448,8 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.aload == ALOAD_CONV3 && (p.conv_c % 16 || p.K != 9 * p.conv_c || !p.zeros || p.M % (p.conv_h * p.conv_w))) return hipErrorInvalidValue;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return hipErrorInvalidValue;
     if (p.aload == ALOAD_IM2COL && ((p.patch & 3) || (p.img & 3))) return hipErrorInvalidValue;
-    int c = choose_cfg(p.M, p.N, p.K, epi_is_reduce(p.epi));
-    const bool tunable = forced_cfg() < 0 && tuning_enabled() && !epi_is_reduce(p.epi) && 2.0 * p.M * (double)p.N * p.K >= 2.5e8;
+    int c = choose_cfg(p.M, p.N, p.K);
+    const bool tunable = forced_cfg() < 0 && tuning_enabled() && 2.0 * p.M * (double)p.N * p.K >= 2.5e8;
     if (tunable) {
         const ShapeKey key{p.M, p.N, p.K, p.epi, p.aload};
         std::lock_guard<std::mutex> lock(g_tuned_mu);

@@ -138,15 +138,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             default: plain_epilogue<EPI_BIAS, false, false>(p, acc, row_w, col_w, l31, lh); break;
         }
     } else {
-        // reduce epilogues: one partial sum per (row, column block); fixed summation order => deterministic
+        // Reduce epilogues: one partial sum per (row, 32-column group) = one MFMA tile row, reduced over the 32 lanes that
+        // hold its columns in a fixed xor tree and written straight from the wave (no LDS staging, no workgroup barrier).
+        // The layout partial[row][N/32] does not depend on the tile configuration, so every configuration produces the same
+        // partials and the finalize kernels add them in the same order: the result is independent of the tile choice and
+        // of M (batch-invariant), and these GEMMs can be tuned per shape like the plain ones.
+        const int ng = (p.N + 31) / 32;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rl = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // row inside the block tile
-                const int row = bm * BM + rl;
+                const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int rowc = row < p.M ? row : p.M - 1;
-                float s = 0.0f;
                 float mu = 0.0f, inv = 1.0f, beta = 0.0f;
                 const float* grow = nullptr;
                 if (p.epi == EPI_SR_LOCAL) {
@@ -157,29 +160,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int col = col_w + j * 32 + l31;
+                    float v = 0.0f;
                     if (col < p.N) {
-                        float v = acc[i][j][r] + p.bias[col];
+                        v = acc[i][j][r] + p.bias[col];
                         if (p.epi == EPI_RELU_DOT) v = fmaxf(v, 0.0f) * p.aux0[col];
                         else v = tanhf((v - mu) * inv + beta) * grow[col] * p.aux0[col];
-                        s += v;
                     }
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 8);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 1);
+                    const int grp = (col_w >> 5) + j;
+                    if (l31 == 0 && row < p.M && grp < ng) p.partial[(long)row * ng + grp] = v;
                 }
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 8);
-                s += __shfl_xor(s, 4);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 1);
-                if (l31 == 0) red[wn][rl] = s;
-            }
-        }
-        __syncthreads();
-        if (tid < BM) {
-            const int row = bm * BM + tid;
-            if (row < p.M) {
-                float s = 0.0f;
-#pragma unroll
-                for (int w = 0; w < WAVES_N; ++w) s += red[w][tid];
-                p.partial[(long)row * nbn + bn] = s;
             }
         }
     }
