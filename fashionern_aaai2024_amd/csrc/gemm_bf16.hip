@@ -189,8 +189,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
 }
 
 struct TileCfgB { int bm, bn, bk; };
-// The tuner's candidates.  Retired after A/B runs on MI355X: 128-byte rows (64-element k tiles), 4-stage rings
-// and 128x64 / 128x128 per-wave tiles -- fewer resident workgroups cost more than the deeper prefetch or the saved LDS reads gain.
+// The tuner's candidates.  Retired after A/B runs on MI355X: 3- and 4-stage rings of the 128x128 tile and
+// 128x64 / 128x128 per-wave tiles -- fewer resident workgroups cost more than the deeper prefetch or the saved LDS reads gain.
 static const TileCfgB kCfgsB[] = {
     {128, 128, 32},   // 0: 4 waves of 64x64, 64-byte rows, 2 stages, 4 workgroups per CU
     {256, 128, 32},   // 1: 8 waves of 64x64, 3 stages
@@ -198,8 +198,9 @@ static const TileCfgB kCfgsB[] = {
     {64, 128, 32},    // 3: 4 waves of 32x64, 2 stages
     {128, 64, 32},    // 4: 4 waves of 64x32, 2 stages
     {64, 64, 32},     // 5: 4 waves of 32x32, 2 stages
+    {128, 128, 64},   // 6: as 0 with 128-byte rows (64-element k tiles): whole 128-byte lines per request, half the barriers, 2 per CU
 };
-constexpr int kNumCfgsB = 6;
+constexpr int kNumCfgsB = 7;
 
 static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsB[c].bm - 1) / kCfgsB[c].bm) * ((p.N + kCfgsB[c].bn - 1) / kCfgsB[c].bn);
@@ -210,6 +211,7 @@ static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
         case 3: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
         case 4: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 64, 64, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
         case 5: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 64, 32, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 6: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -298,10 +300,9 @@ static int tune_shape_b(const GemmParams& p, hipStream_t s) {
     q.C = scratch;            // the residual input is only read: tuning has no side effects on the caller's buffers
     int best = fallback;
     float best_ms = 1e30f;
-    static const int cands_b[] = {0, 1, 2, 3, 4, 5};
-    static const int cands_f8[] = {0, 1, 2, 3, 4, 5};
-    for (int ci = 0; ci < 6; ++ci) {
-        const int c = f8 ? cands_f8[ci] : cands_b[ci];
+    const int ncand = f8 ? kNumCfgsF8 : kNumCfgsB;
+    for (int c = 0; c < ncand; ++c) {
+        if (!f8 && p.K % kCfgsB[c].bk) continue;
         if (launch(c, q, s) != hipSuccess) continue;                       // warm
         (void)hipEventRecord(e0, s);
         (void)launch(c, q, s);

@@ -361,7 +361,7 @@ def test_gemm_bf16x3_is_fp32_grade(engine, m, n, k, epi):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("var,cfg", [("FERN_GEMM_BF16_CFG", c) for c in range(6)] + [("FERN_GEMM_FP8_CFG", c) for c in range(6)] +
+@pytest.mark.parametrize("var,cfg", [("FERN_GEMM_BF16_CFG", c) for c in range(7)] + [("FERN_GEMM_FP8_CFG", c) for c in range(6)] +
                          [("FERN_GEMM_X3_CFG", c) for c in range(2)])
 def test_every_reduced_precision_gemm_tile_variant(var, cfg):
     """The bf16 / fp8 / bf16x3 launchers pick (or tune) a tile per shape; each variant is also forced over its shape suite."""
