@@ -199,7 +199,7 @@ def main():
         overlap = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(ref_idx.cpu(), b_idx.cpu())) / ref_idx.numel()
         info = {"value": world * QUERY_BATCH * args.steps / el, "unit": "queries/sec", "ms_per_step": el / args.steps * 1e3,
                 "dtype": ("bf16" if prec == "bf16" else "fp8 e4m3fn (per-token / per-channel scales)") +
-                         " operands, f32 accumulate (encoder block GEMMs; attention in bf16 operand form)",
+                         " operands, f32 accumulate (encoder block GEMMs; attention and the fusion BERT blocks in bf16 operand form)",
                 "gemm_tflops": tfl, "gemm_peak_tflops": peak, "gemm_frac": tfl / peak, "gemm_ms_per_step": sp[key + "_ms"] / 2,
                 "gemm_f32_ms_per_step": sp["gemm_ms"] / 2, "attention_ms_per_step": sp["attn_ms"] / 2,
                 "vs_fp32_top1_same": float((ref_idx[:, 0] == b_idx[:, 0]).float().mean().item()),

@@ -214,6 +214,8 @@ static int run_attention(fern_ctx* c, const AttnParams& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // weights
 // ------------------------------------------------------------------------------------------------
+static int make_bf16(fern_ctx* c, LinearW* L);
+
 static int upload(fern_ctx* c, const float* h, size_t n, const float** out) {
     float* d = nullptr;
     HIP_TRY(hipMalloc(&d, std::max<size_t>(n, 4) * sizeof(float)));
@@ -420,7 +422,13 @@ extern "C" int fern_finalize_fusion(fern_ctx* c, int D, int parts) {
             FERN_TRY(up_linear(c, lp + ".intermediate.dense", inter, D, &L.inter));
             FERN_TRY(up_linear(c, lp + ".output.dense", D, inter, &L.out));
             FERN_TRY(up_ln(c, lp + ".output.LayerNorm", D, &L.ln2));
+            // bf16 copies for the reduced-precision modes (the fusion BERT blocks follow the towers' bf16 recipe)
+            FERN_TRY(make_bf16(c, &L.qkv));
+            FERN_TRY(make_bf16(c, &L.attn_out));
+            FERN_TRY(make_bf16(c, &L.inter));
+            FERN_TRY(make_bf16(c, &L.out));
         }
+        HIP_TRY(hipStreamSynchronize(nullptr));
         {   // nn.MultiheadAttention packed in-proj: rows [0,D) = q, [D,3D) = k,v
             const float *w, *b;
             FERN_TRY(up_key(c, "DVR.MR_component.in_proj_weight", {3 * D, D}, &w));
@@ -830,8 +838,34 @@ static int dvr_chunk(fern_ctx* c, const float* ref_global, const float* ref_loca
     FERN_TRY(ws_get(c, (size_t)R * inter, &H));
     // PlusModel / BertEmbeddings (fusion_model.py:199-212)
     HIP_TRY(launch_bert_embed(F.cls, ref_local, text_seq, F.type, F.pos, F.emb_ln.g, F.emb_ln.b, X, B, P, T, D, 1e-12f, s));
+    const bool reduced = c->precision != FERN_PREC_FP32;
+    unsigned short* Xb = nullptr;
+    if (reduced) FERN_TRY(ws_get(c, (size_t)R * D, &Xb));
     for (int l = 0; l < 2; ++l) {
         const BertLayerW& L = F.layer[l];
+        if (reduced) {
+            // Reduced-precision modes (bf16 and fp8 alike): the two BERT blocks follow the towers' bf16 recipe -- bf16 operands
+            // on the four token-level GEMMs and the attention, fp32 accumulation, fp32 residual stream and LayerNorm.
+            unsigned short* QKVb = reinterpret_cast<unsigned short*>(QKV);
+            unsigned short* ATTb = reinterpret_cast<unsigned short*>(ATT);
+            unsigned short* Hb = reinterpret_cast<unsigned short*>(H);
+            HIP_TRY(launch_f32_to_bf16(X, Xb, R * D, s));
+            FERN_TRY(run_gemm_b(c, gemm_desc_b(Xb, D, L.qkv, QKVb, 3 * D, (int)R, EPI_BIAS, true), s));
+            AttnParams ab{nullptr, nullptr, nullptr, nullptr, 3L * D, 3L * D, 3L * D, (long)D, B, heads, hd, S, S, 0,
+                          1.0f / std::sqrt((float)hd), ATTb, QKVb, QKVb + D, QKVb + 2 * D};
+            FERN_TRY(run_attention(c, ab, s));
+            GemmParams qo = gemm_desc_b(ATTb, D, L.attn_out, X1, D, (int)R, EPI_BIAS_RESIDUAL, false);
+            qo.R = X;
+            FERN_TRY(run_gemm_b(c, qo, s));
+            HIP_TRY(launch_layernorm(X1, nullptr, L.ln1.g, L.ln1.b, X1, R, D, D, D, 1e-12f, s));
+            HIP_TRY(launch_f32_to_bf16(X1, Xb, R * D, s));
+            FERN_TRY(run_gemm_b(c, gemm_desc_b(Xb, D, L.inter, Hb, inter, (int)R, EPI_BIAS_GELU, true), s));
+            GemmParams q2 = gemm_desc_b(Hb, inter, L.out, X, D, (int)R, EPI_BIAS_RESIDUAL, false);
+            q2.R = X1;
+            FERN_TRY(run_gemm_b(c, q2, s));
+            HIP_TRY(launch_layernorm(X, nullptr, L.ln2.g, L.ln2.b, X, R, D, D, D, 1e-12f, s));
+            continue;
+        }
         FERN_TRY(run_gemm(c, gemm_desc(X, D, L.qkv, QKV, 3 * D, (int)R, EPI_BIAS), s));
         AttnParams a{QKV, QKV + D, QKV + 2 * D, ATT, 3L * D, 3L * D, 3L * D, (long)D, B, heads, hd, S, S, 0, 1.0f / std::sqrt((float)hd)};
         FERN_TRY(run_attention(c, a, s));

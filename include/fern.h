@@ -68,8 +68,9 @@ typedef enum {
  * BF16: in every full transformer block of both towers the QKV / out-proj / c_fc / c_proj contractions (and the last ViT
  * block's K/V projection) read activations and weights rounded to bf16 (RNE) and accumulate in fp32, and the attention
  * of those blocks runs in the bf16 operand form (fern_attention_bf16: q/k/v and the un-normalised softmax weights
- * rounded to bf16, fp32 accumulation); the residual stream, LayerNorm / softmax statistics, GELU, patch embedding,
- * class-token chain of the last ViT block, final projections and the whole fusion / ranking path stay fp32.  Rounding points are fixed by the layer structure, not by
+ * rounded to bf16, fp32 accumulation); the two BERT blocks of the fusion stage (fern_dvr_fuse) follow the same recipe.
+ * The residual streams, LayerNorm / softmax statistics, GELU, patch embedding, class-token chain of the last ViT block,
+ * final projections, cross attention, VisualSR, the combiners and the ranking path stay fp32.  Rounding points are fixed by the layer structure, not by
  * the batch size, so results remain batch-invariant. */
 typedef enum {
     FERN_PREC_FP32 = 0,
@@ -77,7 +78,8 @@ typedef enum {
     /* BASELINE.json config 5 ("fp8 MFMA encoder path"): as BF16, but the four token-level GEMMs of a block (and the last ViT
      * block's K/V projection) take OCP e4m3fn operands on v_mfma_f32_32x32x16_fp8_fp8: one dynamic scale per token row
      * (max|row| / 448, computed where the row is produced) and one static scale per output channel of the weight, both
-     * folded back in the fp32 epilogue; attention stays in the bf16 operand form.  Needs tower / MLP widths % 64 == 0. */
+     * folded back in the fp32 epilogue; attention, and the fusion stage's BERT blocks, stay in the bf16 operand form (fp8 is
+     * for the encoder GEMMs only).  Needs tower / MLP widths % 64 == 0. */
     FERN_PREC_FP8 = 2
 } fern_precision;
 

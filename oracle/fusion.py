@@ -66,13 +66,26 @@ def visual_sr(sd, prefix, local):
     return new_global / norm
 
 
-def bert_encode(sd, prefix, x0, n_type0):
+def _r(x, reduced):
+    """bfloat16 rounding (RNE) carried as fp32: the operand rounding of the product's reduced-precision modes."""
+    return x.bfloat16().float() if reduced else x
+
+
+def bert_encode(sd, prefix, x0, n_type0, precision="fp32"):
     """HF BertModel(inputs_embeds=x0, token_type_ids=[0]*n_type0+[1]*rest, mask=1) -> last_hidden_state.
+
+    ``precision`` "bf16" / "fp8" restate the product's reduced-precision modes (include/fern.h:fern_precision), in which the
+    two BERT blocks follow the towers' bf16 recipe: bf16 operands on query/key/value, attention.output.dense,
+    intermediate.dense and output.dense (activations AND weights rounded, fp32 sums), the packed projection stored as bf16,
+    attention in the bf16 operand form (fp32 scores scaled after the product, un-normalised weights rounded to bf16 for P V,
+    normaliser from the un-rounded weights, output stored as bf16), GELU output stored as bf16; residual stream and
+    LayerNorm in fp32.
 
     Call site fusion_model.py:199-212; config fusion_model.py:162-170 (post-LN, eps 1e-12,
     GELU(erf), absolute positions, intermediate 3072, 8 heads).  The arithmetic itself lives in
     third-party ``transformers`` (pinned 4.30.2, environment.yml:156).
     """
+    red = precision != "fp32"
     b, s, d = x0.shape
     hd = d // BERT_HEADS
     tok = torch.cat((torch.zeros(n_type0, dtype=torch.long), torch.ones(s - n_type0, dtype=torch.long)))
@@ -82,14 +95,23 @@ def bert_encode(sd, prefix, x0, n_type0):
     layer = 0
     while f"{prefix}.encoder.layer.{layer}.attention.self.query.weight" in sd:
         lp = f"{prefix}.encoder.layer.{layer}"
-        q = _lin(sd, lp + ".attention.self.query", x).view(b, s, BERT_HEADS, hd).transpose(1, 2)
-        k = _lin(sd, lp + ".attention.self.key", x).view(b, s, BERT_HEADS, hd).transpose(1, 2)
-        v = _lin(sd, lp + ".attention.self.value", x).view(b, s, BERT_HEADS, hd).transpose(1, 2)
-        p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1)
-        ctx = (p @ v).transpose(1, 2).reshape(b, s, d)
-        x = _ln(sd, lp + ".attention.output.LayerNorm", _lin(sd, lp + ".attention.output.dense", ctx) + x, 1e-12)
-        h = F.gelu(_lin(sd, lp + ".intermediate.dense", x))
-        x = _ln(sd, lp + ".output.LayerNorm", _lin(sd, lp + ".output.dense", h) + x, 1e-12)
+
+        def lin(name, inp):
+            return F.linear(_r(inp, red), _r(sd[lp + name + ".weight"], red), sd[lp + name + ".bias"])
+
+        q = _r(lin(".attention.self.query", x), red).view(b, s, BERT_HEADS, hd).transpose(1, 2)
+        k = _r(lin(".attention.self.key", x), red).view(b, s, BERT_HEADS, hd).transpose(1, 2)
+        v = _r(lin(".attention.self.value", x), red).view(b, s, BERT_HEADS, hd).transpose(1, 2)
+        if red:
+            att = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(hd))
+            e = torch.exp(att - att.max(dim=-1, keepdim=True).values)
+            ctx = _r(((_r(e, True) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(b, s, d), True)
+        else:
+            p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1)
+            ctx = (p @ v).transpose(1, 2).reshape(b, s, d)
+        x = _ln(sd, lp + ".attention.output.LayerNorm", lin(".attention.output.dense", ctx) + x, 1e-12)
+        h = _r(F.gelu(lin(".intermediate.dense", x)), red)
+        x = _ln(sd, lp + ".output.LayerNorm", lin(".output.dense", h) + x, 1e-12)
         layer += 1
     return x
 
@@ -112,15 +134,16 @@ def mha_forward(sd, prefix, query, key, value, heads=MHA_HEADS):
     return _lin(sd, prefix + ".out_proj", o)
 
 
-def dvr_fuse(sd, ref_patch, text_seq, ref_global, text_global, prefix="DVR"):
-    """DVR_module.forward -- fusion_model.py:26-55 (= ERN mode="test", models/model.py:68-69)."""
+def dvr_fuse(sd, ref_patch, text_seq, ref_global, text_global, prefix="DVR", precision="fp32"):
+    """DVR_module.forward -- fusion_model.py:26-55 (= ERN mode="test", models/model.py:68-69).  ``precision``: see bert_encode
+    (only the two BERT blocks change; cross attention, VisualSR and the combiners are fp32 in every mode)."""
     b, p, d = ref_patch.shape
     tl = prefix + ".transformer_layer"
     cls = sd.get(tl + ".cls_token")                  # absent in GPU-trained checkpoints -> zeros (SURVEY 5)
     if cls is None:
         cls = torch.zeros(1, 1, d)
     x0 = torch.cat((cls.expand(b, -1, -1), ref_patch, text_seq), dim=1)             # :199-201
-    hidden = bert_encode(sd, tl + ".bert_encoder.bert_model", x0, p + 1)            # :202-212
+    hidden = bert_encode(sd, tl + ".bert_encoder.bert_model", x0, p + 1, precision)  # :202-212
     img = F.normalize(hidden[:, 1:p + 1], dim=2)                                    # :38,40
     txt = F.normalize(hidden[:, p + 1:], dim=2)                                     # :39,41
     cross = mha_forward(sd, prefix + ".MR_component", txt, img, img)[:, :p]         # :44-47

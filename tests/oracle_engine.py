@@ -47,7 +47,8 @@ class OracleEngine:
         return (g if want_global else None), (s if want_seq else None)
 
     def dvr_fuse(self, ref_global, ref_local, text_global, text_seq):
-        return ofusion.dvr_fuse(self.sd, ref_local.float().cpu(), text_seq.float().cpu(), ref_global.float().cpu(), text_global.float().cpu())
+        return ofusion.dvr_fuse(self.sd, ref_local.float().cpu(), text_seq.float().cpu(), ref_global.float().cpu(), text_global.float().cpu(),
+                                precision=self.precision)
 
     def index_fuse(self, tar_feats, tar_local, normalize_input=False):
         tf = tar_feats.float().cpu()

@@ -298,3 +298,28 @@ def test_fp8_precision_needs_widths_that_are_multiples_of_64():
         with pytest.raises(FernError, match="multiples of 64"):
             eng.set_precision("fp8")
     eng.close()
+
+
+@pytest.mark.parametrize("d,b,t", [(128, 5, 77), (512, 9, 77), (640, 6, 77), (128, 3, 40)])
+def test_dvr_fuse_reduced_precision(d, b, t):
+    """In the reduced-precision modes (bf16 and fp8 alike) the two fusion BERT blocks run with bf16 operands / fp32
+    accumulation and bf16 attention; cross attention, VisualSR and the combiners stay fp32.  (1) against the oracle's
+    restatement of the same rounding points; (2) against the fp32 statement, to state what the mode costs."""
+    eng, sd = fusion_engine(d)
+    rg, rl = _t(synth.global_feats(b, d, tag="rg")), _t(synth.local_feats(b, d, tag="rl"))
+    tg = _t(synth.global_feats(b, d, tag="tg"))
+    ts = _t(synth._normal(42, f"tseq/{d}", (b, t, d)))
+    fp32 = eng.dvr_fuse(rg, rl, tg, ts)
+    ref_b = ofusion.dvr_fuse(sd, rl, ts, rg, tg, precision="bf16")
+    ref_f = ofusion.dvr_fuse(sd, rl, ts, rg, tg)
+    try:
+        for prec in ("bf16", "fp8"):
+            eng.set_precision(prec)
+            got = eng.dvr_fuse(rg, rl, tg, ts)
+            assert torch.equal(eng.dvr_fuse(rg[1:2], rl[1:2], tg[1:2], ts[1:2]), got[1:2])      # batch-invariant
+            assert _maxerr(got, ref_b) < 5e-4                                                    # unit-norm features
+            assert _maxerr(got, ref_f) < 1e-2 and not torch.equal(got, fp32)
+            assert abs(got.norm(dim=1).cpu() - 1).max().item() < 1e-5
+    finally:
+        eng.set_precision("fp32")
+    assert torch.equal(eng.dvr_fuse(rg, rl, tg, ts), fp32)
