@@ -449,7 +449,10 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return hipErrorInvalidValue;
     if (p.aload == ALOAD_IM2COL && ((p.patch & 3) || (p.img & 3))) return hipErrorInvalidValue;
     int c = choose_cfg(p.M, p.N, p.K);
-    const bool tunable = forced_cfg() < 0 && tuning_enabled() && 2.0 * p.M * (double)p.N * p.K >= 2.5e8;
+    // tuned: problems big enough to matter and small enough that ~30 trial launches are cheap (beyond ~0.2 TFLOP per launch
+    // -- the gallery-side GEMMs over tens of thousands of rows -- every candidate fills the chip and the heuristic is used)
+    const double flops = 2.0 * p.M * (double)p.N * p.K;
+    const bool tunable = forced_cfg() < 0 && tuning_enabled() && flops >= 2.5e8 && flops <= 2e11;
     if (tunable) {
         const ShapeKey key{p.M, p.N, p.K, p.epi, p.aload};
         std::lock_guard<std::mutex> lock(g_tuned_mu);

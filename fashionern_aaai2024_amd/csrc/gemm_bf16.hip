@@ -349,7 +349,8 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     }
     int c = forced_cfg_b();
     if (c < 0 || c >= kNumCfgsB || p.K % kCfgsB[c].bk) {
-        if (2.0 * p.M * (double)p.N * p.K >= 2.5e8) {
+        const double flops = 2.0 * p.M * (double)p.N * p.K;
+        if (flops >= 2.5e8 && flops <= 1.6e12) {
             const ShapeKeyB key{p.M, p.N, p.K, p.epi, p.out_bf16};
             std::lock_guard<std::mutex> lock(g_tuned_b_mu);
             auto it = g_tuned_b.find(key);
