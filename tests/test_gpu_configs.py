@@ -283,3 +283,44 @@ def test_c5_fp8_encoder_with_bf16_similarity_end_to_end():
     for row, col in zip(*np.nonzero((i.cpu() != ri).numpy())):
         assert abs(full[row, i[row, col].item()].item() - full[row, ri[row, col]].item()) < 2e-6
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_full_step_is_hipgraph_capturable_in_reduced_precision(precision):
+    """encode -> fuse -> rank of the tiny-hd64 towers in a reduced-precision mode: after a warm-up call (workspaces, bf16 / fp8
+    tile tuning) the whole step only enqueues kernels and replays from a hipGraph with identical results."""
+    cfg = synth.CLIP_CONFIGS["tiny-hd64"]
+    d = cfg.embed_dim
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(synth.clip_state_dict(cfg, seed=2))
+    eng.finalize_clip(cfg)
+    eng.load_tensors(synth.fusion_state_dict(d, seed=3))
+    eng.finalize_fusion(d)
+    eng.set_precision(precision)
+    b = 6
+    imgs = torch.from_numpy(synth.images(b, cfg, 1)).cuda()
+    toks = torch.from_numpy(synth.captions(b, cfg, 1)).cuda()
+    loc = torch.from_numpy(synth.local_feats(b, d, 1)).cuda()
+    gal = torch.nn.functional.normalize(torch.randn(2000, d, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4)), dim=-1)
+
+    def step():
+        tg, ts = eng.encode_text(toks)
+        q = eng.dvr_fuse(eng.encode_image(imgs), loc, tg, ts)
+        return eng.sim_topk(q, gal, 50)
+
+    ref_s, ref_i = step()
+    step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_s, out_i = step()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_i, ref_i) and torch.equal(out_s, ref_s)
+    imgs.mul_(-1.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    exp_s, exp_i = step()
+    assert torch.equal(out_i, exp_i) and torch.equal(out_s, exp_s)
+    eng.close()
