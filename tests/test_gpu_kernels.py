@@ -201,7 +201,7 @@ def test_topk_large_gallery_many_segments(engine):
     assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 8, 9, 10, 11])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 6, 8, 9, 10, 11])
 def test_every_gemm_tile_variant_passes_the_shape_suite(cfg):
     """The launcher autotunes the tile per shape, so each variant is also forced (FERN_GEMM_CFG, read once per process) over
     the whole GEMM shape / epilogue suite, incl. the integer-exactness test: all variants must agree bit for bit."""
@@ -391,3 +391,25 @@ def test_reduced_precision_gemms_are_batch_invariant(engine):
     for lo, hi in ((0, 1), (0, 64), (100, 1124), (2990, 3000)):
         assert torch.equal(engine.gemm_bf16(ab[lo:hi].contiguous(), wb, b, epilogue=1, out_bf16=True).cpu(), full[lo:hi])
         assert torch.equal(engine.gemm_fp8(a8[lo:hi].contiguous(), sa[lo:hi].contiguous(), w8, sw, b, epilogue=0).cpu(), full8[lo:hi])
+
+
+@pytest.mark.gpu
+def test_small_m_16x16_kernel_is_bit_identical_to_the_32x32_kernels(tmp_path):
+    """The small-M kernel (v_mfma_f32_16x16x4_f32, config 6) adds every output's products in the same order as the 32x32
+    kernels: plain GEMMs of every epilogue kind and the fused combiner (reduce epilogue) must match BIT FOR BIT, whichever
+    kernel the launcher is forced to (FERN_GEMM_CFG is read once per process, hence the two subprocesses)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for cfg in ("6", "3", "11"):
+        path = str(tmp_path / f"dump_{cfg}.npz")
+        env = dict(os.environ, FERN_GEMM_CFG=cfg)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_gemm_dump.py"), path], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    for other in outs[1:]:
+        assert sorted(outs[0].files) == sorted(other.files)
+        for k in outs[0].files:
+            assert np.array_equal(outs[0][k].view(np.uint32), other[k].view(np.uint32)), k

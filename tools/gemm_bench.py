@@ -16,6 +16,7 @@ SHAPES = {
     "fusion": [(5824, 3072, 512, 1), (5824, 512, 3072, 3), (5824, 1536, 512, 0), (64, 4096, 4096, 2), (64, 2048, 512, 2),
                (64, 46000, 512, 0), (832, 512, 512, 0)],
     "big": [(4096, 4096, 4096, 0), (8192, 8192, 1024, 0)],
+    "stride": [(64, 4096, 4096, 2), (64, 4096, 4032, 2), (64, 4096, 4160, 2), (64, 4096, 3072, 2), (64, 4096, 2048, 2)],
     "gelu": [(12608, 3072, 768, 0), (12608, 3072, 768, 1), (12608, 3072, 768, 2)],
     "ab": [(12608, 2304, 768, 0), (12608, 3072, 768, 1), (8192, 8192, 1024, 0)],
 }
