@@ -179,3 +179,44 @@ def test_precision_option_of_the_clip_surface_and_oracle_bf16_restatement():
         create_model("tiny-resnet", device="cpu", seed=1, engine=OracleEngine(), precision="bf16")
     with pytest.raises(ValueError):
         clip.engine.set_precision("int4")
+
+
+def test_builtin_clip_bpe_tokenizer_on_a_synthetic_merge_table(tmp_path, monkeypatch):
+    """ClipBpeTokenizer restates the published CLIP byte-level BPE (vocabulary file not available offline: parity unpinned);
+    its algorithmic behaviour is checked on a small merge table: rank order, every-occurrence merging, end-of-word marks,
+    lower-casing / whitespace collapse, framing, padding and truncation."""
+    import gzip
+    from fashionern_aaai2024_amd.tokenizer import ClipBpeTokenizer, _byte_alphabet
+    import fashionern_aaai2024_amd.tokenizer as tk
+    merges = [("r", "e"), ("re", "d</w>"), ("d", "re"), ("s", "s</w>"), ("dre", "ss</w>"), ("l", "o"), ("n", "g</w>"), ("lo", "ng</w>")]
+    tok = ClipBpeTokenizer(merges)
+    alpha = list(_byte_alphabet().values())
+    assert len(set(alpha)) == 256 and tok.vocab_size == 512 + len(merges) + 2
+    assert tok.sot == tok.vocab_size - 2 and tok.eot == tok.vocab_size - 1
+    enc = tok.encoder
+    # "red" -> r e d</w> -> (r,e) rank 0 -> re d</w> -> (re, d</w>) rank 1 -> "red</w>"
+    assert tok.encode("red") == [enc["red</w>"]]
+    # "dress": (r,e) first (rank 0) -> d re s s</w>; then (d,re) rank 2 -> dre s s</w>; (s,s</w>) rank 3; (dre,ss</w>) rank 4
+    assert tok.encode("Dress") == [enc["dress</w>"]]
+    # unknown pairs stay as single symbols; the last symbol of a word carries the end-of-word mark
+    assert tok.encode("ab") == [enc["a"], enc["b</w>"]]
+    # punctuation is its own piece, whitespace collapses, html entities are unescaped
+    assert tok.encode("  long   &amp; red!") == [enc["long</w>"], enc["&</w>"], enc["red</w>"], enc["!</w>"]]
+    # a repeated pair inside one word is merged at every occurrence in the same pass
+    assert tok.encode("rere") == [enc["re"], enc["r"], enc["e</w>"]]      # (r, e</w>) is not a ranked pair
+    assert tok.encode("rered") == [enc["re"], enc["red</w>"]]              # both (r, e) merged in one pass, then (re, d</w>)
+    t = tok(["red dress", "long " * 100], context_length=12)
+    assert t.dtype == torch.int64 and tuple(t.shape) == (2, 12)
+    assert t[0].tolist() == [tok.sot, enc["red</w>"], enc["dress</w>"], tok.eot] + [0] * 8
+    assert t[1, 0] == tok.sot and t[1, -1] == tok.eot and (t[1, 1:-1] == enc["long</w>"]).all()      # truncated, end token kept
+    assert int(t[0].argmax()) == 3                                                                     # EOT is the largest id
+    # file form (header line + one merge per line, optionally gzipped) and the FERN_CLIP_BPE_VOCAB hook of get_tokenizer
+    path = tmp_path / "bpe.txt.gz"
+    with gzip.open(path, "wt", encoding="utf-8") as f:
+        f.write("#version: test\n" + "\n".join(" ".join(m) for m in merges) + "\n")
+    assert ClipBpeTokenizer(str(path)).encode("Long dress") == tok.encode("long dress")
+    monkeypatch.setenv("FERN_CLIP_BPE_VOCAB", str(path))
+    monkeypatch.setitem(tk._REGISTRY, "placeholder", None)
+    got = tk.get_tokenizer("some-unregistered-model")
+    assert isinstance(got, ClipBpeTokenizer) and got("red").shape == (1, 77)
+    tk._REGISTRY.pop("some-unregistered-model", None)
