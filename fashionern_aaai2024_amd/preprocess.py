@@ -196,3 +196,14 @@ def load_patch_features(path: str) -> torch.Tensor:
     if t.dim() != 2 or t.shape[0] != 13:
         raise ValueError(f"{path}: expected a [13, D] tensor, got {tuple(t.shape)}")
     return t.float()
+
+
+def gpu_preprocess(engine: FernEngine, target_ratio: float = 1.25, dim: int = 288):
+    """``PIL.Image -> [3, dim, dim] f32`` (CPU tensor, so that the DataLoader can collate and pin it) running TargetPad /
+    Resize(BICUBIC) / CenterCrop / ToTensor / Normalize on the GPU: the callable the dataset classes take as ``preprocess``
+    (the reference passes ``targetpad_transform(target_ratio, dim)``, dataloader/dataset.py:73-87).  Image *decoding* stays
+    with PIL on the host.  Use with ``num_workers=0`` (the HIP context lives in this process)."""
+    def run(image):
+        arr = torch.from_numpy(np.array(image.convert("RGB"), dtype=np.uint8)).to(engine.device)
+        return targetpad_transform(engine, arr, target_ratio, dim).cpu()
+    return run

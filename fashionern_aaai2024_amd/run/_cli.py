@@ -1,9 +1,10 @@
 """``python -m fashionern_aaai2024_amd.run.test_fiq ...``: the reference drivers' flags (test_fiq.py:127-136) on this path.
 
-The reference's dataset classes and image preprocessing (dataloader/*.py) are the next row of the scope table
- and the datasets themselves are not available offline, so the driver evaluates a seeded
-synthetic dataset of the same tuple format (``--synthetic-gallery N --synthetic-queries Q``) with random-init or
-user-supplied (``--clip-path`` / ``--fusion-model-path``) weights, and prints the reference's summary lines."""
+The datasets themselves are not available offline, so by default the driver evaluates a seeded synthetic dataset of the same
+tuple format (``--synthetic-gallery N --synthetic-queries Q``) with random-init or user-supplied (``--clip-path`` /
+``--fusion-model-path``) weights, and prints the reference's summary lines.  With ``--data-root DIR`` it reads the real
+layouts instead through ``fashionern_aaai2024_amd.dataloader`` (fashion-iq/..., cirr_dataset/..., shoes: SURVEY.md 8f rank 3),
+preprocessing images on the GPU (``preprocess.gpu_preprocess``) and tokenising with ``tokenizer.get_tokenizer``."""
 from __future__ import annotations
 
 import zlib
@@ -81,6 +82,24 @@ def synthetic_split(kind, cfg, d, n, q, seed):
     return _Classic(names, images, local), _Relative(items)
 
 
+def file_splits(kind, args, clip_model):
+    """[(label, classic_dataset, relative_dataset)] read from --data-root in the reference's directory layouts."""
+    from ..dataloader import CIRRDataset, FashionIQDataset, ShoesDataset
+    from ..preprocess import gpu_preprocess
+    pre = gpu_preprocess(clip_model.engine, args.target_ratio, args.input_dim)
+    root = args.data_root
+    if kind in ("fiq", "val"):
+        local_dir = "fashioniq_13_vit_2b" if args.clip_model_name.startswith("ViT") else "fashion_local13"      # fashioniq.py:64,174
+        return [(t, FashionIQDataset("val", [t], "classic", pre, base_path=root, local_dir=local_dir),
+                 FashionIQDataset("val", [t], "relative", pre, base_path=root, local_dir=local_dir)) for t in ("dress", "toptee", "shirt")]
+    if kind == "cirr":
+        return [("cirr", CIRRDataset("val", "classic", pre, base_path=root), CIRRDataset("val", "relative", pre, base_path=root))]
+    if kind == "shoes":
+        sp = root if root.endswith("/") else root + "/"
+        return [("shoes", ShoesDataset("test", "classic", pre, shoes_path=sp), ShoesDataset("test", "relative", pre, shoes_path=sp))]
+    raise SystemExit("--data-root: no file-backed dataset class for Fashion200k in this build (use the synthetic split)")
+
+
 def main(kind: str) -> None:
     p = ArgumentParser()
     p.add_argument("--dataset", default={"fiq": "fashionIQ", "val": "fashionIQ", "cirr": "CIRR", "shoes": "shoes", "200k": "fashion200k"}[kind], type=str)
@@ -96,6 +115,8 @@ def main(kind: str) -> None:
     p.add_argument("--synthetic-gallery", default=2000, type=int)
     p.add_argument("--synthetic-queries", default=256, type=int)
     p.add_argument("--seed", default=42, type=int)
+    p.add_argument("--data-root", type=str, default=None,
+                   help="directory holding fashion-iq/ (fiq, val), cirr_dataset/ (cirr) or the shoes files (shoes); default: synthetic data")
     p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp8"],
                    help="encoder operand precision: fp32 = the reference's arithmetic; bf16 / fp8 = perf modes (ViT / text towers)")
     args = p.parse_args()
@@ -107,7 +128,8 @@ def main(kind: str) -> None:
     cfg = clip_model.cfg
     if cfg.embed_dim != args.feature_dim or cfg.image_size != args.input_dim:
         raise SystemExit(f"--feature-dim/--input-dim do not match {cfg.name} ({cfg.embed_dim}/{cfg.image_size})")
-    register_tokenizer(args.clip_model_name, hash_tokenizer(cfg.vocab_size))
+    if not args.data_root:
+        register_tokenizer(args.clip_model_name, hash_tokenizer(cfg.vocab_size))      # real data: open_clip / FERN_CLIP_BPE_VOCAB / registered
     model = ERN(clip_model, args.feature_dim, device)
     if args.fusion_model_path:
         model.load_state_dict(torch.load(args.fusion_model_path, map_location="cpu"))
@@ -117,11 +139,15 @@ def main(kind: str) -> None:
     fn = {"fiq": test_fiq.compute_fiq_val_metrics, "val": test_val.compute_fiq_val_metrics, "cirr": test_cirr.compute_cirr_val_metrics,
           "shoes": test_shoes.compute_shoes_val_metrics, "200k": test_200k.compute_200k_val_metrics}[kind]
     splits = ["dress", "toptee", "shirt"] if kind in ("fiq", "val") else [kind]
+    if args.data_root:
+        triples = file_splits(kind, args, clip_model)
+    else:
+        triples = [(split,) + synthetic_split(kind, cfg, args.feature_dim, args.synthetic_gallery, args.synthetic_queries, args.seed + i)
+                   for i, split in enumerate(splits)]
     results = []
-    for i, split in enumerate(splits):
-        classic, relative = synthetic_split(kind, cfg, args.feature_dim, args.synthetic_gallery, args.synthetic_queries, args.seed + i)
+    for split, classic, relative in triples:
         feats, names, local = extract_index_features(classic, clip_model, args.patch_num, device, args.feature_dim,
-                                                     num_workers=args.num_workers)
+                                                     num_workers=0 if args.data_root else args.num_workers)
         res = fn(relative, clip_model, feats, local, names, model, device, args.feature_dim, args.batch_size, args.num_workers,
                  args.clip_model_name)
         print(split, "recalls:", res)

@@ -119,3 +119,65 @@ class RelativeDataset(Dataset):
 
     def __getitem__(self, i):
         return self.items[i]
+
+
+# ---- a synthetic directory tree in the reference's dataset layouts (dataloader/fashioniq.py, cirr.py, shoes.py) -----------
+def _write_image(path, seed):
+    import os
+    from PIL import Image
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    rng = np.random.default_rng(seed)
+    Image.fromarray(rng.integers(0, 256, size=(40, 30, 3), dtype=np.uint8)).save(path)
+
+
+def _write_local(path, seed, d):
+    import os
+    from fashionern_aaai2024_amd import synth
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save(torch.from_numpy(synth._normal(seed, "loc", (13, d))), path)
+
+
+def write_dataset_tree(root, d, local_dir="fashion_local13"):
+    """fashion-iq/, cirr_dataset/ and shoes/ under `root` with 12 / 14 / 10 images, their [13, d] local features and the JSON files."""
+    import json
+    import os
+    root = str(root)
+    fiq = os.path.join(root, "fashion-iq")
+    for sub in ("captions", "image_splits"):
+        os.makedirs(os.path.join(fiq, sub), exist_ok=True)
+    for ti, t in enumerate(("dress", "shirt", "toptee")):
+        names = [f"{t}{i:03d}" for i in range(12)]
+        for i, n in enumerate(names):
+            _write_image(os.path.join(fiq, "images", f"{n}.png"), 100 * ti + i)
+            _write_local(os.path.join(fiq, local_dir, f"{n}.pth"), 100 * ti + i, d)
+        trips = [{"candidate": names[i], "target": names[(i * 5 + 3) % 12], "captions": [f"is more {t} like.", "has longer sleeves?"]}
+                 for i in range(8)]
+        for split in ("val", "train", "test"):
+            json.dump(trips, open(os.path.join(fiq, "captions", f"cap.{t}.{split}.json"), "w"))
+            json.dump(names, open(os.path.join(fiq, "image_splits", f"split.{t}.{split}.json"), "w"))
+    cirr = os.path.join(root, "cirr_dataset")
+    os.makedirs(os.path.join(cirr, "cirr", "captions"), exist_ok=True)
+    os.makedirs(os.path.join(cirr, "cirr", "image_splits"), exist_ok=True)
+    cnames = [f"dev-{i}-img" for i in range(14)]
+    for i, n in enumerate(cnames):
+        _write_image(os.path.join(cirr, "dev", f"{n}.png"), 500 + i)
+        _write_local(os.path.join(cirr, "cirr_local_13", f"{n}.pth"), 500 + i, d)
+    ctrips = []
+    for i in range(9):
+        ref, tgt = cnames[i], cnames[(i + 4) % 14]
+        members = [ref] + [cnames[(i + 4 + k) % 14] for k in range(5)]      # 6 members: the reference and five others incl. the target
+        ctrips.append({"pairid": i, "reference": ref, "target_hard": tgt, "caption": f"make it number {i}", "img_set": {"members": members}})
+    for split in ("val", "test1", "train"):
+        json.dump(ctrips, open(os.path.join(cirr, "cirr", "captions", f"cap.rc2.{split}.json"), "w"))
+        json.dump({n: f"./dev/{n}.png" for n in cnames}, open(os.path.join(cirr, "cirr", "image_splits", f"split.rc2.{split}.json"), "w"))
+    shoes = os.path.join(root, "shoes")
+    os.makedirs(shoes, exist_ok=True)
+    rels = [f"womens_athletic_shoes/{i}/img_womens_athletic_shoes_{i}.jpg" for i in range(10)]
+    for i, r in enumerate(rels):
+        _write_image(os.path.join(shoes, r), 900 + i)
+        _write_local(os.path.join(shoes, "shoes_local_feature_13", r.split("/")[-1].split(".jpg")[0] + ".pth"), 900 + i, d)
+    ann = [{"ImageName": rels[(i + 3) % 10], "ReferenceImageName": rels[i], "RelativeCaption": f"are less shiny {i}"} for i in range(7)]
+    for split in ("test", "train"):
+        json.dump(rels, open(os.path.join(shoes, f"split.{split}.json"), "w"))
+        json.dump(ann, open(os.path.join(shoes, f"triplet.{split}.json"), "w"))
+    return root

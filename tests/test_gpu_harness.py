@@ -222,3 +222,25 @@ def test_batch_classification_loss_and_train_mode_match_the_reference():
     assert (fusion.cpu() - torch.from_numpy(z["train_fusion"])).abs().max() < 5e-5
     assert (target.cpu() - torch.from_numpy(z["train_target"])).abs().max() < 5e-5
     assert abs(crit(fusion, target).item() - float(z["train_loss"])) < 5e-3
+
+
+def test_cli_driver_reads_real_layouts_from_data_root(tmp_path):
+    """`python -m ...run.test_fiq/test_cirr/test_shoes --data-root DIR`: the file-backed dataset classes, GPU preprocessing of
+    decoded images (TargetPad / bicubic / crop / normalise kernels), the built-in BPE tokenizer (FERN_CLIP_BPE_VOCAB) and the
+    HIP engine, end to end on a synthetic directory tree in the reference's layouts."""
+    import gzip
+    import subprocess
+    import sys
+    cfg = synth.CLIP_CONFIGS["tiny"]
+    root = sdata.write_dataset_tree(tmp_path / "data", cfg.embed_dim)
+    vocab = tmp_path / "bpe.txt.gz"
+    with gzip.open(vocab, "wt", encoding="utf-8") as f:
+        f.write("#version: test\n" + "\n".join(["l o", "lo n", "lon g</w>", "r e", "m o", "mo re</w>"]) + "\n")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FERN_CLIP_BPE_VOCAB=str(vocab))
+    common = ["--clip-model-name", "tiny", "--feature-dim", str(cfg.embed_dim), "--input-dim", str(cfg.image_size), "--batch-size", "4"]
+    for mod, data_root, marker in (("test_fiq", root, "R@10:"), ("test_cirr", root, "Average:"), ("test_shoes", os.path.join(root, "shoes"), "R@10:")):
+        r = subprocess.run([sys.executable, "-m", f"fashionern_aaai2024_amd.run.{mod}", "--data-root", data_root] + common,
+                           cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert marker in r.stdout and "recalls:" in r.stdout, r.stdout[-500:]
