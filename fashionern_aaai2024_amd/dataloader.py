@@ -1,6 +1,7 @@
 """File-backed dataset classes with the tuple formats the harness consumes.
 
-Counterparts of /root/reference/dataloader/{fashioniq.py:10-110, cirr.py:7-102, shoes.py:11-61}: same constructor arguments,
+Counterparts of /root/reference/dataloader/{fashioniq.py:10-110, cirr.py:7-102, shoes.py:11-61} and the evaluation classes of
+fashion200k_patch.py (:238-405): same constructor arguments,
 same directory layouts and JSON schemas, same ``(mode, split)`` -> tuple table; the root directories are arguments here (the
 reference hard-codes "./" and an absolute /mnt path).  Evaluation splits are covered (``val`` / ``test`` / ``test1`` and the
 ``classic`` gallery mode); ``train`` tuples are provided for completeness.  Like the reference, an item that cannot be read
@@ -183,3 +184,93 @@ class ShoesDataset(_FileDataset):
 
     def __len__(self):
         return len(self.annotations) if self.mode == "relative" else len(self.image_id2name)
+
+
+# ---- Fashion200k (evaluation side) ---------------------------------------------------------------------------------------
+def caption_post_process(s: str) -> str:
+    """fashion200k_patch.py:52-54: captions double as retrieval ids, so the marks that would not survive as names are spelled out."""
+    return s.strip().replace(".", "dotmark").replace("?", "questionmark").replace("&", "andmark").replace("*", "starmark")
+
+
+def get_different_word(source_caption: str, target_caption: str):
+    """fashion200k_patch.py:39-49: the modification text of a test query, "replace <a> with <b>": <a> is the first source word
+    missing from the target caption, <b> the first target word missing from the source caption -- and, as in the reference's
+    loops, the LAST word of the respective caption when no such word exists."""
+    source_words, target_words = source_caption.split(), target_caption.split()
+    source_word = next((w for w in source_words if w not in target_words), source_words[-1])
+    target_word = next((w for w in target_words if w not in source_words), target_words[-1])
+    return source_word, target_word, "replace " + source_word + " with " + target_word
+
+
+class _Fashion200kBase(_FileDataset):
+    """<root>/labels/*_<split>_*.txt: tab-separated ``relative image path, <unused>, caption`` lines (fashion200k_patch.py:299-313);
+    local features at the image path with "women" replaced by ``local_dir`` plus ".pth" (:290; ``fashion200k_13_patch`` for the
+    RN50 variant, :451).  ``split="val"`` reads the test files, as in the reference (:243-244)."""
+
+    def __init__(self, root_path: str, split: str = "test", img_transform: Optional[Callable] = None, text_transform: Optional[Callable] = None,
+                 local_dir: str = "local_features", strict: bool = False):
+        import glob
+        self.root_path, self.split = root_path, ("test" if split == "val" else split)
+        self.preprocess, self.text_transform, self.local_dir, self.strict = img_transform, text_transform, local_dir, strict
+        self.imgs: List[dict] = []
+        for label_file in sorted(glob.glob(os.path.join(root_path, "labels", "*_" + self.split + "_*.txt"))):
+            with open(label_file, "r", encoding="utf8") as fd:
+                for line in fd.readlines():
+                    cols = line.split("\t")
+                    self.imgs.append({"file_path": cols[0], "captions": [caption_post_process(cols[2])], "modifiable": False})
+
+    def _local(self, img_path: str) -> torch.Tensor:
+        return _load_feature(img_path.replace("women", self.local_dir) + ".pth")
+
+    def _rgb(self, img_path: str):
+        import PIL.Image
+        with open(img_path, "rb") as f:
+            img = PIL.Image.open(f).convert("RGB")
+        return self.preprocess(img) if self.preprocess is not None else img
+
+
+class Fashion200kTestDataset(_Fashion200kBase):
+    """Gallery: ``(img_id, image, local_feature)`` with ``img_id`` = the post-processed first caption (fashion200k_patch.py:282-293):
+    several images share an id, recall counts any of them (run/test/test_200k.py:54-60)."""
+
+    def _item(self, idx):
+        img = self.imgs[idx]
+        path = os.path.join(self.root_path, img["file_path"])
+        return caption_post_process(img["captions"][0]), self._rgb(path), self._local(path)
+
+    def __len__(self):
+        return len(self.imgs)
+
+
+class Fashion200kTestQueryDataset(_Fashion200kBase):
+    """Queries from <root>/test_queries.txt (``source_file target_file`` per line):
+    ``(ref_image, ref_id, modifier, target_id, len(modifier), ref_local_feature)`` (fashion200k_patch.py:340-354, 371-405)."""
+
+    def __init__(self, root_path: str, split: str = "test", img_transform: Optional[Callable] = None, text_transform: Optional[Callable] = None,
+                 local_dir: str = "local_features", strict: bool = False):
+        super().__init__(root_path, split, img_transform, text_transform, local_dir, strict)
+        self.source_files: List[str] = []
+        self.ref_ids: List[str] = []
+        self.targ_ids: List[str] = []
+        self.modify_texts: List[str] = []
+        if self.split == "test":
+            index = {img["file_path"]: i for i, img in enumerate(self.imgs)}
+            with open(os.path.join(root_path, "test_queries.txt")) as f:
+                for line in f.readlines():
+                    source_file, target_file = line.split()
+                    src_cap = self.imgs[index[source_file]]["captions"][0]
+                    tgt_cap = self.imgs[index[target_file]]["captions"][0]
+                    self.source_files.append(os.path.join(root_path, source_file))
+                    self.ref_ids.append(src_cap)
+                    self.targ_ids.append(tgt_cap)
+                    self.modify_texts.append(get_different_word(src_cap, tgt_cap)[2])
+
+    def _item(self, idx):
+        path = self.source_files[idx]
+        modifier = self.modify_texts[idx]
+        modifier = self.text_transform(modifier) if self.text_transform else modifier
+        return (self._rgb(path), caption_post_process(self.ref_ids[idx]), modifier, caption_post_process(self.targ_ids[idx]), len(modifier),
+                self._local(path))
+
+    def __len__(self):
+        return len(self.modify_texts)

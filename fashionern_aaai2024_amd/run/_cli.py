@@ -84,7 +84,7 @@ def synthetic_split(kind, cfg, d, n, q, seed):
 
 def file_splits(kind, args, clip_model):
     """[(label, classic_dataset, relative_dataset)] read from --data-root in the reference's directory layouts."""
-    from ..dataloader import CIRRDataset, FashionIQDataset, ShoesDataset
+    from ..dataloader import CIRRDataset, Fashion200kTestDataset, Fashion200kTestQueryDataset, FashionIQDataset, ShoesDataset
     from ..preprocess import gpu_preprocess
     pre = gpu_preprocess(clip_model.engine, args.target_ratio, args.input_dim)
     root = args.data_root
@@ -97,7 +97,9 @@ def file_splits(kind, args, clip_model):
     if kind == "shoes":
         sp = root if root.endswith("/") else root + "/"
         return [("shoes", ShoesDataset("test", "classic", pre, shoes_path=sp), ShoesDataset("test", "relative", pre, shoes_path=sp))]
-    raise SystemExit("--data-root: no file-backed dataset class for Fashion200k in this build (use the synthetic split)")
+    local_dir = "local_features" if args.clip_model_name.startswith("ViT") else "fashion200k_13_patch"       # fashion200k_patch.py:290,451
+    return [("200k", Fashion200kTestDataset(root, "val", pre, local_dir=local_dir),
+             Fashion200kTestQueryDataset(root, "val", pre, local_dir=local_dir))]
 
 
 def main(kind: str) -> None:
@@ -116,7 +118,7 @@ def main(kind: str) -> None:
     p.add_argument("--synthetic-queries", default=256, type=int)
     p.add_argument("--seed", default=42, type=int)
     p.add_argument("--data-root", type=str, default=None,
-                   help="directory holding fashion-iq/ (fiq, val), cirr_dataset/ (cirr) or the shoes files (shoes); default: synthetic data")
+                   help="directory holding fashion-iq/ (fiq, val), cirr_dataset/ (cirr), the shoes files (shoes) or the Fashion200k root (200k); default: synthetic data")
     p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp8"],
                    help="encoder operand precision: fp32 = the reference's arithmetic; bf16 / fp8 = perf modes (ViT / text towers)")
     args = p.parse_args()

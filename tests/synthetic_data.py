@@ -180,4 +180,23 @@ def write_dataset_tree(root, d, local_dir="fashion_local13"):
     for split in ("test", "train"):
         json.dump(rels, open(os.path.join(shoes, f"split.{split}.json"), "w"))
         json.dump(ann, open(os.path.join(shoes, f"triplet.{split}.json"), "w"))
+    # Fashion200k: <f2k>/{labels/dress_test_detect_all.txt, test_queries.txt, women/.../x.jpeg, <local_dir>/.../x.jpeg.pth}
+    f2k = os.path.join(root, "fashion200k")
+    os.makedirs(os.path.join(f2k, "labels"), exist_ok=True)
+    colours = ["red", "blue", "green", "black"]
+    kinds = ["mini dress", "maxi dress & belt", "shirt dress."]
+    rows = []
+    for i in range(12):
+        rel = f"women/dresses/casual/{i}/{i}_0.jpeg"
+        cap = f"{colours[i % 4]} {kinds[i % 3]}"
+        rows.append((rel, cap))
+        _write_image(os.path.join(f2k, rel), 1300 + i)
+        for ld in ("local_features", "fashion200k_13_patch"):
+            _write_local(os.path.join(f2k, rel.replace("women", ld) + ".pth"), 1300 + i, d)
+    with open(os.path.join(f2k, "labels", "dress_test_detect_all.txt"), "w", encoding="utf8") as f:
+        for rel, cap in rows:
+            f.write(f"{rel}\t0.9\t{cap}\n")
+    with open(os.path.join(f2k, "test_queries.txt"), "w") as f:
+        for i in range(8):
+            f.write(f"{rows[i][0]} {rows[(i + 1) % 12][0]}\n")
     return root

@@ -105,3 +105,28 @@ def test_harnesses_run_from_files(tree):
     feats, names, local = extract_index_features(sc, clip, 13, "cpu", D, num_workers=0)
     out = test_shoes.compute_shoes_val_metrics(sr, clip, feats, local, names, model, "cpu", D, 4, 0, "tiny")
     assert all(0.0 <= v <= 100.0 for v in out)
+
+
+def test_fashion200k_evaluation_datasets_and_harness(tree):
+    from fashionern_aaai2024_amd.dataloader import (Fashion200kTestDataset, Fashion200kTestQueryDataset, caption_post_process,
+                                                    get_different_word)
+    from fashionern_aaai2024_amd.run import test_200k
+    assert caption_post_process(" a.b?c&d*e ") == "adotmarkbquestionmarkcandmarkdstarmarke"
+    assert get_different_word("red mini dress", "blue mini dress") == ("red", "blue", "replace red with blue")
+    assert get_different_word("red dress", "red dress")[2] == "replace dress with dress"          # no differing word: the last words
+    root = os.path.join(tree, "fashion200k")
+    gal = Fashion200kTestDataset(root, "val", cpu_preprocess)
+    qs = Fashion200kTestQueryDataset(root, "val", cpu_preprocess)
+    assert len(gal) == 12 and len(qs) == 8
+    img_id, img, loc = gal[1]
+    assert img_id == "blue maxi dress andmark belt" and tuple(img.shape) == (3, CFG.image_size, CFG.image_size) and tuple(loc.shape) == (13, D)
+    ref_img, ref_id, mod, tgt_id, n, ref_loc = qs[0]
+    assert (ref_id, tgt_id) == ("red mini dress", "blue maxi dress andmark belt") and mod == "replace red with blue" and n == len(mod)
+    assert tuple(ref_img.shape) == (3, CFG.image_size, CFG.image_size) and tuple(ref_loc.shape) == (13, D)
+    register_tokenizer("tiny", sdata.stub_tokenizer)
+    clip = create_model(CFG, device="cpu", seed=3, engine=OracleEngine())
+    model = ERN(clip, D, "cpu", engine=clip.engine).init_random(5)
+    feats, names, local = extract_index_features(gal, clip, 13, "cpu", D, num_workers=0)
+    assert len(names) == 12 and len(set(names)) == 12
+    out = test_200k.compute_200k_val_metrics(qs, clip, feats, local, names, model, "cpu", D, 4, 0, "tiny")
+    assert all(0.0 <= v <= 100.0 for v in out)

@@ -239,7 +239,8 @@ def test_cli_driver_reads_real_layouts_from_data_root(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FERN_CLIP_BPE_VOCAB=str(vocab))
     common = ["--clip-model-name", "tiny", "--feature-dim", str(cfg.embed_dim), "--input-dim", str(cfg.image_size), "--batch-size", "4"]
-    for mod, data_root, marker in (("test_fiq", root, "R@10:"), ("test_cirr", root, "Average:"), ("test_shoes", os.path.join(root, "shoes"), "R@10:")):
+    for mod, data_root, marker in (("test_fiq", root, "R@10:"), ("test_cirr", root, "Average:"), ("test_shoes", os.path.join(root, "shoes"), "R@10:"),
+                                   ("test_200k", os.path.join(root, "fashion200k"), "R@10:")):
         r = subprocess.run([sys.executable, "-m", f"fashionern_aaai2024_amd.run.{mod}", "--data-root", data_root] + common,
                            cwd=repo, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
