@@ -245,3 +245,29 @@ def test_cli_driver_reads_real_layouts_from_data_root(tmp_path):
                            cwd=repo, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert marker in r.stdout and "recalls:" in r.stdout, r.stdout[-500:]
+
+
+def test_extract_patch_driver_writes_the_features_the_datasets_read(tmp_path):
+    """`python -m ...run.extract_patch`: images under a directory -> <name>.pth with [13, D] float32 features; the files are what
+    FashionIQDataset loads, equal what `preprocess.extract_patch_features` returns in-process, and a second run skips them."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from fashionern_aaai2024_amd.dataloader import FashionIQDataset
+    from fashionern_aaai2024_amd.preprocess import extract_patch_features
+    cfg = synth.CLIP_CONFIGS["tiny"]
+    root = sdata.write_dataset_tree(tmp_path / "data", cfg.embed_dim)
+    images = os.path.join(root, "fashion-iq", "images")
+    out = os.path.join(root, "fashion-iq", "my_local13")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "fashionern_aaai2024_amd.run.extract_patch", "--images", images, "--out", out, "--clip-model-name", "tiny", "--seed", "7"]
+    r = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "36 feature files written" in r.stdout, r.stderr[-2000:] + r.stdout[-500:]
+    r2 = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and "0 feature files written" in r2.stdout
+    ds = FashionIQDataset("val", ["dress"], "classic", lambda im: torch.zeros(3, 4, 4), base_path=root, local_dir="my_local13", strict=True)
+    name, _, loc = ds[5]
+    assert loc.dtype == torch.float32 and tuple(loc.shape) == (13, cfg.embed_dim)
+    clip = create_model(cfg, device=DEV, seed=7)
+    img = torch.from_numpy(np.array(Image.open(os.path.join(images, f"{name}.png")).convert("RGB"), dtype=np.uint8)).to(DEV)
+    assert torch.equal(extract_patch_features(clip, img).cpu(), loc)
