@@ -220,3 +220,22 @@ def test_builtin_clip_bpe_tokenizer_on_a_synthetic_merge_table(tmp_path, monkeyp
     got = tk.get_tokenizer("some-unregistered-model")
     assert isinstance(got, ClipBpeTokenizer) and got("red").shape == (1, 77)
     tk._REGISTRY.pop("some-unregistered-model", None)
+
+
+def test_small_caption_and_feature_helpers_match_the_reference_rules():
+    import random
+    from fashionern_aaai2024_amd.utils import concat_global_local_feats, generate_randomized_fiq_caption, generate_shoes_caption
+    g, l = torch.randn(3, 8), torch.randn(3, 13, 8)
+    c = concat_global_local_feats(g, l)
+    assert tuple(c.shape) == (3, 14, 8) and torch.equal(c[:, 0], g) and torch.equal(c[:, 1:], l)
+    assert generate_shoes_caption(["are more shiny.", " has a strap? "]) == ["Are more shiny", "Has a strap"]
+    caps = ["is red.", "has long sleeves?", "is blue, ", "is shorter"]
+    random.seed(0)
+    draws = [random.random(), random.random()]
+    random.seed(0)
+    got = generate_randomized_fiq_caption(caps)
+
+    def expect(u, a, b):
+        a, b = a.strip(".?, "), b.strip(".?, ")
+        return f"{a.capitalize()} and {b}" if u < 0.25 else f"{b.capitalize()} and {a}" if 0.25 < u < 0.5 else a.capitalize() if 0.5 < u < 0.75 else b.capitalize()
+    assert got == [expect(draws[0], caps[0], caps[1]), expect(draws[1], caps[2], caps[3])]
