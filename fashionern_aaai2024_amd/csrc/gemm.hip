@@ -39,7 +39,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
 
     __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDS_S];
     __shared__ __attribute__((aligned(16))) float Ws[NBUF][BN * LDS_S];
-    __shared__ float red[WAVES_N][BM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -155,7 +154,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
         }
     }
 
-    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, red, bm, bn, nbn, wm, wn, l31, lh, tid);
+    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
 }
 
 // ---- LDS-DMA variant --------------------------------------------------------------------------------------------
@@ -180,12 +179,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
     constexpr int FSH = BKT == 16 ? 2 : 1;
     constexpr int FMASK = C4 - 1;
 
-    // ONE __shared__ object (tile buffers + the reduce-epilogue scratch): with a second LDS object next to the DMA
+    // ONE __shared__ object: with a second LDS object next to the DMA
     // destination hipcc drains the DMA (s_waitcnt vmcnt(0)) before the first ds_read of every k step, which serialises
     // the copy and the MFMAs of a wave.
     constexpr int TILE = ROWS * BKT;
-    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE + WAVES_N * BM];
-    float (*red)[BM] = reinterpret_cast<float (*)[BM]>(smem + 2 * TILE);
+    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -296,7 +294,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my DMA pieces landed, my fragment reads are done
         __builtin_amdgcn_s_barrier();
     }
-    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, red, bm, bn, nbn, wm, wn, l31, lh, tid);
+    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
 }
 
 // ---- small-M variant on v_mfma_f32_16x16x4_f32 ----------------------------------------------------------------------

@@ -50,8 +50,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
     constexpr int TILE = PL * ROWS * RB;                 // bytes per stage
 
     // one __shared__ object (see gemm.hip: a second one makes hipcc drain the DMA before every first fragment read)
-    __shared__ __attribute__((aligned(1024))) char smem[STAGES * TILE + WAVES_N * BM * 4];
-    float (*red)[BM] = reinterpret_cast<float (*)[BM]>(smem + STAGES * TILE);
+    __shared__ __attribute__((aligned(1024))) char smem[STAGES * TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -185,7 +184,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
         compute(slot);
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
-    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N, true>(p, acc, red, bm, bn, nbn, wm, wn, l31, lh, tid);
+    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N, true>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
 }
 
 struct TileCfgB { int bm, bn, bk; };

@@ -104,7 +104,7 @@ __device__ __forceinline__ void plain_epilogue(const GemmParams& p, f32x16 (&acc
 
 // Shared epilogue of the fp32 and bf16 GEMM kernels (ALLOW_BF16_OUT: only the bf16 kernel stores bf16 outputs).
 template <int BM, int BN, int WM, int WN, int TM, int TN, int WAVES_N, bool ALLOW_BF16_OUT = false>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], float (*red)[BM], int bm, int bn, int nbn,
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int bm, int bn, int nbn,
                                               int wm, int wn, int l31, int lh, int tid) {
     const int row_w = bm * BM + wm * WM;
     const int col_w = bn * BN + wn * WN;
