@@ -323,3 +323,35 @@ def test_dvr_fuse_reduced_precision(d, b, t):
     finally:
         eng.set_precision("fp32")
     assert torch.equal(eng.dvr_fuse(rg, rl, tg, ts), fp32)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp8"])
+def test_encoders_chunk_large_batches_without_changing_rows(precision):
+    """Batches larger than the internal chunk (64 images, 256 captions, 256 fusion rows) are processed in pieces: every row
+    must equal the row computed alone, in every precision mode (workspace reuse across chunks, scale buffers, bf16 copies)."""
+    cfg = synth.CLIP_CONFIGS["tiny-hd64"]
+    d = cfg.embed_dim
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(synth.clip_state_dict(cfg, seed=8))
+    eng.finalize_clip(cfg)
+    eng.load_tensors(synth.fusion_state_dict(d, seed=9))
+    eng.finalize_fusion(d)
+    eng.set_precision(precision)
+    n_img, n_txt = 150, 530
+    imgs = _t(synth.images(n_img, cfg, 2))
+    toks = _t(synth.captions(n_txt, cfg, 2, full_length=False))
+    fi = eng.encode_image(imgs)
+    g, s = eng.encode_text(toks)
+    for i in (0, 63, 64, 65, 127, 128, 149):
+        assert torch.equal(eng.encode_image(imgs[i:i + 1]), fi[i:i + 1]), i
+    for i in (0, 255, 256, 257, 511, 512, 529):
+        gi, si = eng.encode_text(toks[i:i + 1])
+        assert torch.equal(gi, g[i:i + 1]) and torch.equal(si, s[i:i + 1]), i
+    b = 300
+    loc = _t(synth.local_feats(b, d, 3))
+    fused = eng.dvr_fuse(fi[:1].expand(b, -1).contiguous() + g[:b] * 0.1, loc, g[:b], s[:b])
+    for i in (0, 255, 256, 299):
+        one = eng.dvr_fuse((fi[:1] + g[i:i + 1] * 0.1).contiguous(), loc[i:i + 1], g[i:i + 1], s[i:i + 1])
+        assert torch.equal(one, fused[i:i + 1]), i
+    assert torch.isfinite(fused).all()
+    eng.close()
