@@ -1173,7 +1173,7 @@ extern "C" int fern_vit_encode_image(fern_ctx* c, const float* images, float* ou
     const fern_clip_config& cf = c->clip.cfg;
     const long img_sz = 3L * cf.image_size * cf.image_size;
     const bool resnet = cf.v_arch == 1;
-    const int CH = resnet ? 32 : 64;
+    const int CH = resnet ? 128 : 64;      // the ResNet's late stages have few pixels per image: larger chunks fill the chip (M = 128 x 81 rows)
     for (int o = 0; o < b; o += CH) {
         const int m = std::min(CH, b - o);
         FERN_TRY(ws_begin(c, s));
