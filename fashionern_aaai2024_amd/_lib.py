@@ -38,7 +38,7 @@ SIGNATURES = {
     "fern_finalize_fusion": (c_int, [c_void_p, c_int, c_int]),
     "fern_finalize_clip": (c_int, [c_void_p, C.POINTER(ClipConfigC)]),
     "fern_vit_encode_image": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "fern_text_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "fern_text_encode": (c_int, [c_void_p, c_void_p, c_void_p, C.POINTER(c_i64), c_void_p, c_void_p, c_int, c_void_p]),
     "fern_dvr_fuse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fern_index_fuse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "fern_combiner": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
@@ -64,9 +64,6 @@ SIGNATURES = {
     "fern_get_precision": (c_int, [c_void_p]),
     "fern_gemm_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
                                c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "fern_split_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
-    "fern_gemm_bf16x3": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
-                                 c_int, c_int, c_int, c_int, c_void_p]),
     "fern_quantize_rows_fp8": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),
     "fern_gemm_fp8": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
                               c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -98,7 +95,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.fern_abi_version() != 1:
+    if lib.fern_abi_version() != 2:
         raise RuntimeError("libfern.so ABI version mismatch")
     _lib = lib
     return lib

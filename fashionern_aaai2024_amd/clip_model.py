@@ -89,6 +89,8 @@ class FernCLIP:
             ve = tuple(visual_emb.shape)
             if len(ve) != 3 or ve[0] != PATCH_NUM or ve[1] != text.shape[0] or ve[2] != self.cfg.embed_dim:
                 raise ValueError(f"visual_emb must be [{PATCH_NUM}, B, {self.cfg.embed_dim}], got {ve}")
+        if not text.is_cuda and text.numel() and (int(text.min()) < 0 or int(text.max()) >= self.cfg.vocab_size):
+            raise IndexError(f"token id out of range [0, {self.cfg.vocab_size})")      # nn.Embedding's error in the reference
         t = text.to(device=self.device, dtype=torch.int64)
         # the reference calls encode_text twice on the same tokens (global, then seq: test_fiq.py:102-103);
         # one tower pass serves both
@@ -96,7 +98,7 @@ class FernCLIP:
         if c is not None and c[0].shape == t.shape and torch.equal(c[0], t):
             g, s = c[1], c[2]
         else:
-            g, s = self.engine.encode_text(t)
+            g, s = self.engine.encode_text(t, visual_emb=visual_emb)
             self._text_cache = (t.clone(), g, s)
         return s if mode == "seq" else (g, s)
 

@@ -97,7 +97,16 @@ struct ProfRec { hipEvent_t a, b; int kind; double work; int m, n, k, tag; };
 struct fern_ctx {
     int device = 0;
     std::map<std::string, HostTensor> host;
-    std::vector<void*> owned;        // device weight buffers
+    // device weight buffers, per weight group: re-finalising a group frees its previous generation
+    enum { G_CLIP = 0, G_DVR, G_TARGET_SR, G_TARGET_COMBINER, G_CLIP4CIR, G_COUNT };
+    std::vector<void*> owned[G_COUNT];
+    int cur_group = G_CLIP;          // group the upload helpers currently allocate into
+    // forks point into the parent's buffers: `generation` counts the parent's re-finalisations, a fork remembers the value
+    // it was created at and every weight-reading entry point refuses to run on a stale fork
+    unsigned generation = 0;
+    const fern_ctx* parent = nullptr;
+    unsigned parent_generation = 0;
+    int* tok_flag = nullptr;         // host-mapped: set by the text embedding kernel when a token id is out of range
     FusionW fusion;
     ClipW clip;
     Clip4CirW c4c;
@@ -220,7 +229,7 @@ static int upload(fern_ctx* c, const float* h, size_t n, const float** out) {
     float* d = nullptr;
     HIP_TRY(hipMalloc(&d, std::max<size_t>(n, 4) * sizeof(float)));
     HIP_TRY(hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice));
-    c->owned.push_back(d);
+    c->owned[c->cur_group].push_back(d);
     *out = d;
     return FERN_OK;
 }
@@ -319,6 +328,28 @@ static int up_combiner(fern_ctx* c, const std::string& p, int D, CombinerW* W) {
     return up_key(c, p + ".dynamic_scalar.3.bias", {1}, &W->b2);
 }
 
+// Start (re-)finalising one weight group: everything that may still read the previous generation is drained, the old
+// buffers are released, and forks created before this point become stale (they hold pointers into the freed memory).
+static int begin_group(fern_ctx* c, int group) {
+    if (c->parent) return fail(FERN_ERR_STATE, "weights are finalised on the root context, not on a fork");
+    c->cur_group = group;
+    if (!c->owned[group].empty()) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (void* p : c->owned[group]) HIP_TRY(hipFree(p));
+        c->owned[group].clear();
+    }
+    c->generation++;
+    return FERN_OK;
+}
+static int check_token_flag(fern_ctx* c, const char* fn);
+// Weight-reading entry points call this first: a fork made before the parent's last re-finalisation must not run.
+static int check_fresh(fern_ctx* c, const char* fn) {
+    if (c->parent && c->parent->generation != c->parent_generation)
+        return fail(FERN_ERR_STATE, std::string(fn) + ": this fork predates the parent's last fern_finalize_*: its weight pointers are stale "
+                                                       "(fork again after loading weights)");
+    return FERN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // exported: lifetime, weights
 // ------------------------------------------------------------------------------------------------
@@ -342,6 +373,9 @@ extern "C" int fern_ctx_fork(fern_ctx* parent, fern_ctx** out) {
     if (!parent || !out) return fail(FERN_ERR_ARG, "fern_ctx_fork: NULL argument");
     auto* c = new fern_ctx();
     c->device = parent->device;
+    if (parent->parent) return fail(FERN_ERR_ARG, "fern_ctx_fork: fork the root context, not a fork");
+    c->parent = parent;
+    c->parent_generation = parent->generation;
     c->fusion = parent->fusion;      // pointers into the parent's `owned` buffers; the parent must outlive its forks
     c->clip = parent->clip;
     c->c4c = parent->c4c;
@@ -354,7 +388,9 @@ extern "C" int fern_ctx_destroy(fern_ctx* c) {
     if (!c) return FERN_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (void* p : c->owned) (void)hipFree(p);
+    for (auto& grp : c->owned)
+        for (void* p : grp) (void)hipFree(p);
+    if (c->tok_flag) (void)hipHostFree(c->tok_flag);
     for (auto& b : c->blocks) (void)hipFree(b.p);
     for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -364,7 +400,7 @@ extern "C" int fern_ctx_destroy(fern_ctx* c) {
 extern "C" int fern_sync(fern_ctx* c, void* stream) {
     if (!c) return fail(FERN_ERR_ARG, "fern_sync: ctx is NULL");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return FERN_OK;
+    return check_token_flag(c, "fern_sync");
 }
 
 extern "C" int fern_load_tensor(fern_ctx* c, const char* key, const void* host_ptr, int dtype, int ndim, const int64_t* shape) {
@@ -396,6 +432,7 @@ extern "C" int fern_finalize_fusion(fern_ctx* c, int D, int parts) {
     F.D = D;
     if (parts & FERN_PART_DVR) {
         F.parts &= ~FERN_PART_DVR;
+        FERN_TRY(begin_group(c, fern_ctx::G_DVR));
         const std::string tl = "DVR.transformer_layer";
         const std::string bm = tl + ".bert_encoder.bert_model";
         if (c->host.count(tl + ".cls_token")) FERN_TRY(up_key(c, tl + ".cls_token", {1, 1, D}, &F.cls));
@@ -445,11 +482,13 @@ extern "C" int fern_finalize_fusion(fern_ctx* c, int D, int parts) {
     }
     if (parts & FERN_PART_TARGET_SR) {
         F.parts &= ~FERN_PART_TARGET_SR;
+        FERN_TRY(begin_group(c, fern_ctx::G_TARGET_SR));
         FERN_TRY(up_sr(c, "SR_module", D, &F.sr[FERN_SR_TARGET]));
         F.parts |= FERN_PART_TARGET_SR;
     }
     if (parts & FERN_PART_TARGET_COMBINER) {
         F.parts &= ~FERN_PART_TARGET_COMBINER;
+        FERN_TRY(begin_group(c, fern_ctx::G_TARGET_COMBINER));
         FERN_TRY(up_combiner(c, "Combiner_module", D, &F.comb[FERN_COMBINER_TARGET]));
         F.parts |= FERN_PART_TARGET_COMBINER;
     }
@@ -461,7 +500,7 @@ static int make_bf16(fern_ctx* c, LinearW* L) {
     const size_t n = (size_t)L->out * L->in;
     unsigned short* d = nullptr;
     HIP_TRY(hipMalloc(&d, n * sizeof(unsigned short)));
-    c->owned.push_back(d);
+    c->owned[c->cur_group].push_back(d);
     HIP_TRY(launch_f32_to_bf16(L->w, d, (long)n, nullptr));
     L->wb = d;
     return FERN_OK;
@@ -473,9 +512,9 @@ static int make_fp8(fern_ctx* c, LinearW* L) {
     unsigned char* d = nullptr;
     float* sw = nullptr;
     HIP_TRY(hipMalloc(&d, (size_t)L->out * L->in));
-    c->owned.push_back(d);
+    c->owned[c->cur_group].push_back(d);
     HIP_TRY(hipMalloc(&sw, (size_t)L->out * sizeof(float)));
-    c->owned.push_back(sw);
+    c->owned[c->cur_group].push_back(sw);
     HIP_TRY(launch_quantize_rows_fp8(nullptr, L->w, L->in, d, L->in, sw, L->out, L->in, nullptr));
     L->w8 = d;
     L->sw = sw;
@@ -576,6 +615,7 @@ extern "C" int fern_finalize_clip(fern_ctx* c, const fern_clip_config* cfg) {
     HIP_TRY(hipSetDevice(c->device));
     ClipW& W = c->clip;
     W = ClipW();
+    FERN_TRY(begin_group(c, fern_ctx::G_CLIP));
     W.cfg = *cfg;
     auto bad = [](int w, int heads) { return w <= 0 || w % 32 || w > 1024 || heads <= 0 || w % heads || (w / heads) % 4 || w / heads > 96; };
     if (cfg->embed_dim <= 0 || cfg->embed_dim % 4 || cfg->embed_dim > 1024) return fail(FERN_ERR_ARG, "clip: unsupported embed_dim");
@@ -673,6 +713,7 @@ static int run_combiner(fern_ctx* c, const CombinerW& W, const float* image, con
 static int check_fusion(fern_ctx* c, const char* fn, int parts) {
     if (!c) return fail(FERN_ERR_ARG, std::string(fn) + ": ctx is NULL");
     if ((c->fusion.parts & parts) != parts) return fail(FERN_ERR_STATE, std::string(fn) + ": fusion weights not finalised (fern_finalize_fusion)");
+    FERN_TRY(check_fresh(c, fn));
     HIP_TRY(hipSetDevice(c->device));
     return FERN_OK;
 }
@@ -714,6 +755,7 @@ extern "C" int fern_finalize_clip4cir(fern_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     Clip4CirW& W = c->c4c;
     W = Clip4CirW();
+    FERN_TRY(begin_group(c, fern_ctx::G_CLIP4CIR));
     const std::string p = "clip4cir.";
     const HostTensor *tp, *cl;
     FERN_TRY(need(c, p + "text_projection_layer.weight", {}, &tp));
@@ -736,6 +778,7 @@ extern "C" int fern_finalize_clip4cir(fern_ctx* c) {
 extern "C" int fern_combiner_clip4cir(fern_ctx* c, const float* image, const float* text, float* out, int64_t n, void* stream) {
     if (!c) return fail(FERN_ERR_ARG, "fern_combiner_clip4cir: ctx is NULL");
     if (!c->c4c.ready) return fail(FERN_ERR_STATE, "fern_combiner_clip4cir: weights not finalised (fern_finalize_clip4cir)");
+    FERN_TRY(check_fresh(c, "fern_combiner_clip4cir"));
     if (n < 0 || (n && (!image || !text || !out))) return fail(FERN_ERR_ARG, "fern_combiner_clip4cir: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
@@ -913,7 +956,9 @@ extern "C" int fern_dvr_fuse(fern_ctx* c, const float* ref_global, const float* 
                              float* out, int B, int seq_len, void* stream) {
     FERN_TRY(check_fusion(c, "fern_dvr_fuse", FERN_PART_DVR));
     if (B < 0 || (B && (!ref_global || !ref_local || !text_global || !text_seq || !out))) return fail(FERN_ERR_ARG, "fern_dvr_fuse: bad argument");
-    if (seq_len < 1 || 1 + 13 + seq_len > 96) return fail(FERN_ERR_ARG, "fern_dvr_fuse: 1 + 13 + seq_len must be <= 96");
+    // the MR cross-attention keeps output rows [:13] of the text queries (fusion_model.py:47) and feeds them to BatchNorm1d(13):
+    // fewer than 13 text rows fail there in the reference; here they would read the next sample's rows
+    if (seq_len < 13 || 1 + 13 + seq_len > 96) return fail(FERN_ERR_ARG, "fern_dvr_fuse: need 13 <= seq_len and 1 + 13 + seq_len <= 96");
     hipStream_t s = (hipStream_t)stream;
     const int D = c->fusion.D, CH = 256;
     for (int o = 0; o < B; o += CH) {
@@ -1167,6 +1212,7 @@ extern "C" int fern_vit_encode_image(fern_ctx* c, const float* images, float* ou
     if (!c) return fail(FERN_ERR_ARG, "fern_vit_encode_image: ctx is NULL");
     if (!c->clip.ready || (c->clip.cfg.v_arch == 0 && c->clip.cfg.v_layers <= 0))
         return fail(FERN_ERR_STATE, "fern_vit_encode_image: image tower not finalised (fern_finalize_clip)");
+    FERN_TRY(check_fresh(c, "fern_vit_encode_image"));
     if (b < 0 || (b && (!images || !out))) return fail(FERN_ERR_ARG, "fern_vit_encode_image: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1196,7 +1242,7 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
     FERN_TRY(ws_get(c, (size_t)R * tw, &ATT));
     FERN_TRY(ws_get(c, (size_t)R * cf.t_mlp, &H));
     FERN_TRY(ws_get(c, (size_t)B, &eot));
-    HIP_TRY(launch_text_embed(tokens, W.tok_emb, W.tpos, X, eot, B, T, tw, cf.vocab_size, s));
+    HIP_TRY(launch_text_embed(tokens, W.tok_emb, W.tpos, X, eot, B, T, tw, cf.vocab_size, c->tok_flag, s));
     for (int l = 0; l < cf.t_layers; ++l) {
         if (c->precision == FERN_PREC_FP8) {
             unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
@@ -1225,13 +1271,36 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
     return FERN_OK;
 }
 
-extern "C" int fern_text_encode(fern_ctx* c, const int64_t* tokens, float* out_global, float* out_seq, int B, void* stream) {
+// A token id outside the vocabulary cannot raise from inside a kernel (nn.Embedding does, in the reference): the embedding
+// kernel poisons the row with NaN and sets a host-mapped flag; it is turned into FERN_ERR_ARG here, at fern_sync and at the
+// next fern_text_encode -- without a synchronisation on the launch path.
+static int check_token_flag(fern_ctx* c, const char* fn) {
+    if (!c->tok_flag) return FERN_OK;
+    const int v = __atomic_load_n(c->tok_flag, __ATOMIC_RELAXED);
+    if (v == 0) return FERN_OK;
+    __atomic_store_n(c->tok_flag, 0, __ATOMIC_RELAXED);
+    return fail(FERN_ERR_ARG, std::string(fn) + ": an earlier fern_text_encode on this context read a token id outside [0, vocab_size) at flat "
+                                                 "position " + std::to_string(v - 1) + " of its chunk (its features are NaN): tokenizer / vocabulary mismatch?");
+}
+
+extern "C" int fern_text_encode(fern_ctx* c, const int64_t* tokens, const float* visual_emb, const int64_t* visual_emb_shape, float* out_global,
+                                float* out_seq, int B, void* stream) {
     if (!c) return fail(FERN_ERR_ARG, "fern_text_encode: ctx is NULL");
     if (!c->clip.ready || c->clip.cfg.t_layers <= 0) return fail(FERN_ERR_STATE, "fern_text_encode: text tower not finalised (fern_finalize_clip)");
+    FERN_TRY(check_fresh(c, "fern_text_encode"));
     if (B < 0 || (B && (!tokens || (!out_global && !out_seq)))) return fail(FERN_ERR_ARG, "fern_text_encode: bad argument");
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = (hipStream_t)stream;
     const fern_clip_config& cf = c->clip.cfg;
+    if (visual_emb) {      // clip_model.py:23-31: visual_emb = ref_patch_feats.transpose(0, 1), [13, B, D]; checked, then unused (vanilla CLIP branch)
+        if (!visual_emb_shape || visual_emb_shape[0] != 13 || visual_emb_shape[1] != B || visual_emb_shape[2] != cf.embed_dim)
+            return fail(FERN_ERR_ARG, "fern_text_encode: visual_emb must be [13, B, embed_dim]");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->tok_flag) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->tok_flag), sizeof(int), hipHostMallocMapped));
+        *c->tok_flag = 0;
+    }
+    FERN_TRY(check_token_flag(c, "fern_text_encode"));
+    hipStream_t s = (hipStream_t)stream;
     const int CH = 256;
     for (int o = 0; o < B; o += CH) {
         const int m = std::min(CH, B - o);
@@ -1393,31 +1462,6 @@ extern "C" int fern_gemm_bf16(fern_ctx* c, const uint16_t* A, int64_t lda, const
     p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aload = ALOAD_PLAIN; p.out_bf16 = out_bf16 ? 1 : 0;
     int slot;
     FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * M * (double)N * K, (hipStream_t)stream, &slot, M, N, K, 100 + epilogue));
-    HIP_TRY(launch_gemm_bf16(p, (hipStream_t)stream));
-    return prof_close(c, slot, (hipStream_t)stream);
-}
-
-extern "C" int fern_split_bf16x3(fern_ctx* c, const float* x, uint16_t* y, int64_t n, void* stream) {
-    if (!c || n < 0 || (n && (!x || !y)) || n % 4) return fail(FERN_ERR_ARG, "fern_split_bf16x3: bad argument (n % 4 == 0)");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(launch_split_bf16x3(x, y, n, n, (hipStream_t)stream));
-    return FERN_OK;
-}
-
-extern "C" int fern_gemm_bf16x3(fern_ctx* c, const uint16_t* A3, int64_t lda, const uint16_t* W3, int64_t ldw, const float* bias,
-                                const float* residual, float* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream) {
-    if (!c || M < 0 || N < 0 || K <= 0) return fail(FERN_ERR_ARG, "fern_gemm_bf16x3: bad argument");
-    if (M == 0 || N == 0) return FERN_OK;
-    if (!A3 || !W3 || !C) return fail(FERN_ERR_ARG, "fern_gemm_bf16x3: NULL argument");
-    if (epilogue < FERN_EPI_BIAS || epilogue > FERN_EPI_BIAS_RESIDUAL) return fail(FERN_ERR_ARG, "fern_gemm_bf16x3: unknown epilogue");
-    if (epilogue == FERN_EPI_BIAS_RESIDUAL && !residual) return fail(FERN_ERR_ARG, "fern_gemm_bf16x3: residual is NULL");
-    if (K % 32 || lda % 8 || ldw % 8) return fail(FERN_ERR_ARG, "fern_gemm_bf16x3: K % 32, lda % 8 and ldw % 8 must be 0");
-    HIP_TRY(hipSetDevice(c->device));
-    GemmParams p{};
-    p.Ab = A3; p.lda = lda; p.a_plane = (long)M * lda; p.Wb = W3; p.ldw = ldw; p.w_plane = (long)N * ldw; p.planes = 3;
-    p.bias = bias; p.R = residual; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aload = ALOAD_PLAIN;
-    int slot;
-    FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * M * (double)N * K, (hipStream_t)stream, &slot, M, N, K, 300 + epilogue));
     HIP_TRY(launch_gemm_bf16(p, (hipStream_t)stream));
     return prof_close(c, slot, (hipStream_t)stream);
 }

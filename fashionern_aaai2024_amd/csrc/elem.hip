@@ -285,14 +285,23 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const float* cls, const
 }
 
 __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* text, const float* tok_emb, const float* pos_emb, float* X,
-                                                         int B, int T, int d, int vocab) {
+                                                         int B, int T, int d, int vocab, int* bad_flag) {
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= (long)B * T) return;
     const int s = (int)(row % T);
-    long tok = text[row];
-    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    const long tok = text[row];
     RowRegs r, q;
+    if (tok < 0 || tok >= vocab) {
+        // nn.Embedding raises on such an id (the reference's token_embedding lookup); a kernel cannot, so the row is poisoned
+        // with NaN -- which reaches every feature of this caption -- and the host-visible flag records where it happened
+        // (1 + flat position); fern_sync / the next fern_text_encode on this context report it as FERN_ERR_ARG
+        if (lane == 0 && bad_flag) __hip_atomic_store(bad_flag, (int)(row < 0x7FFFFFFEL ? row + 1 : 0x7FFFFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) r.v[i] = __builtin_nanf("");
+        row_store(r, X + row * d, d, lane);
+        return;
+    }
     row_load(r, tok_emb + tok * d, d, lane);
     row_load(q, pos_emb + (long)s * d, d, lane);
 #pragma unroll
@@ -544,10 +553,10 @@ hipError_t launch_bert_embed(const float* cls, const float* local, const float* 
     return hipGetLastError();
 }
 hipError_t launch_text_embed(const int64_t* text, const float* tok_emb, const float* pos_emb, float* X, int* eot, int B, int T, int d,
-                             int vocab, hipStream_t s) {
+                             int vocab, int* bad_flag, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (bad_width(d)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(text_embed_kernel, row_grid((long)B * T), dim3(256), 0, s, text, tok_emb, pos_emb, X, B, T, d, vocab);
+    hipLaunchKernelGGL(text_embed_kernel, row_grid((long)B * T), dim3(256), 0, s, text, tok_emb, pos_emb, X, B, T, d, vocab, bad_flag);
     hipLaunchKernelGGL(text_eot_kernel, dim3((B + 63) / 64), dim3(64), 0, s, text, eot, B, T);
     return hipGetLastError();
 }

@@ -25,12 +25,7 @@ typedef long i64x2 __attribute__((ext_vector_type(2)));
 // FP8: the operands are OCP e4m3fn bytes and the MFMA is v_mfma_f32_32x32x16_fp8_fp8 (same rate as bf16, half the bytes):
 // a BKE-element tile row is then BKE bytes, one ds_read_b128 holds the fragments of TWO consecutive MFMA k-steps (low /
 // high 8 bytes), and the tile loop runs half as many iterations for the same K.
-// PL = 3 ("bf16x3"): fp32-grade products from bf16 MFMAs.  Each fp32 operand x is carried as three bf16 planes
-// x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (x0 + x1 + x2 = x to 2^-27), products of bf16 pairs are exact in
-// fp32, and the six terms a_i b_j with i + j <= 2 are accumulated (smallest first) into the same fp32 accumulator: what
-// is dropped is below 2^-25 |a||b|, i.e. below one fp32 rounding of the product.  Six 32-cycle MFMAs replace eight
-// 64-cycle fp32 MFMAs per 16 k (x 0.375), with every fragment read once and used in two or three MFMAs.
-template <int BM, int BN, int WM, int WN, int BKE, int STAGES, int MINW, bool FP8 = false, int PL = 1>
+template <int BM, int BN, int WM, int WN, int BKE, int STAGES, int MINW, bool FP8 = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_glds_kernel(GemmParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
@@ -41,13 +36,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
     constexpr int RB = BKE * ES;                         // bytes per tile row (64 or 128)
     constexpr int C4 = RB / 16;                          // 16-byte chunks per tile row
     constexpr int RPP = 64 / C4;                         // tile rows per 1 KiB piece
-    constexpr int PIECES = PL * ROWS / RPP;              // planes are stacked: [plane][A rows; W rows]
+    constexpr int PIECES = ROWS / RPP;
     static_assert(PIECES % NW == 0, "pieces must divide over the waves");
-    static_assert(PL == 1 || (PL == 3 && !FP8), "planes: 1 (plain) or 3 (bf16x3)");
     constexpr int PPW = PIECES / NW;
     constexpr int FSH = RB == 64 ? 2 : 1;                // chunk c of row r lives at position c ^ ((r >> FSH) & FMASK)
     constexpr int FMASK = C4 - 1;
-    constexpr int TILE = PL * ROWS * RB;                 // bytes per stage
+    constexpr int TILE = ROWS * RB;                      // bytes per stage
 
     // one __shared__ object (see gemm.hip: a second one makes hipcc drain the DMA before every first fragment read)
     __shared__ __attribute__((aligned(1024))) char smem[STAGES * TILE];
@@ -70,17 +64,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int piece = wave + NW * j;                       // wave-uniform
-        const int prow = piece * RPP + lane / C4;              // row in the stacked [plane][A; W] space
-        const int plane = prow / ROWS, trow = prow % ROWS;     // ROWS % RPP == 0: a piece never straddles planes
+        const int trow = piece * RPP + lane / C4;              // row in the [A; W] tile-row space
         const int chunk = (lane & FMASK) ^ ((trow >> FSH) & FMASK);
         if (trow < BM) {
             int row = bm * BM + trow;
             row = row < p.M ? row : p.M - 1;
-            src[j] = reinterpret_cast<const char*>(p.Ab) + ((long)plane * p.a_plane + (long)row * p.lda) * ES + chunk * 16;
+            src[j] = reinterpret_cast<const char*>(p.Ab) + (long)row * p.lda * ES + chunk * 16;
         } else {
             int row = bn * BN + (trow - BM);
             row = row < p.N ? row : p.N - 1;
-            src[j] = reinterpret_cast<const char*>(p.Wb) + ((long)plane * p.w_plane + (long)row * p.ldw) * ES + chunk * 16;
+            src[j] = reinterpret_cast<const char*>(p.Wb) + (long)row * p.ldw * ES + chunk * 16;
         }
     }
     auto stage = [&](int buf, int k0) {
@@ -112,30 +105,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (wm * WM + i * 32 + l31) * RB + pc);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Ws + (wn * WN + j * 32 + l31) * RB + pc);
-            if (PL == 3) {
-                bf16x8 a1[TM], a2[TM], b1[TN], b2[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    a1[i] = *reinterpret_cast<const bf16x8*>(As + ROWS * RB + (wm * WM + i * 32 + l31) * RB + pc);
-                    a2[i] = *reinterpret_cast<const bf16x8*>(As + 2 * ROWS * RB + (wm * WM + i * 32 + l31) * RB + pc);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    b1[j] = *reinterpret_cast<const bf16x8*>(Ws + ROWS * RB + (wn * WN + j * 32 + l31) * RB + pc);
-                    b2[j] = *reinterpret_cast<const bf16x8*>(Ws + 2 * ROWS * RB + (wn * WN + j * 32 + l31) * RB + pc);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], bf[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], b2[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], bf[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], b1[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                    }
-            } else if (FP8) {
+            if (FP8) {
                 // the 16 bytes are k = 32kk + 16h .. +15 of this lane's row: bytes 0-7 feed one 32x32x16 step, 8-15 the next
                 // (both operands use the same k grouping, so the sum is the plain dot product)
 #pragma unroll
@@ -233,22 +203,6 @@ static hipError_t launch_cfg_f8(int c, const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// bf16x3 tile family (three planes per operand: 3x the LDS of the plain kernel per stage)
-static const TileCfgB kCfgsX3[] = {
-    {256, 128, 32},   // 0: 8 waves of 64x64, 2 stages (144 KB of LDS: one workgroup per CU)
-    {128, 64, 32},    // 1: 4 waves of 64x32, 2 stages, 2 per CU (small problems)
-};
-constexpr int kNumCfgsX3 = 2;
-static hipError_t launch_cfg_x3(int c, const GemmParams& p, hipStream_t s) {
-    const int nb = ((p.M + kCfgsX3[c].bm - 1) / kCfgsX3[c].bm) * ((p.N + kCfgsX3[c].bn - 1) / kCfgsX3[c].bn);
-    switch (c) {
-        case 0: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 2, 1, false, 3>), dim3(nb), dim3(512), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 64, 64, 32, 32, 2, 2, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
 static int forced_cfg_b() {
     static int v = [] {
         const char* e = getenv("FERN_GEMM_BF16_CFG");
@@ -324,13 +278,6 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     if (p.K <= 0 || (p.K % kq) != 0 || (p.lda & aq) || (p.ldw & aq) || p.aload != ALOAD_PLAIN || epi_is_reduce(p.epi)) return hipErrorInvalidValue;
     if (!p.Ab || !p.Wb || ((uintptr_t)p.Ab & 15) || ((uintptr_t)p.Wb & 15)) return hipErrorInvalidValue;
     if ((p.scale_a == nullptr) != (p.scale_w == nullptr)) return hipErrorInvalidValue;
-    if (p.planes == 3) {
-        if (p.fp8 || p.out_bf16) return hipErrorInvalidValue;
-        static int forced = [] { const char* e = getenv("FERN_GEMM_X3_CFG"); return e ? atoi(e) : -1; }();
-        int c = forced;
-        if (c < 0 || c >= kNumCfgsX3) c = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) >= 256 ? 0 : 1;
-        return launch_cfg_x3(c, p, s);
-    }
     if (p.fp8) {
         static int forced = [] { const char* e = getenv("FERN_GEMM_FP8_CFG"); return e ? atoi(e) : -1; }();
         int c = forced;

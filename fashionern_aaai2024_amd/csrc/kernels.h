@@ -49,8 +49,6 @@ struct GemmParams {
     // fp8 (OCP e4m3fn) operand form: Ab / Wb point at fp8 bytes (strides in elements = bytes), K % 64 == 0; the quantisation
     // scales are folded back in the epilogue: C = acc * scale_a[row] * scale_w[col] (+ bias ...)
     int fp8;
-    int planes;                   // 3: bf16x3 operands (three bf16 planes per operand, plane strides below, in elements); else 1
-    long a_plane, w_plane;
     const float* scale_a;         // [M] per-row (token) activation scales, or null
     const float* scale_w;         // [N] per-output-channel weight scales, or null
 };
@@ -116,9 +114,10 @@ hipError_t launch_gather_rows(const float* x, long ldx, float* y, long ldy, long
 hipError_t launch_bert_embed(const float* cls, const float* local, const float* seq, const float* type_emb,
                              const float* pos_emb, const float* gamma, const float* beta, float* X,
                              int B, int P, int T, int d, float eps, hipStream_t s);
-// CLIP text embeddings: X[b,s] = tok_emb[text[b,s]] + pos[s]; also eot[b] = argmax_s text[b,s]
+// CLIP text embeddings: X[b,s] = tok_emb[text[b,s]] + pos[s]; also eot[b] = argmax_s text[b,s].  A token id outside
+// [0, vocab) poisons its row with NaN and stores 1 + its flat position in *bad_flag (host-mapped, may be null).
 hipError_t launch_text_embed(const int64_t* text, const float* tok_emb, const float* pos_emb, float* X, int* eot,
-                             int B, int T, int d, int vocab, hipStream_t s);
+                             int B, int T, int d, int vocab, int* bad_flag, hipStream_t s);
 // ViT class rows: X[b, 0, :] = cls + pos[0]
 hipError_t launch_vit_cls(const float* cls, const float* pos, float* X, int B, int tokens, int d, hipStream_t s);
 // CombinerSimple tail: s = sigmoid(sum_nb partial[row][nb] + b2); out = normalize(s*text + (1-s)*image)
@@ -148,8 +147,6 @@ hipError_t launch_u8_to_chw(const unsigned char* src, long src_ld, int x0, int y
 
 // ---- bf16 gallery sweep (sweep_bf16.hip) ---------------------------------------------------------------------------
 hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStream_t s);
-// x [n] fp32 -> three bf16 planes y[0..n), y[plane..), y[2 plane..): x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)
-hipError_t launch_split_bf16x3(const float* x, unsigned short* y, long n, long plane, hipStream_t s);
 // scores[q, n] = Q[q] . G[n] for q < B <= 64, bf16 gallery [N, D] (D % 64 == 0), fp32 accumulate, scores row stride ld
 hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, hipStream_t s);
 

@@ -130,31 +130,6 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
     }
 }
 
-__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* x, u16* y, long n4, long plane) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
-    ushort4 o0, o1, o2;
-    u16* q0 = reinterpret_cast<u16*>(&o0); u16* q1 = reinterpret_cast<u16*>(&o1); u16* q2 = reinterpret_cast<u16*>(&o2);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const u16 b0 = f32_to_bf16_rne(v[e]);
-        const float r1 = v[e] - __uint_as_float((unsigned)b0 << 16);
-        const u16 b1 = f32_to_bf16_rne(r1);
-        const float r2 = r1 - __uint_as_float((unsigned)b1 << 16);
-        q0[e] = b0; q1[e] = b1; q2[e] = f32_to_bf16_rne(r2);
-    }
-    *reinterpret_cast<ushort4*>(y + i * 4) = o0;
-    *reinterpret_cast<ushort4*>(y + plane + i * 4) = o1;
-    *reinterpret_cast<ushort4*>(y + 2 * plane + i * 4) = o2;
-}
-hipError_t launch_split_bf16x3(const float* x, unsigned short* y, long n, long plane, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
-    if ((n & 3) || (plane & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, y, n / 4, plane);
-    return hipGetLastError();
-}
-
 hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (n & 3) return hipErrorInvalidValue;

@@ -86,9 +86,13 @@ class FernEngine:
 
     # ---- tensors ------------------------------------------------------------------------------
     def _f32(self, t, shape=None) -> torch.Tensor:
+        """The tensor as a contiguous fp32 tensor on this engine's device.  A tensor that already is one is passed through
+        untouched (the hot path); anything else (host tensors as the reference's loaders yield them, other dtypes, numpy)
+        is converted -- an H2D copy per call, which a caller on the hot path avoids by keeping its tensors on the device."""
         if not isinstance(t, torch.Tensor):
             t = torch.as_tensor(np.asarray(t))
-        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if not (t.device == self.device and t.dtype == torch.float32 and t.is_contiguous()):
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
         if shape is not None and tuple(t.shape) != tuple(shape):
             raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
         return t
@@ -134,17 +138,29 @@ class FernEngine:
         _lib.check(self.lib.fern_vit_encode_image(self._h, _ptr(x), _ptr(out), x.shape[0], _stream()), "fern_vit_encode_image")
         return out
 
-    def encode_text(self, tokens: torch.Tensor, want_global=True, want_seq=True):
+    def encode_text(self, tokens: torch.Tensor, want_global=True, want_seq=True, visual_emb: Optional[torch.Tensor] = None):
+        """tokens int64 [B,ctx] -> (global [B,D] | None, seq [B,ctx,D] | None).  `visual_emb` [13,B,D] is the reference's
+        argument of that name (models/clip_model.py:23-31): shape-checked by the library, values unused.  Token ids outside
+        the vocabulary raise IndexError like nn.Embedding when the tokens are on the host (as the reference's tokenizer leaves
+        them, test_fiq.py:98); for device tokens the library flags them at the next sync / encode_text (no sync here)."""
         cfg = self.clip_cfg
         if cfg is None:
             raise _lib.FernError("encode_text: CLIP weights not finalised")
+        if tokens.dim() != 2 or tokens.shape[1] != cfg.context_length:
+            raise ValueError(f"text must be int64 [B,{cfg.context_length}], got {tuple(tokens.shape)}")
+        if not tokens.is_cuda and tokens.numel() and (int(tokens.min()) < 0 or int(tokens.max()) >= cfg.vocab_size):
+            raise IndexError(f"token id out of range [0, {cfg.vocab_size}): min {int(tokens.min())}, max {int(tokens.max())}")
         t = tokens.to(device=self.device, dtype=torch.int64).contiguous()
-        if t.dim() != 2 or t.shape[1] != cfg.context_length:
-            raise ValueError(f"text must be int64 [B,{cfg.context_length}], got {tuple(t.shape)}")
         b = t.shape[0]
+        ve, ve_shape = None, None
+        if visual_emb is not None:
+            if visual_emb.dim() != 3:
+                raise ValueError(f"visual_emb must be [{PATCH_NUM}, B, {cfg.embed_dim}], got {tuple(visual_emb.shape)}")
+            ve = visual_emb if visual_emb.is_cuda else visual_emb.to(self.device)      # only its address and shape cross the ABI
+            ve_shape = (C.c_int64 * 3)(*visual_emb.shape)
         g = self._empty(b, cfg.embed_dim) if want_global else None
         s = self._empty(b, cfg.context_length, cfg.embed_dim) if want_seq else None
-        _lib.check(self.lib.fern_text_encode(self._h, _ptr(t), _ptr(g), _ptr(s), b, _stream()), "fern_text_encode")
+        _lib.check(self.lib.fern_text_encode(self._h, _ptr(t), _ptr(ve), ve_shape, _ptr(g), _ptr(s), b, _stream()), "fern_text_encode")
         return g, s
 
     # ---- fusion -------------------------------------------------------------------------------
@@ -162,6 +178,8 @@ class FernEngine:
             raise ValueError(f"ref_local_feats must be [B,{PATCH_NUM},{d}], got {tuple(rl.shape)}")
         if ts.dim() != 3 or ts.shape[0] != b or ts.shape[2] != d:
             raise ValueError(f"text_seq_feats must be [B,T,{d}], got {tuple(ts.shape)}")
+        if ts.shape[1] < PATCH_NUM:      # fusion_model.py:47 keeps 13 text-query rows for BatchNorm1d(13)
+            raise ValueError(f"text_seq_feats needs at least {PATCH_NUM} token rows, got {ts.shape[1]}")
         rg, tg = self._f32(ref_global, (b, d)), self._f32(text_global, (b, d))
         out = self._empty(b, d)
         _lib.check(self.lib.fern_dvr_fuse(self._h, _ptr(rg), _ptr(rl), _ptr(tg), _ptr(ts), _ptr(out), b, ts.shape[1],
@@ -315,26 +333,6 @@ class FernEngine:
         out = torch.empty(m, n, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=self.device)
         _lib.check(self.lib.fern_gemm_bf16(self._h, _ptr(a), k, _ptr(w), k, _ptr(bias), _ptr(residual), _ptr(out), n, m, n, k,
                                            int(epilogue), int(bool(out_bf16)), _stream()), "fern_gemm_bf16")
-        return out
-
-    def split_bf16x3(self, x) -> torch.Tensor:
-        """fp32 [R,C] -> bf16 [3,R,C]: x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)."""
-        x = self._f32(x)
-        out = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device=self.device)
-        _lib.check(self.lib.fern_split_bf16x3(self._h, _ptr(x), _ptr(out), x.numel(), _stream()), "fern_split_bf16x3")
-        return out
-
-    def gemm_bf16x3(self, a3, w3, bias=None, residual=None, epilogue=EPI_BIAS) -> torch.Tensor:
-        """fp32-grade GEMM from bf16x3 operands; a3 [3,M,K] / w3 [3,N,K] from `split_bf16x3` (fp32 inputs are split first)."""
-        a3 = a3 if a3.dtype == torch.bfloat16 else self.split_bf16x3(a3)
-        w3 = w3 if w3.dtype == torch.bfloat16 else self.split_bf16x3(w3)
-        _, m, k = a3.shape
-        n = w3.shape[1]
-        bias = None if bias is None else self._f32(bias, (n,))
-        residual = None if residual is None else self._f32(residual, (m, n))
-        out = self._empty(m, n)
-        _lib.check(self.lib.fern_gemm_bf16x3(self._h, _ptr(a3), k, _ptr(w3), k, _ptr(bias), _ptr(residual), _ptr(out), n, m, n, k,
-                                             int(epilogue), _stream()), "fern_gemm_bf16x3")
         return out
 
     def quantize_rows_fp8(self, x):

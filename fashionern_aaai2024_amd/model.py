@@ -31,7 +31,14 @@ class ERN:
     def load_state_dict(self, state_dict: Mapping[str, object], strict: bool = True):
         """Accepts a full ``ERN.state_dict()``: fusion keys are consumed; ``image_clip.*`` / ``text_clip.*`` are
         forwarded to the wrapped clip_model when it can take them; ``position_ids`` / ``num_batches_tracked`` /
-        pooler weights are accepted and unused."""
+        pooler weights are accepted and unused.
+
+        ``strict`` follows ``nn.Module.load_state_dict`` (test_fiq.py:149 calls it with the default, True): with
+        ``strict=True`` a missing or an unexpected fusion key raises ``RuntimeError`` naming the keys; with ``strict=False``
+        unexpected keys are dropped, missing ones keep the values of the previous load (an error if there was none), and the
+        ``(missing_keys, unexpected_keys)`` pair is returned instead of ``self``.  Two keys are optional in both modes
+        because real checkpoints differ in them: ``DVR.transformer_layer.cls_token`` (absent from GPU-trained
+        checkpoints -> zeros) and ``...embeddings.position_ids`` (a buffer in transformers 4.30.2, gone in later versions)."""
         fusion, clip = {}, {}
         for k, v in state_dict.items():
             arr = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
@@ -41,13 +48,28 @@ class ERN:
                 clip.setdefault(k[len(_CLIP_PREFIXES[1]):], arr)
             else:
                 fusion[k] = arr
-        self.engine.load_tensors(fusion)
+        expected = set(synth.fusion_state_dict(self.feature_dim, 0).keys())
+        optional = {"DVR.transformer_layer.cls_token", "DVR.transformer_layer.bert_encoder.bert_model.embeddings.position_ids"}
+        optional |= {k for k in fusion if k.endswith("num_batches_tracked")}
+        missing = sorted(k for k in expected - optional if k not in fusion)
+        unexpected = sorted(k for k in fusion if k not in expected and k not in optional)
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict for ERN: missing key(s): " + ", ".join(missing or ["-"]) +
+                               "; unexpected key(s): " + ", ".join(unexpected or ["-"]))
+        for k in unexpected:
+            del fusion[k]
+        still = [k for k in missing if k not in self._state]
+        if still:
+            raise RuntimeError("load_state_dict(strict=False): no earlier value to keep for missing key(s): " + ", ".join(still))
+        merged = dict(self._state) if missing else {}
+        merged.update(fusion)
+        self.engine.load_tensors(merged)
         self.engine.finalize_fusion(self.feature_dim, PART_ALL)
-        self._state = fusion
+        self._state = merged
         cm = self.image_clip.clip_model
         if clip and hasattr(cm, "load_state_dict") and getattr(cm, "engine", None) is not None:
             cm.load_state_dict(clip)
-        return self
+        return self if strict else (missing, unexpected)
 
     def init_random(self, seed: int = 0):
         return self.load_state_dict(synth.fusion_state_dict(self.feature_dim, seed))

@@ -204,6 +204,35 @@ def gpu_preprocess(engine: FernEngine, target_ratio: float = 1.25, dim: int = 28
     (the reference passes ``targetpad_transform(target_ratio, dim)``, dataloader/dataset.py:73-87).  Image *decoding* stays
     with PIL on the host.  Use with ``num_workers=0`` (the HIP context lives in this process)."""
     def run(image):
-        arr = torch.from_numpy(np.array(image.convert("RGB"), dtype=np.uint8)).to(engine.device)
-        return targetpad_transform(engine, arr, target_ratio, dim).cpu()
+        if image.mode == "RGB":
+            arr = torch.from_numpy(np.array(image, dtype=np.uint8)).to(engine.device)
+            return targetpad_transform(engine, arr, target_ratio, dim).cpu()
+        # The reference pads and resizes in the image's NATIVE mode and converts to RGB afterwards (dataset.py:73-87), and PIL's
+        # resize is mode dependent (RGBA / LA: premultiplied alpha; P / 1: forced NEAREST; a P-mode pad fill of 0 is palette
+        # entry 0, not black).  The GPU resampler implements the 8-bit RGB arithmetic only, so such files -- rare: FashionIQ /
+        # CIRR ship RGB PNGs -- take PIL itself for pad + resize, beside the decode it already does; crop / ToTensor /
+        # Normalize still run on the GPU.
+        return pil_native_mode_transform(engine, image, target_ratio, dim).cpu()
     return run
+
+
+def pil_native_mode_transform(engine: FernEngine, image, target_ratio: float, dim: int) -> torch.Tensor:
+    """dataset.py:73-87 for a non-RGB PIL image: TargetPad and Resize(dim, BICUBIC) by Pillow in the image's own mode, then
+    RGB conversion, then CenterCrop + ToTensor + Normalize through ``fern_u8_to_normalized_chw``."""
+    from PIL import Image
+    w, h = image.size
+    if max(w, h) / min(w, h) >= target_ratio:                                       # TargetPad.__call__ (dataset.py:46-54)
+        scaled = max(w, h) / target_ratio
+        hp, vp = max(int((scaled - w) / 2), 0), max(int((scaled - h) / 2), 0)
+        padded = Image.new(image.mode, (w + 2 * hp, h + 2 * vp), 0)                 # F.pad(image, [hp, vp], 0, 'constant')
+        if image.mode == "P":
+            padded.putpalette(image.getpalette())
+        padded.paste(image, (hp, vp))
+        image = padded
+    w, h = image.size
+    size = (dim, int(dim * h / w)) if w <= h else (int(dim * w / h), dim)           # torchvision Resize(int)
+    image = image.resize(size, Image.BICUBIC).convert("RGB")
+    nw, nh = image.size
+    top, left = int(round((nh - dim) / 2.0)), int(round((nw - dim) / 2.0))          # CenterCrop
+    arr = torch.from_numpy(np.array(image, dtype=np.uint8)).to(engine.device)
+    return to_normalized_chw(engine, arr, dim, dim, x0=left, y0=top)[0]

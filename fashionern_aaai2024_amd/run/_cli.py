@@ -132,7 +132,7 @@ def main(kind: str) -> None:
         raise SystemExit(f"--feature-dim/--input-dim do not match {cfg.name} ({cfg.embed_dim}/{cfg.image_size})")
     if not args.data_root:
         register_tokenizer(args.clip_model_name, hash_tokenizer(cfg.vocab_size))      # real data: open_clip / FERN_CLIP_BPE_VOCAB / registered
-    model = ERN(clip_model, args.feature_dim, device)
+    model = ERN(clip_model, args.feature_dim, device, engine=clip_model.engine)      # one context: --precision reaches the fusion blocks too
     if args.fusion_model_path:
         model.load_state_dict(torch.load(args.fusion_model_path, map_location="cpu"))
     else:

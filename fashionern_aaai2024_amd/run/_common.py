@@ -18,7 +18,6 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 from torch.utils.data import DataLoader
 
 from ..tokenizer import get_tokenizer
@@ -86,11 +85,7 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
 
 def fuse_index(model, index_features, index_local_features):
     """test_fiq.py:45-46."""
-    eng = getattr(model, "engine", None)
-    if eng is not None and hasattr(eng, "index_fuse"):
-        return eng.index_fuse(index_features, index_local_features, normalize_input=True)
-    idx = F.normalize(index_features, dim=-1).float()
-    return model(tar_feats=idx, tar_local_feats=index_local_features, mode="index").float()
+    return _engine_of(model).index_fuse(index_features, index_local_features, normalize_input=True)
 
 
 def _pct(count: int, total: int) -> float:

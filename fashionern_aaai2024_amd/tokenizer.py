@@ -22,16 +22,15 @@ _REGISTRY: Dict[str, Callable] = {}
 
 @lru_cache()
 def _byte_alphabet() -> Dict[int, str]:
-    """Every byte value as one printable unicode character: the printable Latin-1 ranges map to themselves, the other 68
-    bytes to code points 256, 257, ... in increasing byte order."""
-    keep = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
-    table, extra = {}, 0
+    """Every byte value as one printable unicode character.  ORDER MATTERS: the dict's insertion order is CLIP's vocabulary
+    order of the 256 single-byte symbols -- first the 188 printable Latin-1 bytes ('!'..'~', 0xA1..0xAC, 0xAE..0xFF), mapped to
+    themselves (so '!' is id 0, 'a' id 64), then the remaining 68 bytes in increasing byte order, mapped to code points 256,
+    257, ... (ids 188..255).  ``list(_byte_alphabet().values())`` is therefore rows 0..255 of ``token_embedding``."""
+    printable = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    table = {b: chr(b) for b in printable}
     for b in range(256):
-        if b in keep:
-            table[b] = chr(b)
-        else:
-            table[b] = chr(256 + extra)
-            extra += 1
+        if b not in table:
+            table[b] = chr(256 + len(table) - len(printable))
     return table
 
 

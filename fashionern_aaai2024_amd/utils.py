@@ -49,36 +49,3 @@ def extract_index_features(dataset, clip_model, patch_num, device, feature_dim, 
         names.extend(batch_names)
         at += b
     return whole[:at], names, local[:at]       # at < n only if collate_fn dropped unreadable items
-
-
-def concat_global_local_feats(global_feats: torch.Tensor, local_feats: torch.Tensor) -> torch.Tensor:
-    """[B, D] and [B, P, D] -> [B, P + 1, D], global feature first (utils/utils.py:32-41)."""
-    return torch.cat((global_feats.unsqueeze(1), local_feats), dim=1)
-
-
-def _clean_caption(c: str) -> str:
-    return c.strip(".?, ")
-
-
-def generate_shoes_caption(flattened_captions: List[str]) -> List[str]:
-    """One caption per query, trimmed of '.?, ' and capitalised (utils/utils.py:126-130)."""
-    return [_clean_caption(c).capitalize() for c in flattened_captions]
-
-
-def generate_randomized_fiq_caption(flattened_captions: List[str]) -> List[str]:
-    """Training-time FashionIQ caption mixing (utils/utils.py:102-123): per pair, with probability 1/4 each, "A and b",
-    "B and a", "A" or "B" (drawn with ``random.random()`` like the reference, so ``setup_seed`` makes it reproducible)."""
-    import random
-    out = []
-    for i in range(0, len(flattened_captions), 2):
-        a, b = _clean_caption(flattened_captions[i]), _clean_caption(flattened_captions[i + 1])
-        u = random.random()
-        if u < 0.25:
-            out.append(f"{a.capitalize()} and {b}")
-        elif 0.25 < u < 0.5:
-            out.append(f"{b.capitalize()} and {a}")
-        elif 0.5 < u < 0.75:
-            out.append(a.capitalize())
-        else:
-            out.append(b.capitalize())
-    return out

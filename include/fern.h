@@ -14,7 +14,13 @@
  *   - launch functions are asynchronous on `stream` (a hipStream_t passed as void*) and never
  *     synchronise; workspaces grow on first use (hipMalloc), so run one warm-up call per shape
  *     before capturing into a hipGraph;
- *   - a context is bound to one device and is not thread-safe (one per device per process).
+ *   - a context is bound to one device and is not thread-safe (one per device per process);
+ *   - re-finalising a weight group (fern_finalize_*) frees its previous device copy and invalidates forks made earlier;
+ *   - NO collectives are exported.  SURVEY.md 8b listed fern_comm_init / fern_all_gather; they are deliberately left to
+ *     torch.distributed (backend "nccl" = RCCL over xGMI, "gloo" in the CPU tests): the path has exactly one exchange
+ *     step -- the all-gather of fused gallery shards -- and the reference side already owns a process group, so a second
+ *     communicator inside this library would only duplicate its bootstrap.  The gallery-sharded alternative needs
+ *     fern_sim_topk(idx_offset=) + fern_topk_merge from this library and two all-gathers from the caller.
  */
 #ifndef FERN_H
 #define FERN_H
@@ -26,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FERN_ABI_VERSION 1
+#define FERN_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define FERN_API __attribute__((visibility("default")))
@@ -156,9 +162,14 @@ FERN_API int fern_finalize_clip(fern_ctx* ctx, const fern_clip_config* cfg); /* 
 FERN_API int fern_vit_encode_image(fern_ctx* ctx, const float* images, float* out, int b, void* stream);
 /* clip_model.encode_text(text, mode=, visual_emb=) -- call sites run/test/test_fiq.py:102-103,
  * models/clip_model.py:23-31.  tokens [B,ctx] int64 -> out_global [B,D] (may be NULL) and
- * out_seq [B,ctx,D] (may be NULL); one tower pass serves both (SURVEY.md 8c definition). */
-FERN_API int fern_text_encode(fern_ctx* ctx, const int64_t* tokens, float* out_global, float* out_seq, int B,
-                     void* stream);
+ * out_seq [B,ctx,D] (may be NULL); one tower pass serves both (SURVEY.md 8c definition).
+ * visual_emb (may be NULL) is the reference's `visual_emb=ref_patch_feats.transpose(0, 1)` argument: a device pointer with
+ * visual_emb_shape = HOST int64[3], which must equal {13, B, embed_dim} (FERN_ERR_ARG otherwise); its values are not read
+ * (the text encoder that consumes them is unreleased, README.md:41 -- "vanilla CLIP single branch").
+ * A token id outside [0, vocab_size) makes the caption's features NaN and is reported as FERN_ERR_ARG by fern_sync or by the
+ * next fern_text_encode on the context (nn.Embedding raises in the reference; the launch path here never synchronises). */
+FERN_API int fern_text_encode(fern_ctx* ctx, const int64_t* tokens, const float* visual_emb, const int64_t* visual_emb_shape,
+                              float* out_global, float* out_seq, int B, void* stream);
 
 /* fusion -------------------------------------------------------------------------------- */
 /* ERN.forward(mode="test") = DVR_module.forward -- models/model.py:68-69, fusion_model.py:26-55 */
@@ -246,14 +257,6 @@ FERN_API int fern_gemm(fern_ctx* ctx, const float* A, int64_t lda, const float* 
 FERN_API int fern_gemm_bf16(fern_ctx* ctx, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias,
                    const float* residual, void* C, int64_t ldc, int M, int N, int K, int epilogue, int out_bf16,
                    void* stream);
-/* bf16x3 operand form: fp32-grade products from bf16 MFMAs.  fern_split_bf16x3 writes an fp32 buffer of n elements as three
- * bf16 planes y[0..n), y[n..2n), y[2n..3n): x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (their sum is x to 2^-27).
- * fern_gemm_bf16x3 takes A3 [3][M,lda] and W3 [3][N,ldw] in that layout and accumulates the six products a_i b_j with
- * i + j <= 2 in fp32: the dropped terms are below 2^-25 |a||b|, under one fp32 rounding of the product, so the result is
- * an fp32 dot product in a different summation order (not bit-identical to fern_gemm).  K % 32 == 0, lda/ldw % 8 == 0. */
-FERN_API int fern_split_bf16x3(fern_ctx* ctx, const float* x, uint16_t* y, int64_t n, void* stream);
-FERN_API int fern_gemm_bf16x3(fern_ctx* ctx, const uint16_t* A3, int64_t lda, const uint16_t* W3, int64_t ldw, const float* bias,
-                     const float* residual, float* C, int64_t ldc, int M, int N, int K, int epilogue, void* stream);
 /* fp8 (OCP e4m3fn) operand form: A [M,lda] / W [N,ldw] bytes with per-row scales (fern_quantize_rows_fp8 produces both:
  * scale[r] = max|row r| / 448, or 1 for a zero row; y = fp8(x / scale[r]), round to nearest even);
  * C = (sum_k A8 W8) * scale_a[row] * scale_w[col] + bias (+ GELU | + residual), fp32 accumulation on

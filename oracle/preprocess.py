@@ -21,6 +21,8 @@ def target_pad(img: Image.Image, target_ratio: float) -> Image.Image:           
     scaled = max(w, h) / target_ratio
     hp, vp = max(int((scaled - w) / 2), 0), max(int((scaled - h) / 2), 0)
     out = Image.new(img.mode, (w + 2 * hp, h + 2 * vp), 0)                              # F.pad(image, padding, 0, 'constant')
+    if img.mode == "P":                                                                 # torchvision keeps the palette of P-mode images
+        out.putpalette(img.getpalette())
     out.paste(img, (hp, vp))
     return out
 

@@ -42,7 +42,7 @@ class OracleEngine:
     def encode_image(self, images):
         return oclip.encode_image(self.sd, self.clip_cfg, images.float().cpu(), precision=self.precision)
 
-    def encode_text(self, tokens, want_global=True, want_seq=True):
+    def encode_text(self, tokens, want_global=True, want_seq=True, visual_emb=None):
         g, s = oclip.encode_text(self.sd, self.clip_cfg, tokens.cpu(), precision=self.precision)
         return (g if want_global else None), (s if want_seq else None)
 

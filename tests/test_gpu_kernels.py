@@ -334,42 +334,14 @@ def test_gemm_fp8(engine, m, n, k, epi, out_bf16):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m,n,k", [(64, 128, 64), (197, 384, 96), (1000, 520, 256), (4096, 768, 768)])
-@pytest.mark.parametrize("epi", [0, 1, 3])
-def test_gemm_bf16x3_is_fp32_grade(engine, m, n, k, epi):
-    """bf16x3 GEMM (three bf16 planes per operand, six exact partial products, fp32 accumulation) against fp64 math on the
-    ORIGINAL fp32 operands, at the tolerance of the fp32 MFMA GEMM test -- and no further from the truth than that kernel."""
-    g = torch.Generator().manual_seed(m * 3 + n + k + epi)
-    a = torch.randn(m, k, generator=g)
-    w = torch.randn(n, k, generator=g) * k ** -0.5
-    b = torch.randn(n, generator=g)
-    r = torch.randn(m, n, generator=g)
-    a3 = engine.split_bf16x3(a)
-    s = a3.float().cpu()
-    assert (s[0] + s[1] + s[2] - a).abs().max().item() <= 2 ** -24 * a.abs().max().item()       # the planes re-assemble x
-    assert torch.equal(s[0], a.bfloat16().float())
-    ref = a.double() @ w.double().T + b.double()
-    if epi == 1:
-        ref = torch.nn.functional.gelu(ref)
-    elif epi == 3:
-        ref = ref + r.double()
-    got = engine.gemm_bf16x3(a, w, b, residual=r if epi == 3 else None, epilogue=epi).cpu().double()
-    f32 = engine.gemm(a, w, b, residual=r if epi == 3 else None, epilogue=epi).cpu().double()
-    assert torch.allclose(got, ref, rtol=1e-5, atol=2e-5)
-    err_x3, err_f32 = (got - ref).abs().max().item(), (f32 - ref).abs().max().item()
-    assert err_x3 < 4 * err_f32 + 1e-7, (err_x3, err_f32)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("var,cfg", [("FERN_GEMM_BF16_CFG", c) for c in range(7)] + [("FERN_GEMM_FP8_CFG", c) for c in range(6)] +
-                         [("FERN_GEMM_X3_CFG", c) for c in range(2)])
+@pytest.mark.parametrize("var,cfg", [("FERN_GEMM_BF16_CFG", c) for c in range(7)] + [("FERN_GEMM_FP8_CFG", c) for c in range(6)])
 def test_every_reduced_precision_gemm_tile_variant(var, cfg):
-    """The bf16 / fp8 / bf16x3 launchers pick (or tune) a tile per shape; each variant is also forced over its shape suite."""
+    """The bf16 / fp8 launchers pick (or tune) a tile per shape; each variant is also forced over its shape suite."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    key = {"FERN_GEMM_BF16_CFG": "test_gemm_bf16 and not x3", "FERN_GEMM_FP8_CFG": "test_gemm_fp8", "FERN_GEMM_X3_CFG": "test_gemm_bf16x3"}[var]
+    key = {"FERN_GEMM_BF16_CFG": "test_gemm_bf16", "FERN_GEMM_FP8_CFG": "test_gemm_fp8"}[var]
     env = dict(os.environ, **{var: str(cfg)})
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "-m", "gpu", "-q", "-x", "-k", key, "-p", "no:cacheprovider"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)

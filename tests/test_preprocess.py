@@ -75,6 +75,26 @@ def test_gpu_targetpad_transform_matches_reference_pipeline(engine, w, h, dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "LA", "L", "P", "1"])
+def test_gpu_preprocess_callable_handles_every_pil_mode_like_the_reference(engine, mode):
+    """The dataset classes hand `gpu_preprocess(...)` PIL images of whatever mode the file decodes to; the reference pads and
+    resizes in that mode and converts to RGB afterwards (dataset.py:73-87).  Wide image, so TargetPad is exercised."""
+    rgb = Image.fromarray(_img(610, 300, 9))
+    if mode in ("RGBA", "LA"):
+        alpha = Image.fromarray(_img(610, 300, 10)[..., 0])
+        img = rgb.convert(mode[:-1])
+        img.putalpha(alpha)
+    elif mode == "P":
+        img = rgb.quantize(colors=64)
+    else:
+        img = rgb.convert(mode)
+    assert img.mode == mode
+    ref = opp.targetpad_transform(img, 1.25, 224)
+    got = pp.gpu_preprocess(engine, 1.25, 224)(img)
+    assert got.shape == (3, 224, 224) and not got.is_cuda and torch.equal(got, ref)
+
+
+@pytest.mark.gpu
 def test_gpu_patch_extraction_matches_reference_pipeline(engine):
     from fashionern_aaai2024_amd import synth
     from fashionern_aaai2024_amd.clip_model import create_model

@@ -26,7 +26,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--shapes", default="all")
-    ap.add_argument("--x3", action="store_true", help="bf16x3 kernel (fp32-grade; FERN_GEMM_X3_CFG picks the tile)")
     ap.add_argument("--bf16", action="store_true", help="bf16-operand kernel (FERN_GEMM_BF16_CFG picks the tile)")
     args = ap.parse_args()
     eng = FernEngine("cuda:0")
@@ -38,10 +37,7 @@ def main():
             w = torch.randn(n, k, device="cuda") * k ** -0.5
             b = torch.randn(n, device="cuda")
             r = torch.randn(m, n, device="cuda") if epi == 3 else None
-            if args.x3:
-                a3, w3 = eng.split_bf16x3(a), eng.split_bf16x3(w)
-                run = lambda: eng.gemm_bf16x3(a3, w3, b, residual=r, epilogue=epi)  # noqa: E731
-            elif args.bf16:
+            if args.bf16:
                 ab, wb = eng.to_bf16(a), eng.to_bf16(w)
                 out_b = epi in (0, 1)
                 run = lambda: eng.gemm_bf16(ab, wb, b, residual=r, epilogue=epi, out_bf16=out_b)  # noqa: E731
