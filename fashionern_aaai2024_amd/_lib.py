@@ -74,6 +74,7 @@ SIGNATURES = {
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "fern_prof_enable": (c_int, [c_void_p, c_int]),
     "fern_prof_collect": (c_int, [c_void_p, C.POINTER(ProfStats)]),
+    "fern_tuner_export": (c_i64, [C.c_char_p, c_i64]),
 }
 
 _lib = None

@@ -107,6 +107,7 @@ struct fern_ctx {
     const fern_ctx* parent = nullptr;
     unsigned parent_generation = 0;
     int* tok_flag = nullptr;         // host-mapped: set by the text embedding kernel when a token id is out of range
+    int* rank_flag = nullptr;        // host-mapped: set when a top-K candidate list overflowed twice (result row is NaN / -1)
     FusionW fusion;
     ClipW clip;
     Clip4CirW c4c;
@@ -342,6 +343,7 @@ static int begin_group(fern_ctx* c, int group) {
     return FERN_OK;
 }
 static int check_token_flag(fern_ctx* c, const char* fn);
+static int check_rank_flag(fern_ctx* c, const char* fn);
 // Weight-reading entry points call this first: a fork made before the parent's last re-finalisation must not run.
 static int check_fresh(fern_ctx* c, const char* fn) {
     if (c->parent && c->parent->generation != c->parent_generation)
@@ -391,6 +393,7 @@ extern "C" int fern_ctx_destroy(fern_ctx* c) {
     for (auto& grp : c->owned)
         for (void* p : grp) (void)hipFree(p);
     if (c->tok_flag) (void)hipHostFree(c->tok_flag);
+    if (c->rank_flag) (void)hipHostFree(c->rank_flag);
     for (auto& b : c->blocks) (void)hipFree(b.p);
     for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -400,6 +403,7 @@ extern "C" int fern_ctx_destroy(fern_ctx* c) {
 extern "C" int fern_sync(fern_ctx* c, void* stream) {
     if (!c) return fail(FERN_ERR_ARG, "fern_sync: ctx is NULL");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    FERN_TRY(check_rank_flag(c, "fern_sync"));
     return check_token_flag(c, "fern_sync");
 }
 
@@ -1283,6 +1287,17 @@ static int check_token_flag(fern_ctx* c, const char* fn) {
                                                  "position " + std::to_string(v - 1) + " of its chunk (its features are NaN): tokenizer / vocabulary mismatch?");
 }
 
+// The fused sweep's candidate lists are sized for ~4x the expected survivors and get one retry with a tightened bound; a second
+// overflow (more than cap^2 / K rows above the sampled bound) leaves NaN / -1 in that query's row and is reported here.
+static int check_rank_flag(fern_ctx* c, const char* fn) {
+    if (!c->rank_flag) return FERN_OK;
+    const int v = __atomic_load_n(c->rank_flag, __ATOMIC_RELAXED);
+    if (v == 0) return FERN_OK;
+    __atomic_store_n(c->rank_flag, 0, __ATOMIC_RELAXED);
+    return fail(FERN_ERR_STATE, std::string(fn) + ": an earlier fern_sim_topk on this context overflowed a candidate list twice (query " +
+                                    std::to_string(v - 1) + " of its chunk): that row holds NaN scores and -1 indices");
+}
+
 extern "C" int fern_text_encode(fern_ctx* c, const int64_t* tokens, const float* visual_emb, const int64_t* visual_emb_shape, float* out_global,
                                 float* out_seq, int B, void* stream) {
     if (!c) return fail(FERN_ERR_ARG, "fern_text_encode: ctx is NULL");
@@ -1314,6 +1329,49 @@ extern "C" int fern_text_encode(fern_ctx* c, const int64_t* tokens, const float*
 // ------------------------------------------------------------------------------------------------
 // rank
 // ------------------------------------------------------------------------------------------------
+// Fused sweep + selection (kernels.h: TopkFilter): plan and workspace of one query chunk.
+//   sample pass   S = N / R rows (R = 64; at least 1024 rows, or all of them), scores stored [m, S]       -> PROF_TOPK
+//   bound         per query the K-th best sample key, a lower bound of the true K-th best                 -> PROF_TOPK
+//   sweep         the full pass: nothing stored, ~K*R survivors per query appended to cand[m][cap]        -> PROF_SWEEP
+//   select        exact top-K of each list; an overflowed list raises its bound and arms the retry pair   -> PROF_TOPK
+//   retry pair    the same sweep + select, gated on flags[0] (empty launches unless a list overflowed)    -> PROF_TOPK
+struct RankPlan {
+    long S; int R; int cap;
+    float* sample; long ld;
+    unsigned long long* thr; int* count; int* flags;
+    TopkFilter filt;
+};
+static int rank_plan(fern_ctx* c, int m, int64_t N, int K, const int32_t* exclude, int64_t idx_offset, RankPlan* P) {
+    P->R = 64;
+    P->S = N / P->R;
+    if (P->S < 1024) {
+        P->S = std::min<long>(N, 1024);
+        P->R = P->S > 0 ? (int)(N / P->S) : 1;
+    }
+    long cap = 1024;
+    while (cap < 4L * K * P->R) cap *= 2;          // expected survivors per query ~ K * R
+    static const int cap_override = [] { const char* e = std::getenv("FERN_RANK_CAP"); return e ? std::atoi(e) : 0; }();
+    if (cap_override >= 64) cap = cap_override;     // test hook: tiny lists force the overflow / retry / error paths
+    P->cap = (int)cap;
+    P->ld = (std::max<long>(P->S, 4) + 3) & ~3L;
+    FERN_TRY(ws_get(c, (size_t)m * P->ld, &P->sample));
+    FERN_TRY(ws_get(c, (size_t)m, &P->thr));
+    FERN_TRY(ws_get(c, (size_t)m, &P->count));
+    FERN_TRY(ws_get(c, (size_t)4, &P->flags));
+    unsigned long long* cand;
+    FERN_TRY(ws_get(c, (size_t)m * P->cap, &cand));
+    P->filt = TopkFilter{cand, P->thr, P->count, exclude, (long)idx_offset, P->cap};
+    return FERN_OK;
+}
+static int rank_flag_ready(fern_ctx* c, const char* fn) {
+    if (!c->rank_flag) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->rank_flag), sizeof(int), hipHostMallocMapped));
+        *c->rank_flag = 0;
+    }
+    return check_rank_flag(c, fn);
+}
+static const size_t kRankQueryChunk = 1024;      // queries per plan: bounds cand[m][cap] (128 KiB per query at K = 50, R = 64)
+
 extern "C" int fern_sim_topk(fern_ctx* c, const float* q, const float* gallery, int B, int64_t N, int D, int K, float* out_scores,
                              int32_t* out_idx, int64_t idx_offset, const int32_t* exclude_idx, void* stream) {
     if (!c) return fail(FERN_ERR_ARG, "fern_sim_topk: ctx is NULL");
@@ -1323,28 +1381,33 @@ extern "C" int fern_sim_topk(fern_ctx* c, const float* q, const float* gallery, 
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) return FERN_OK;
-    // queries are processed in chunks so the [chunk, N] score tile stays cache-sized
-    long chunk = std::max<long>(64, std::min<long>(1024, ((long)64 << 20) / std::max<long>(1, (long)N * 4)));
-    chunk = (chunk / 64) * 64;
-    for (long o = 0; o < B; o += chunk) {
-        const int m = (int)std::min<long>(chunk, B - o);
-        const int nseg = topk_num_segments(m, N);
+    FERN_TRY(rank_flag_ready(c, "fern_sim_topk"));
+    for (long o = 0; o < B; o += (long)kRankQueryChunk) {
+        const int m = (int)std::min<long>((long)kRankQueryChunk, B - o);
+        const int32_t* ex = exclude_idx ? exclude_idx + o : nullptr;
         FERN_TRY(ws_begin(c, s));
-        float* scores = nullptr;
-        unsigned long long* keys;
-        const long ld = ((long)N + 3) & ~3L;
-        FERN_TRY(ws_get(c, (size_t)m * std::max<long>(ld, 4), &scores));
-        FERN_TRY(ws_get(c, (size_t)m * nseg * 64, &keys));
-        if (N > 0) {
-            GemmParams p{};
-            p.A = q + o * D; p.lda = D; p.W = gallery; p.ldw = D; p.C = scores; p.ldc = ld;
-            p.M = m; p.N = (int)N; p.K = D; p.epi = EPI_BIAS; p.aload = ALOAD_PLAIN;
-            FERN_TRY(run_gemm(c, p, s, PROF_SWEEP, (double)N * D * 4 + (double)m * D * 4 + (double)m * N * 4));
-        }
+        RankPlan P;
+        FERN_TRY(rank_plan(c, m, N, K, ex, idx_offset, &P));
         int slot;
         FERN_TRY(prof_open(c, PROF_TOPK, 0, s, &slot));
-        HIP_TRY(launch_topk_rows(scores, ld, m, N, K, idx_offset, exclude_idx ? exclude_idx + o : nullptr, keys, out_scores + o * K,
-                                 out_idx + o * K, s));
+        if (P.S > 0) {      // sample pass: the same GEMM, W rows = jittered 1-in-R sample of the gallery
+            GemmParams p{};
+            p.A = q + o * D; p.lda = D; p.W = gallery; p.ldw = D; p.C = P.sample; p.ldc = P.ld;
+            p.M = m; p.N = (int)P.S; p.K = D; p.epi = EPI_BIAS; p.aload = ALOAD_PLAIN; p.w_sample = P.R;
+            HIP_TRY(launch_gemm(p, s));
+        }
+        HIP_TRY(launch_topk_sample_bound(P.sample, P.ld, m, P.S, P.R, K, ex, idx_offset, P.thr, P.count, P.flags, s));
+        FERN_TRY(prof_close(c, slot, s));
+        GemmParams p{};
+        p.A = q + o * D; p.lda = D; p.W = gallery; p.ldw = D; p.ldc = 4;
+        p.M = m; p.N = (int)N; p.K = D; p.epi = EPI_TOPK_FILTER; p.aload = ALOAD_PLAIN; p.filt = P.filt;
+        // algorithmic bytes of the sweep: gallery once, queries, results
+        if (N > 0) FERN_TRY(run_gemm(c, p, s, PROF_SWEEP, (double)N * D * 4 + (double)m * D * 4 + (double)m * K * 8));
+        FERN_TRY(prof_open(c, PROF_TOPK, 0, s, &slot));
+        HIP_TRY(launch_topk_candidates(P.filt, P.thr, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, 0, c->rank_flag, s));
+        p.gate = P.flags;
+        if (N > 0) HIP_TRY(launch_gemm(p, s));
+        HIP_TRY(launch_topk_candidates(P.filt, P.thr, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, 1, c->rank_flag, s));
         FERN_TRY(prof_close(c, slot, s));
     }
     return FERN_OK;
@@ -1368,22 +1431,42 @@ extern "C" int fern_sim_topk_bf16(fern_ctx* c, const float* q, const uint16_t* g
     if (N > 0x7FFFFFF0LL) return fail(FERN_ERR_ARG, "fern_sim_topk_bf16: N too large for int32 indices");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    const long ld = ((long)N + 3) & ~3L;
-    for (long o = 0; o < B; o += 64) {                         // the kernel keeps <= 64 queries resident in LDS
-        const int m = (int)std::min<long>(64, B - o);
-        const int nseg = topk_num_segments(m, N);
+    if (B == 0) return FERN_OK;
+    FERN_TRY(rank_flag_ready(c, "fern_sim_topk_bf16"));
+    for (long o = 0; o < B; o += (long)kRankQueryChunk) {
+        const int m = (int)std::min<long>((long)kRankQueryChunk, B - o);
+        const int32_t* ex = exclude_idx ? exclude_idx + o : nullptr;
         FERN_TRY(ws_begin(c, s));
-        float* scores;
-        unsigned long long* keys;
-        FERN_TRY(ws_get(c, (size_t)m * std::max<long>(ld, 4), &scores));
-        FERN_TRY(ws_get(c, (size_t)m * nseg * 64, &keys));
+        RankPlan P;
+        FERN_TRY(rank_plan(c, m, N, K, ex, idx_offset, &P));
+        // the sweep kernel keeps <= 64 queries resident in LDS: one launch per 64-query block, shared plan buffers
+        auto block_filter = [&](long b0) {
+            TopkFilter f = P.filt;
+            f.cand += b0 * P.cap; f.thr_key += b0; f.count += b0;
+            if (f.exclude) f.exclude += b0;
+            return f;
+        };
         int slot;
-        FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + (double)m * D * 4 + (double)m * N * 4, s, &slot, m, (int)N, D, 16));
-        HIP_TRY(launch_sweep_bf16(q + o * D, gallery, scores, ld, m, N, D, s));
-        FERN_TRY(prof_close(c, slot, s));
         FERN_TRY(prof_open(c, PROF_TOPK, 0, s, &slot));
-        HIP_TRY(launch_topk_rows(scores, ld, m, N, K, idx_offset, exclude_idx ? exclude_idx + o : nullptr, keys, out_scores + o * K,
-                                 out_idx + o * K, s));
+        for (long b0 = 0; b0 < m; b0 += 64)
+            HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery, P.sample + b0 * P.ld, P.ld, (int)std::min<long>(64, m - b0), N, D, P.S, P.R,
+                                      nullptr, nullptr, s));
+        HIP_TRY(launch_topk_sample_bound(P.sample, P.ld, m, P.S, P.R, K, ex, idx_offset, P.thr, P.count, P.flags, s));
+        FERN_TRY(prof_close(c, slot, s));
+        for (long b0 = 0; b0 < m; b0 += 64) {
+            const int mb = (int)std::min<long>(64, m - b0);
+            const TopkFilter f = block_filter(b0);
+            FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + (double)mb * D * 4 + (double)mb * K * 8, s, &slot, mb, (int)N, D, 16));
+            HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery, nullptr, 0, mb, N, D, 0, 1, &f, nullptr, s));
+            FERN_TRY(prof_close(c, slot, s));
+        }
+        FERN_TRY(prof_open(c, PROF_TOPK, 0, s, &slot));
+        HIP_TRY(launch_topk_candidates(P.filt, P.thr, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, 0, c->rank_flag, s));
+        for (long b0 = 0; b0 < m; b0 += 64) {
+            const TopkFilter f = block_filter(b0);
+            HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery, nullptr, 0, (int)std::min<long>(64, m - b0), N, D, 0, 1, &f, P.flags, s));
+        }
+        HIP_TRY(launch_topk_candidates(P.filt, P.thr, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, 1, c->rank_flag, s));
         FERN_TRY(prof_close(c, slot, s));
     }
     return FERN_OK;
@@ -1521,6 +1604,21 @@ extern "C" int fern_attention_bf16(fern_ctx* c, const uint16_t* q, int64_t ldq, 
     AttnParams a{nullptr, nullptr, nullptr, nullptr, (long)ldq, (long)ldk, (long)ldv, (long)ldo, batch, heads, head_dim, s_q, s_k, causal, scale,
                  out, q, k, v};
     return run_attention(c, a, (hipStream_t)stream);
+}
+
+// The tuner's per-shape tile choices of this process (every context shares them), as text: one line per shape,
+// "f32|bf16|fp8 M N K epilogue loader|outflags cfg".  Returns the number of bytes the full text needs (excluding the
+// terminator); writes at most cap - 1 bytes + NUL.  A file of these lines, named by FERN_GEMM_TILES, pins the choices.
+extern "C" int64_t fern_tuner_export(char* buf, int64_t cap) {
+    std::string text;
+    gemm_tuner_export(text);
+    gemm_bf16_tuner_export(text);
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>(text.size(), (size_t)cap - 1);
+        std::memcpy(buf, text.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)text.size();
 }
 
 extern "C" int fern_prof_enable(fern_ctx* c, int on) {

@@ -17,9 +17,12 @@
 #include "kernels.h"
 #include "gemm_epilogue.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 
 namespace fern {
 
@@ -39,6 +42,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
 
     __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDS_S];
     __shared__ __attribute__((aligned(16))) float Ws[NBUF][BN * LDS_S];
+    if (p.gate && *p.gate == 0) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -76,7 +80,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
     for (int j = 0; j < WJ; ++j) {
         int row = bn * BN + r0 + RSTEP * j;
         row = row < p.N ? row : p.N - 1;
-        w_base[j] = p.W + (long)row * p.ldw;
+        w_base[j] = p.W + sample_row(row, p.w_sample) * p.ldw;
     }
 
     f32x4 a_stage[AJ], w_stage[WJ];
@@ -184,6 +188,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
     // the copy and the MFMAs of a wave.
     constexpr int TILE = ROWS * BKT;
     __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
+    if (p.gate && *p.gate == 0) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
         } else {
             int row = bn * BN + (trow - BM);
             row = row < p.N ? row : p.N - 1;
-            src[j] = p.W + (long)row * p.ldw + chunk * 4;
+            src[j] = p.W + sample_row(row, p.w_sample) * p.ldw + chunk * 4;
         }
     }
     auto stage = [&](int buf, int k0) {
@@ -318,6 +323,7 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmParams p) {
     constexpr int PPW = PIECES / NW;
     constexpr int TILE = ROWS * BKT;                     // floats per stage
     __shared__ __attribute__((aligned(1024))) float smem[STAGES * TILE];
+    if (p.gate && *p.gate == 0) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmParams p) {
         } else {
             int row = bn * BN + (trow - BM);
             row = row < p.N ? row : p.N - 1;
-            src[j] = p.W + (long)row * p.ldw + chunk * 4;
+            src[j] = p.W + sample_row(row, p.w_sample) * p.ldw + chunk * 4;
         }
     }
     auto stage = [&](int buf, int k0) {
@@ -529,7 +535,7 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
 }
 
 static bool skinny_ok(const GemmParams& p) {      // shapes / forms the 16x16 small-M kernel covers
-    return p.M <= 128 && (p.K % 64) == 0 && p.aload == ALOAD_PLAIN && p.epi != EPI_SR_LOCAL && p.epi != EPI_PATCH_EMBED;
+    return p.M <= 128 && (p.K % 64) == 0 && p.aload == ALOAD_PLAIN && p.epi != EPI_SR_LOCAL && p.epi != EPI_PATCH_EMBED && p.epi != EPI_TOPK_FILTER;
 }
 
 // ---- per-shape tile selection -------------------------------------------------------------------------------------
@@ -550,6 +556,33 @@ struct ShapeKey {
 static std::map<ShapeKey, int> g_tuned;
 static std::mutex g_tuned_mu;
 
+// FERN_GEMM_TILES=<file>: pin the per-shape choices (lines "f32 M N K epi aload cfg", as written by gemm_tuner_export /
+// fern_tuner_export): listed shapes are never timed again, so a run's kernels -- and its HBM / L2 traffic -- are reproducible
+// from box to box.  Loaded once, before the first tuned launch.
+static void load_pinned_tiles() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* path = getenv("FERN_GEMM_TILES");
+        FILE* f = path ? fopen(path, "r") : nullptr;
+        if (!f) return;
+        char kind[16];
+        int M, N, K, epi, aload, cfg;
+        std::lock_guard<std::mutex> lock(g_tuned_mu);
+        while (fscanf(f, "%15s %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &aload, &cfg) == 7)
+            if (!strcmp(kind, "f32") && cfg >= 0 && cfg < kNumCfgs && kCfgs[cfg].bk && K % kCfgs[cfg].bk == 0)
+                g_tuned[ShapeKey{M, N, K, epi, aload}] = cfg;
+        fclose(f);
+    });
+}
+void gemm_tuner_export(std::string& out) {
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    for (const auto& kv : g_tuned) {
+        char line[128];
+        snprintf(line, sizeof line, "f32 %d %d %d %d %d %d\n", kv.first.M, kv.first.N, kv.first.K, kv.first.epi, kv.first.aload, kv.second);
+        out += line;
+    }
+}
+
 static bool tuning_enabled() {
     static bool v = [] {
         const char* e = getenv("FERN_GEMM_TUNE");
@@ -565,15 +598,17 @@ static int tune_shape(const GemmParams& p, hipStream_t s) {
     long out_rows = p.M;
     if (p.epi == EPI_PATCH_EMBED) out_rows = p.M + p.M / (p.grid * p.grid) + 2;
     const bool reduce = epi_is_reduce(p.epi);
-    const size_t scratch_floats = reduce ? (size_t)p.M * ((p.N + 31) / 32) : (size_t)out_rows * p.ldc;
+    const size_t scratch_floats = reduce ? (size_t)p.M * ((p.N + 31) / 32) : p.epi == EPI_TOPK_FILTER ? 4 : (size_t)out_rows * p.ldc;
     float* scratch = nullptr;
     if (hipMalloc(&scratch, scratch_floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fallback; }
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     GemmParams q = p;
+    q.gate = nullptr;
     if (reduce) q.partial = scratch;
     else q.C = scratch;       // residual input (p.R) is only read: tuning has no side effects on the caller's buffers
+    if (p.epi == EPI_TOPK_FILTER) q.filt.thr_key = nullptr;      // trial launches reject every score: nothing is appended
     int best = fallback;
     float best_ms = 1e30f;
     static const int cands[] = {0, 1, 2, 3, 6, 8, 9, 10, 11};
@@ -610,6 +645,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     const double flops = 2.0 * p.M * (double)p.N * p.K;
     const bool tunable = forced_cfg() < 0 && tuning_enabled() && flops >= 2.5e8 && flops <= 2e11;
     if (tunable) {
+        load_pinned_tiles();
         const ShapeKey key{p.M, p.N, p.K, p.epi, p.aload};
         std::lock_guard<std::mutex> lock(g_tuned_mu);
         auto it = g_tuned.find(key);

@@ -13,9 +13,12 @@
 // results and a row's result does not depend on the batch it is part of.
 #include "gemm_epilogue.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 
 namespace fern {
 
@@ -226,6 +229,34 @@ struct ShapeKeyB {
 static std::map<ShapeKeyB, int> g_tuned_b;
 static std::mutex g_tuned_b_mu;
 
+// FERN_GEMM_TILES=<file>: lines "bf16 M N K epi ob cfg" / "fp8 M N K epi ob cfg" pin the choices (see gemm.hip)
+static void load_pinned_tiles_b() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* path = getenv("FERN_GEMM_TILES");
+        FILE* f = path ? fopen(path, "r") : nullptr;
+        if (!f) return;
+        char kind[16];
+        int M, N, K, epi, ob, cfg;
+        std::lock_guard<std::mutex> lock(g_tuned_b_mu);
+        while (fscanf(f, "%15s %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &ob, &cfg) == 7) {
+            const bool f8 = !strcmp(kind, "fp8");
+            if ((f8 || !strcmp(kind, "bf16")) && cfg >= 0 && cfg < (f8 ? kNumCfgsF8 : kNumCfgsB) && (f8 || K % kCfgsB[cfg].bk == 0))
+                g_tuned_b[ShapeKeyB{M, N, K, epi, ob}] = cfg;
+        }
+        fclose(f);
+    });
+}
+void gemm_bf16_tuner_export(std::string& out) {
+    std::lock_guard<std::mutex> lock(g_tuned_b_mu);
+    for (const auto& kv : g_tuned_b) {
+        char line[128];
+        snprintf(line, sizeof line, "%s %d %d %d %d %d %d\n", (kv.first.ob & 2) ? "fp8" : "bf16", kv.first.M, kv.first.N, kv.first.K, kv.first.epi,
+                 kv.first.ob, kv.second);
+        out += line;
+    }
+}
+
 static int heuristic_b(int M, int N) {
     static const int order[] = {2, 1, 0, 3, 5};       // largest tile that still gives every CU >= 2 workgroups' worth of work
     for (int c : order) {
@@ -274,6 +305,7 @@ static int tune_shape_b(const GemmParams& p, hipStream_t s) {
 
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    load_pinned_tiles_b();
     const int kq = p.fp8 ? 64 : 32, aq = p.fp8 ? 15 : 7;
     if (p.K <= 0 || (p.K % kq) != 0 || (p.lda & aq) || (p.ldw & aq) || p.aload != ALOAD_PLAIN || epi_is_reduce(p.epi)) return hipErrorInvalidValue;
     if (!p.Ab || !p.Wb || ((uintptr_t)p.Ab & 15) || ((uintptr_t)p.Wb & 15)) return hipErrorInvalidValue;

@@ -4,7 +4,31 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace fern {
+
+// ---- fused similarity sweep + top-K selection (shared by the fp32 GEMM sweep and the bf16 sweep) ------------------
+// The sweep never stores the [B, N] score matrix.  A first, small pass scores a jittered 1-in-R row SAMPLE of the gallery
+// and takes each query's K-th best sample key as a lower bound of its true K-th best; the full sweep then appends only
+// the scores that reach that bound (about K*R of N per query) to a per-query candidate list, and the final kernel
+// selects the exact top-K from the list.  Keys order by (score desc, gallery index asc) as one unsigned compare.
+struct TopkFilter {
+    unsigned long long* cand;             // [B][cap] candidate keys, appended in arrival order
+    const unsigned long long* thr_key;    // [B] lower bound: keys below it are not in the top-K (0: accept all, ~0: reject all)
+    int* count;                           // [B] candidates offered so far (may exceed cap: overflow, handled by a retry pass)
+    const int* exclude;                   // [B] gallery index to drop per query (CIRR reference removal), or null ...
+    long exclude_off;                     // ... as a global index: the local row is exclude[q] - exclude_off
+    int cap;
+};
+// sample column c -> gallery row: one row out of every run of R consecutive rows, at a hashed offset inside the run (a fixed
+// stride would alias with periodic structure in the gallery order); monotonic in c, so sample order = gallery order
+__host__ __device__ inline long sample_row(long c, int R) {
+    if (R <= 1) return c;
+    unsigned h = (unsigned)c * 2654435761u;
+    h ^= h >> 15;
+    return c * R + (long)(h % (unsigned)R);
+}
 
 // ---- GEMM: C[M,N] = A[M,K] * W[N,K]^T with fused epilogue (gemm.hip) ---------------------------
 enum GemmEpi : int {
@@ -17,7 +41,8 @@ enum GemmEpi : int {
     EPI_RELU_DOT = 6,        // partial[row][nb] = sum_col relu(acc + bias[col]) * aux0[col]       (Combiner hidden layer . w2)
     EPI_SR_LOCAL = 7,        // p = row % 13: v = tanh((acc + bias[col] - aux1[p]) * aux2[p] + aux3[p]);
                              // partial[row][nb] = sum_col v * G[(row/13)*ldg + col] * aux0[col]     (VisualSR local branch)
-    EPI_BIAS_RESIDUAL_RELU = 8  // C = relu(acc + bias + R[row*ldc + col])   (ResNet bottleneck tail: conv3 + BN folded + identity)
+    EPI_BIAS_RESIDUAL_RELU = 8, // C = relu(acc + bias + R[row*ldc + col])   (ResNet bottleneck tail: conv3 + BN folded + identity)
+    EPI_TOPK_FILTER = 9         // rows = queries, columns = gallery rows: nothing is stored; acc >= the query's bound is appended to p.filt
 };
 __host__ __device__ inline bool epi_is_reduce(int e) { return e == EPI_RELU_DOT || e == EPI_SR_LOCAL; }
 // ALOAD_IM2COL: non-overlapping patches of an NCHW image (ViT conv1); ALOAD_CONV3: 3x3 / stride 1 / pad 1 window over an
@@ -42,6 +67,9 @@ struct GemmParams {
     int img, patch, grid;  // ALOAD_IM2COL: image side, patch side, patches per side; EPI_PATCH_EMBED uses grid*grid
     int conv_h, conv_w, conv_c;   // ALOAD_CONV3
     const float* zeros;           // ALOAD_CONV3: >= 64 bytes of zeros (16-byte aligned)
+    int w_sample;                 // > 1: W row r is gallery row sample_row(r, w_sample) (the sample pass of the fused top-K sweep)
+    TopkFilter filt;              // EPI_TOPK_FILTER
+    const int* gate;              // when set: the launch does nothing unless *gate != 0 (retry pass of the fused top-K sweep)
     // bf16 operand form (launch_gemm_bf16): A [M, lda] and W [N, ldw] hold bf16 bit patterns, strides in elements
     const unsigned short* Ab;
     const unsigned short* Wb;
@@ -57,8 +85,51 @@ int gemm_num_col_blocks(int M, int N, int K);
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 // bf16 x bf16 -> fp32-accumulate GEMM (v_mfma_f32_32x32x16_bf16); plain epilogues only, K % 32 == 0, ALOAD_PLAIN
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s);
+// the per-shape tile choices made so far, one text line per shape (the format FERN_GEMM_TILES=<file> reads back)
+void gemm_tuner_export(std::string& out);
+void gemm_bf16_tuner_export(std::string& out);
 
 #ifdef __HIPCC__
+// 64-bit ranking keys: orderable(score) << 32 | ~index, so "score descending, index ascending" is one unsigned compare
+__device__ __forceinline__ unsigned orderable(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unorderable(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned long long make_key(float score, unsigned idx) {
+    return ((unsigned long long)orderable(score) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+// the score part of a bound as the float the fast reject compares with: !(acc < bound) lets every key >= thr_key through
+// (and NaNs, which rank first as keys); 0 = accept all -> NaN, ~0 = reject all -> +inf
+__device__ __forceinline__ float filter_bound(unsigned long long thr_key) {
+    return thr_key == ~0ull ? __builtin_inff() : unorderable((unsigned)(thr_key >> 32));
+}
+// One 32x32 accumulator tile of scores (register r = query q0 + (r & 3) + 8 (r >> 2) + 4 lh, lane = gallery row n): the
+// common case -- no score reaches its query's bound -- is 16 compares and one branch; survivors are appended one lane at a time.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void topk_filter_tile(const f32x16_t& acc, const float (&bound)[16], int q0, int lh, long n, bool n_ok, int B,
+                                                 const TopkFilter& f) {
+    bool hit = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hit |= !(acc[r] < bound[r]);
+    if (!__any(hit && n_ok)) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (!(acc[r] < bound[r]) && n_ok) {
+            const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (q < B) {
+                const unsigned long long key = make_key(acc[r], (unsigned)n);
+                if (key >= f.thr_key[q] && !(f.exclude && (long)f.exclude[q] - f.exclude_off == n)) {
+                    const int pos = atomicAdd(&f.count[q], 1);
+                    if (pos < f.cap) f.cand[(long)q * f.cap + pos] = key;
+                }
+            }
+        }
+    }
+}
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 // four floats -> four OCP e4m3fn bytes (v_cvt_pk_fp8_f32: round to nearest even; inputs are pre-scaled into [-448, 448])
 __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
@@ -147,15 +218,25 @@ hipError_t launch_u8_to_chw(const unsigned char* src, long src_ld, int x0, int y
 
 // ---- bf16 gallery sweep (sweep_bf16.hip) ---------------------------------------------------------------------------
 hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStream_t s);
-// scores[q, n] = Q[q] . G[n] for q < B <= 64, bf16 gallery [N, D] (D % 64 == 0), fp32 accumulate, scores row stride ld
-hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, hipStream_t s);
+// q < B <= 64 queries against a bf16 gallery [N, D] (D % 64 == 0), fp32 accumulation.
+// Sample form (filt == null): scores[q, c] = Q[q] . G[sample_row(c, R)] for c < S, row stride ld.
+// Filter form (filt != null): nothing is stored, survivors go to filt (gate as GemmParams.gate).
+hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
+                             const TopkFilter* filt, const int* gate, hipStream_t s);
 
 // ---- top-K (topk.hip) ------------------------------------------------------------------------
-// Per row of `scores` [B, ld] (n valid columns): K best (score desc, index asc).  out idx = col + idx_offset.
-// `keys_ws` must hold B * nseg * 64 uint64 (nseg = topk_num_segments(B, n)).
-int topk_num_segments(int B, long n);
-hipError_t launch_topk_rows(const float* scores, long ld, int B, long n, int K, long idx_offset, const int* exclude_idx,
-                            unsigned long long* keys_ws, float* out_scores, int* out_idx, hipStream_t s);
+// Fused sweep, step 2: per query the K-th best key of the sample scores [B, ld] (S valid columns; column c is gallery row
+// sample_row(c, R)) -> thr_key[b] (0 when the sample holds fewer than K rows); also resets count[b] and flags[0..1].  A sample
+// row that is the query's excluded gallery index (exclude[b] - exclude_off, exclude may be null) does not count.
+hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S, int R, int K, const int* exclude, long exclude_off,
+                                    unsigned long long* thr_key, int* count, int* flags, hipStream_t s);
+// Fused sweep, final step: exact top-K of each query's candidate list -> out (idx = row + idx_offset; unfilled: -inf / -1).
+// A query whose list overflowed (count > cap) is not written in the first pass: its bound is raised to the K-th best of the
+// cap stored candidates, its count reset, flags[0] set, and the sweep + this kernel run again with pass = 1 (gated on
+// flags[0]); queries that did not overflow get bound ~0 (reject all) for that pass.  An overflow in pass 1 sets *error_flag
+// (host-mapped) and writes NaN scores / idx -1.
+hipError_t launch_topk_candidates(const TopkFilter& f, unsigned long long* thr_key_rw, int B, int K, long idx_offset, float* out_scores,
+                                  int* out_idx, int* flags, int pass, int* error_flag, hipStream_t s);
 // Merge R lists [R,B,K] (score, idx) -> [B,K]
 hipError_t launch_topk_merge(const float* scores, const int* idx, float* out_scores, int* out_idx, int R, int B, int K,
                              hipStream_t s);

@@ -10,7 +10,9 @@
 //     per CU) stay in flight to cover HBM latency;
 //   * MFMA operands: A = queries (rows on the registers), B = gallery rows (row on the lane), so a 32x32 accumulator
 //     register holds 32 consecutive gallery rows of one query: score stores are 128-byte coalesced.
-// Top-K selection then runs on the fp32 score chunk exactly as in the fp32 path.
+// The [B, N] score matrix is never stored: a small SAMPLE pass (every R-th row, jittered) is stored and yields a per-query
+// lower bound of the K-th best score; the full pass compares each finished 32x32 score tile with the bounds in registers and
+// appends only the survivors (~K*R of N per query) to per-query candidate lists (kernels.h: TopkFilter, topk.hip).
 #include "kernels.h"
 
 namespace fern {
@@ -39,8 +41,13 @@ constexpr int ROWS_T = 32;              // gallery rows per wave tile
 constexpr int KSTAGE = 64;              // k elements per ring stage (128 bytes per row)
 constexpr int STAGE_BYTES = ROWS_T * KSTAGE * 2;   // 4096
 
-template <int STAGES>
-__global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u16* g, float* scores, long ld, int B, long N, int D) {
+// FILTER = false: the sample pass -- tile rows are the gallery rows sample_row(c, R) of S sample columns, scores are stored
+// ([B, ld], 128-byte coalesced).  FILTER = true: the full sweep -- nothing is stored; every finished 32x32 score tile is
+// compared with the per-query bounds held in registers and only survivors are appended to the candidate lists.
+template <int STAGES, bool FILTER>
+__global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u16* g, float* scores, long ld, int B, long N, int D, long S, int R,
+                                                         TopkFilter filt, const int* gate) {
+    if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int q_stride = D * 2 + 16;                               // bytes; +16 spreads rows over the banks
     unsigned char* ring_base = smem + ((64 * q_stride + 1023) & ~1023);
@@ -63,9 +70,22 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
     }
     __syncthreads();
 
+    // per-query bounds of the filter, laid out like the accumulator registers (query = tm*32 + (r&3) + 8(r>>2) + 4 lh)
+    float bound[2][16];
+    if (FILTER) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                bound[tm][r] = qi < B ? filter_bound(filt.thr_key[qi]) : __builtin_inff();
+            }
+    }
+
     unsigned char* ring = ring_base + wave * (STAGES * STAGE_BYTES);
     const int kchunks = D / KSTAGE;                                // stages per tile
-    const long ntiles = (N + ROWS_T - 1) / ROWS_T;
+    const long rows_total = FILTER ? N : S;
+    const long ntiles = (rows_total + ROWS_T - 1) / ROWS_T;
     const long gw = (long)blockIdx.x * 4 + wave, GW = (long)gridDim.x * 4;
     const long my_tiles = gw < ntiles ? (ntiles - gw + GW - 1) / GW : 0;
     const long nstages = my_tiles * kchunks;
@@ -80,6 +100,7 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
         for (int p = 0; p < 4; ++p) {
             const int row = p * 8 + (lane >> 3);
             long n = t * ROWS_T + row;
+            if (!FILTER) n = sample_row(n < S ? n : S - 1, R);
             n = n < N ? n : N - 1;
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
             const u16* src = g + n * D + kc * KSTAGE + chunk * 8;
@@ -115,17 +136,27 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
                 acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[tm], 0, 0, 0);
             }
         }
-        if (kc == kchunks - 1) {                                     // tile finished: 128-byte coalesced score stores
+        if (kc == kchunks - 1) {                                     // tile finished
             const long t = gw + (s / kchunks) * GW;
             const long n = t * ROWS_T + l31;
+            if (FILTER) {
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+                for (int tm = 0; tm < 2; ++tm) {
+                    topk_filter_tile(acc[tm], bound[tm], tm * 32, lh, n, n < N, B, filt);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int qi = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (qi < B && n < N) scores[(long)qi * ld + n] = acc[tm][r];
-                    acc[tm][r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) acc[tm][r] = 0.0f;
                 }
+            } else {                                                 // sample pass: 128-byte coalesced score stores
+                const long grow = sample_row(n < S ? n : S - 1, R);
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int qi = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (qi < B && n < S) scores[(long)qi * ld + n] = grow < N ? acc[tm][r] : -__builtin_inff();
+                        acc[tm][r] = 0.0f;
+                    }
+            }
         }
     }
 }
@@ -137,33 +168,44 @@ hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStre
     return hipGetLastError();
 }
 
-template <int STAGES>
-static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, hipStream_t s) {
+template <int STAGES, bool FILTER>
+static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
+                                    const TopkFilter& filt, const int* gate, hipStream_t s) {
     const size_t lds = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024 + (size_t)4 * STAGES * STAGE_BYTES;
     static size_t attr_set = 0;
-    auto kern = sweep_bf16_kernel<STAGES>;
+    auto kern = sweep_bf16_kernel<STAGES, FILTER>;
     if (lds > attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = lds;
     }
-    const long ntiles = (N + ROWS_T - 1) / ROWS_T;
+    const long ntiles = ((FILTER ? N : S) + ROWS_T - 1) / ROWS_T;
     long blocks = (ntiles + 3) / 4;
     if (blocks > 256) blocks = 256;                                // one persistent workgroup per CU
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, q, g, scores, ld, B, N, D);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, q, g, scores, ld, B, N, D, S, R, filt, gate);
     return hipGetLastError();
 }
 
-hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, hipStream_t s) {
-    if (B <= 0 || N <= 0) return hipSuccess;
-    if (B > 64 || D % 64 || D > 1024) return hipErrorInvalidValue;
+template <bool FILTER>
+static hipError_t launch_sweep_mode(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
+                                    const TopkFilter& filt, const int* gate, hipStream_t s) {
     const size_t qbytes = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024;
     const size_t room = (size_t)160 * 1024 - qbytes;
     const int stages = (int)(room / (4 * STAGE_BYTES));
-    if (stages >= 5) return launch_sweep_inst<5>(q, g, scores, ld, B, N, D, s);
-    if (stages >= 4) return launch_sweep_inst<4>(q, g, scores, ld, B, N, D, s);
-    if (stages >= 3) return launch_sweep_inst<3>(q, g, scores, ld, B, N, D, s);
+    if (stages >= 5) return launch_sweep_inst<5, FILTER>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+    if (stages >= 4) return launch_sweep_inst<4, FILTER>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+    if (stages >= 3) return launch_sweep_inst<3, FILTER>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
+                             const TopkFilter* filt, const int* gate, hipStream_t s) {
+    if (B <= 0 || N <= 0) return hipSuccess;
+    if (B > 64 || D % 64 || D > 1024 || R < 1) return hipErrorInvalidValue;
+    if (filt) return launch_sweep_mode<true>(q, g, nullptr, 0, B, N, D, 0, 1, *filt, gate, s);
+    if (S <= 0) return hipSuccess;
+    if (!scores || (S - 1) * (long)R >= N) return hipErrorInvalidValue;      // every sample run must start inside the gallery
+    return launch_sweep_mode<false>(q, g, scores, ld, B, N, D, S, R, TopkFilter{}, gate, s);
 }
 
 }  // namespace fern

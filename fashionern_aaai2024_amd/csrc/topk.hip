@@ -1,34 +1,23 @@
-// Wavefront-reduced exact top-K (K <= 64) over score rows; replaces the reference's full
-// torch.argsort of the [Q, N] distance matrix (run/test/test_fiq.py:50), of which only ranks
-// < 50 (51 for CIRR) are ever consumed.
+// Wavefront-reduced exact top-K (K <= 64); replaces the reference's full torch.argsort of the [Q, N] distance matrix
+// (run/test/test_fiq.py:50), of which only ranks < 50 (51 for CIRR) are ever consumed.
 //
 // Ordering = score descending, gallery index ascending.  Both are packed into one 64-bit key
 //     key = orderable(score) << 32 | (0xFFFFFFFF - index)
 // so a plain unsigned compare implements the whole rule and ties are deterministic.
 //
-// A wave keeps its current best-64 list SORTED, ONE ENTRY PER LANE.  Scores are streamed 64 at a time
-// (coalesced); a candidate enters only if it beats the list's K-th entry, so after warm-up almost every
-// 64-wide step is a single compare + ballot.  An insertion is O(1) wave operations:
-// position = popcount(ballot(list > cand)), shift the tail down one lane, drop the candidate in.
-// Level 1: grid (segments, B), 4 waves per workgroup each streaming a slice; the 4 lists are merged
-// through LDS by streaming them into wave 0's list.  Level 2: one wave per query merges the segment lists.
+// A wave keeps its current best-64 list SORTED, ONE ENTRY PER LANE.  Candidates are streamed 64 at a time (coalesced); a
+// candidate enters only if it beats the list's K-th entry, so after warm-up almost every 64-wide step is a single compare +
+// ballot.  An insertion is O(1) wave operations: position = popcount(ballot(list > cand)), shift the tail down one lane, drop
+// the candidate in; dense batches and whole lists are merged with a bitonic network instead.
+// The score matrix is never materialised: the sweep (gemm.hip EPI_TOPK_FILTER / sweep_bf16.hip) appends only the scores that
+// reach a per-query bound to candidate lists; the two kernels here compute that bound from a row sample of the gallery
+// (topk_sample_bound_kernel) and select the exact top-K from the lists (topk_candidates_kernel).  kernels.h: TopkFilter.
 #include "kernels.h"
 
 namespace fern {
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ unsigned orderable(float f) {
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float unorderable(unsigned k) {
-    const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-    return __uint_as_float(u);
-}
-__device__ __forceinline__ u64 make_key(float score, unsigned idx) {
-    return ((u64)orderable(score) << 32) | (u64)(0xFFFFFFFFu - idx);
-}
 // Cross-lane moves without the LDS crossbar: a wave-uniform source lane is a v_readlane_b32 (SGPR lane select), the
 // shift-by-one of the sorted list is a DPP wave_shr:1 move.  ds_bpermute-based __shfl made every insertion a chain of
 // ~4 dependent ~120-cycle LDS round trips; these are plain VALU/SALU latencies.
@@ -107,65 +96,6 @@ __device__ __forceinline__ void wave_offer(u64& best, u64 cand, int K, int lane)
     }
 }
 
-__global__ __launch_bounds__(256) void topk_rows_kernel(const float* scores, long ld, long n, int K, const int* exclude_idx,
-                                                        long idx_offset, u64* keys_ws, int nseg, long seg_size) {
-    __shared__ u64 lists[4][64];
-    const int seg = blockIdx.x, b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* row = scores + (long)b * ld;
-    const long seg_lo = (long)seg * seg_size;
-    const long seg_hi = seg_lo + seg_size < n ? seg_lo + seg_size : n;
-    const long per_wave = seg_size / 4;
-    const long lo = seg_lo + wave * per_wave;
-    const long hi = lo + per_wave < seg_hi ? lo + per_wave : seg_hi;
-    const long excl = exclude_idx ? (long)exclude_idx[b] - idx_offset : -1;   // local column to drop
-
-    u64 best = 0;
-    long base = lo;
-    for (; base + 256 <= hi; base += 256) {                  // 4 independent coalesced loads in flight, then 4 offers
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = row[base + u * 64 + lane];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long j = base + u * 64 + lane;
-            wave_offer(best, j != excl ? make_key(v[u], (unsigned)j) : 0, K, lane);
-        }
-    }
-    for (; base < hi; base += 64) {
-        const long j = base + lane;
-        u64 cand = 0;
-        if (j < hi && j != excl) cand = make_key(row[j], (unsigned)j);
-        wave_offer(best, cand, K, lane);
-    }
-    lists[wave][lane] = best;
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll 1
-        for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, lists[w][lane], lane);     // the other waves' lists are sorted
-        keys_ws[((long)b * nseg + seg) * 64 + lane] = best;
-    }
-}
-
-// one wave per query: merge `nlists` sorted 64-entry lists, decode to (score, global index)
-__global__ __launch_bounds__(64) void topk_final_kernel(const u64* keys_ws, int nlists, int K, long idx_offset, float* out_scores,
-                                                        int* out_idx) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    u64 best = keys_ws[(long)b * nlists * 64 + lane];
-#pragma unroll 1
-    for (int l = 1; l < nlists; ++l) best = merge_sorted_desc(best, keys_ws[((long)b * nlists + l) * 64 + lane], lane);
-    if (lane < K) {
-        float s = -INFINITY;
-        int idx = -1;
-        if (best != 0) {
-            s = unorderable((unsigned)(best >> 32));
-            idx = (int)((long)(0xFFFFFFFFu - (unsigned)best) + idx_offset);
-        }
-        out_scores[(long)b * K + lane] = s;
-        out_idx[(long)b * K + lane] = idx;
-    }
-}
-
 // merge R per-shard lists given as (score, global idx) pairs [R,B,K]
 __global__ __launch_bounds__(64) void topk_merge_kernel(const float* scores, const int* idx, float* out_scores, int* out_idx, int R,
                                                         int B, int K) {
@@ -193,27 +123,112 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float* scores, con
     }
 }
 
-// Scores per level-1 workgroup (4 waves): long enough that the number of per-wave lists -- and with it the total number
-// of insertions, ~K (1 + ln(len / K)) per list -- stays small on big galleries, short enough to fill the chip on small ones.
-long topk_segment_size(int B, long n) {
-    long per_wave = ((long)B * n / 4096 + 63) / 64 * 64;
-    per_wave = per_wave < 2048 ? 2048 : (per_wave > 65536 ? 65536 : per_wave);
-    return per_wave * 4;
-}
-int topk_num_segments(int B, long n) {
-    const long seg = topk_segment_size(B, n);
-    const long k = (n + seg - 1) / seg;
-    return (int)(k > 0 ? k : 1);
+// ---- fused sweep + selection (kernels.h: TopkFilter) -----------------------------------------------------------------
+// Step 2: one workgroup per query reads that query's SAMPLE scores (S columns; column c is gallery row sample_row(c, R)),
+// keeps the best 64 keys (4 waves, merged through LDS) and publishes the K-th as the query's bound.  Sample columns are in
+// gallery order, so a key built from the column index ranks ties like one built from the row; the published key carries the
+// real row.  Fewer than K sample rows -> bound 0 (accept all).
+__global__ __launch_bounds__(256) void topk_sample_bound_kernel(const float* scores, long ld, long S, int R, int K, const int* exclude,
+                                                                long exclude_off, u64* thr_key, int* count, int* flags) {
+    __shared__ u64 lists[4][64];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* row = scores + (long)b * ld;
+    // sample column of the excluded gallery row (if it was sampled at all): it must not count towards the K rows of the bound
+    long drop = -1;
+    if (exclude) {
+        const long er = (long)exclude[b] - exclude_off;
+        if (er >= 0 && er / R < S && sample_row(er / R, R) == er) drop = er / R;
+    }
+    u64 best = 0;
+    for (long base = (long)wave * 64; base < S; base += 256) {
+        const long c = base + lane;
+        u64 cand = 0;
+        if (c < S && c != drop) {
+            const float v = row[c];
+            if (v != -INFINITY) cand = make_key(v, (unsigned)c);      // -inf marks padding
+        }
+        wave_offer(best, cand, K, lane);
+    }
+    lists[wave][lane] = best;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll 1
+        for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, lists[w][lane], lane);
+        const u64 kth = shfl64(best, K - 1);
+        if (lane == 0) {
+            u64 out = 0;
+            if (kth != 0) {
+                const long c = (long)(0xFFFFFFFFu - (unsigned)kth);
+                out = (kth & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - (unsigned)sample_row(c, R));
+            }
+            thr_key[b] = out;
+            count[b] = 0;
+            if (b == 0) { flags[0] = 0; flags[1] = 0; }
+        }
+    }
 }
 
-hipError_t launch_topk_rows(const float* scores, long ld, int B, long n, int K, long idx_offset, const int* exclude_idx, u64* keys_ws,
-                            float* out_scores, int* out_idx, hipStream_t s) {
+// Final step: one workgroup per query streams its candidate keys (arrival order, 64-bit) through the same wave lists.
+__global__ __launch_bounds__(256) void topk_candidates_kernel(TopkFilter f, u64* thr_key_rw, int K, long idx_offset, float* out_scores,
+                                                              int* out_idx, int* flags, int pass, int* error_flag) {
+    __shared__ u64 lists[4][64];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (pass == 1) {
+        if (flags[0] == 0) return;                       // no query overflowed in pass 0: nothing to redo
+        if (thr_key_rw[b] == ~0ull) return;              // this query was final after pass 0
+    }
+    const int total = f.count[b];
+    const int n = total < f.cap ? total : f.cap;
+    const u64* cand = f.cand + (long)b * f.cap;
+    u64 best = 0;
+    for (int base = wave * 64; base < n; base += 256) {
+        const int c = base + lane;
+        wave_offer(best, c < n ? cand[c] : 0, K, lane);
+    }
+    lists[wave][lane] = best;
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll 1
+    for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, lists[w][lane], lane);
+    if (total > f.cap) {
+        // More rows reached the bound than the list holds (a sample that missed a cluster of good rows).  The K-th best of
+        // what WAS stored is still a valid -- and much tighter -- bound (K distinct rows reach it): sweep once more with it.
+        if (pass == 0) {
+            const u64 kth = shfl64(best, K - 1);
+            if (lane == 0) { thr_key_rw[b] = kth; f.count[b] = 0; flags[0] = 1; }
+            return;
+        }
+        if (lane == 0 && error_flag) __hip_atomic_store(error_flag, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane < K) { out_scores[(long)b * K + lane] = __builtin_nanf(""); out_idx[(long)b * K + lane] = -1; }
+        return;
+    }
+    if (pass == 0 && lane == 0) thr_key_rw[b] = ~0ull;   // final: a retry sweep (if another query needs one) must skip this query
+    if (lane < K) {
+        float sc = -INFINITY;
+        int idx = -1;
+        if (best != 0) {
+            sc = unorderable((unsigned)(best >> 32));
+            idx = (int)((long)(0xFFFFFFFFu - (unsigned)best) + idx_offset);
+        }
+        out_scores[(long)b * K + lane] = sc;
+        out_idx[(long)b * K + lane] = idx;
+    }
+}
+
+hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S, int R, int K, const int* exclude, long exclude_off,
+                                    u64* thr_key, int* count, int* flags, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (K < 1 || K > 64 || n < 0 || n > 0x7FFFFFF0L) return hipErrorInvalidValue;
-    const int nseg = topk_num_segments(B, n);
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(nseg, B), dim3(256), 0, s, scores, ld, n, K, exclude_idx, idx_offset, keys_ws, nseg,
-                       topk_segment_size(B, n));
-    hipLaunchKernelGGL(topk_final_kernel, dim3(B), dim3(64), 0, s, keys_ws, nseg, K, idx_offset, out_scores, out_idx);
+    if (K < 1 || K > 64 || S < 0 || R < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_sample_bound_kernel, dim3(B), dim3(256), 0, s, scores, ld, S, R, K, exclude, exclude_off, thr_key, count, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_topk_candidates(const TopkFilter& f, u64* thr_key_rw, int B, int K, long idx_offset, float* out_scores, int* out_idx,
+                                  int* flags, int pass, int* error_flag, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (K < 1 || K > 64 || f.cap < 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_candidates_kernel, dim3(B), dim3(256), 0, s, f, thr_key_rw, K, idx_offset, out_scores, out_idx, flags, pass,
+                       error_flag);
     return hipGetLastError();
 }
 

@@ -403,5 +403,12 @@ class FernEngine:
         _lib.check(self.lib.fern_prof_collect(self._h, C.byref(st)), "fern_prof_collect")
         return {f: getattr(st, f) for f, _ in st._fields_}
 
+    def tuner_export(self) -> str:
+        """The GEMM tuner's per-shape tile choices so far (text; a file of it named by FERN_GEMM_TILES pins them)."""
+        n = self.lib.fern_tuner_export(None, 0)
+        buf = C.create_string_buffer(int(n) + 1)
+        self.lib.fern_tuner_export(buf, int(n) + 1)
+        return buf.value.decode()
+
     def sync(self) -> None:
         _lib.check(self.lib.fern_sync(self._h, _stream()), "fern_sync")

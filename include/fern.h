@@ -281,6 +281,12 @@ FERN_API int fern_attention_bf16(fern_ctx* ctx, const uint16_t* q, int64_t ldq, 
                         int64_t ldv, uint16_t* out, int64_t ldo, int batch, int heads, int head_dim, int s_q, int s_k,
                         int causal, float scale, void* stream);
 
+/* The GEMM launchers time their tile candidates once per new shape (all candidates are bit-identical).  This
+ * returns the choices made so far in this process as text, one line per shape ("f32|bf16|fp8 M N K epilogue loader cfg");
+ * the return value is the full length.  Setting FERN_GEMM_TILES=<file of such lines> before the first launch pins those
+ * shapes (no timing runs, same kernels on every box).  No reference counterpart (cuBLAS picks its own kernels). */
+FERN_API int64_t fern_tuner_export(char* buf, int64_t cap);
+
 /* profiling ----------------------------------------------------------------------------- */
 FERN_API int fern_prof_enable(fern_ctx* ctx, int on);    /* wrap GEMM/attention/top-K launches in HIP events */
 FERN_API int fern_prof_collect(fern_ctx* ctx, fern_prof_stats* out);  /* synchronises, sums, resets */

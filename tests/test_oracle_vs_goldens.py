@@ -142,3 +142,45 @@ def test_loss_and_train_mode_against_the_reference():
     assert (fusion - torch.from_numpy(z["train_fusion"])).abs().max() < 2e-5
     assert (target - torch.from_numpy(z["train_target"])).abs().max() < 2e-5
     assert abs(ofusion.batch_classification_loss(fusion, target).item() - float(z["train_loss"])) < 1e-3
+
+
+def _round_to_f32(x):
+    """Correctly rounded (nearest, ties to even) float32 of an exact Fraction -- no intermediate double rounding."""
+    from fractions import Fraction
+    if x == 0:
+        return np.float32(0.0)
+    sign, x = (-1, -x) if x < 0 else (1, x)
+    e = 0
+    while x >= Fraction(1 << 24):
+        x, e = x / 2, e + 1
+    while x < Fraction(1 << 23):
+        x, e = x * 2, e - 1
+    m, rem = divmod(x.numerator, x.denominator)
+    twice = 2 * rem
+    if twice > x.denominator or (twice == x.denominator and m % 2 == 1):
+        m += 1
+    return np.float32(sign * float(m) * 2.0 ** e)
+
+
+def test_chain_oracle_is_an_exact_fma_chain_in_the_kernels_k_order():
+    """oracle/chain.c against exact rational arithmetic: acc <- round_f32(a*b + acc) with the products taken in the order
+    8g, 8g+4, 8g+1, 8g+5, ... (gemm.hip).  Pins the C restatement itself (libm's fmaf, compiler flags) before the GPU
+    tests trust it bit for bit."""
+    from fractions import Fraction
+    from oracle import chain
+    r = np.random.default_rng(5)
+    q = r.standard_normal((3, 40)).astype(np.float32)
+    g = (r.standard_normal((7, 40)) * 1e-3).astype(np.float32)
+    g[2] *= 1e6                                        # mixed magnitudes: cancellation and sticky bits both occur
+    got = chain.chain_scores(q, g)
+    order = [8 * grp + off for grp in range(5) for off in (0, 4, 1, 5, 2, 6, 3, 7)]
+    for b in range(3):
+        for n in range(7):
+            acc = np.float32(0.0)
+            for k in order:
+                acc = _round_to_f32(Fraction(float(q[b, k])) * Fraction(float(g[n, k])) + Fraction(float(acc)))
+            assert acc.view(np.uint32) == got[b, n].view(np.uint32), (b, n, acc, got[b, n])
+    s, i = chain.chain_topk(q, np.repeat(g, 2, axis=0), 5)          # duplicated rows: ties resolve to the lower index
+    for b in range(3):
+        for a, c in zip(i[b][:-1], i[b][1:]):
+            assert s[b][list(i[b]).index(a)] > s[b][list(i[b]).index(c)] or a < c
