@@ -1,23 +1,35 @@
 #!/usr/bin/env python
 """Headline benchmark: composed queries/sec of the encode -> fuse -> rank path (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): FashionIQ ViT-B/16, one batch of 64 composed queries per GPU against a
-46k-image fused gallery, fp32, synthetic data, random-init weights of the real architecture.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
 
-One STEP on one GPU = one batch of 64 composed queries, inputs already resident in HBM:
-    encode_image(64 x 3x224x224)  ->  encode_text(64 x 77 tokens, one tower pass)
+One STEP on one GPU = one batch of composed queries, inputs already resident in HBM:
+    encode_image(B x 3xSxS) -> encode_text(B x 77 tokens, one tower pass)
     -> ERN mode="test" fusion (2-layer BERT over 91 tokens, cross-attention, SR pooling, 3 Combiners)
-    -> cosine top-50 against the replicated fused gallery [46000, 512].
-The gallery is built before the timed region (every rank fuses its shard with mode="index", one RCCL all_gather).
-N GPUs = N ranks (torchrun), query-data-parallel, weak scaling: value = N * 64 * K / (max-over-ranks time).
+    -> cosine top-K against the fused gallery (fused sweep + selection: the [B, N] score matrix is never stored).
+Workloads (BASELINE.json configs; synthetic data, random-init weights of the real architecture):
+    c2  (default, the headline)  FashionIQ ViT-B/16, fp32, 64 queries per GPU vs a 46k-row gallery            configs[1]
+    c3  Fashion200k RN50x4 (D = 640, 288 px), fp32, 64 queries per GPU vs a 200k-row gallery                  configs[2]
+    c4  CIRR ViT-B/16, fp32, 128 queries per GPU (1024 on 8), K = 51 with the reference removed + subset      configs[3]
+    c5  FashionIQ ViT-B/16, fp8 encoder GEMMs + bf16 similarity, 64 queries per GPU vs a 1M-row bf16 gallery  configs[4]
 
-After the timed region the same step is run with libfern's HIP-event instrumentation (events on the launch stream
-around every fp32-MFMA GEMM / attention / sweep / top-K launch) to fill `roofline`; on rank 0 at N=1 the CPU oracle
-is timed on a bounded sample for `cpu_baseline`.
+N GPUs = N ranks, one process per GPU (torch.distributed, backend nccl = RCCL over xGMI).  `python bench.py --gpus N` launches
+them itself -- N fresh children through torch.distributed.run, BEFORE this process touches the GPU -- and also runs as a
+rank when started under torchrun (RANK / WORLD_SIZE present).  The gallery is built sharded: every rank synthesises and
+fuses ONLY its own rows (seed + rank), then one all_gather replicates the fused rows; queries are data parallel (weak scaling:
+value = N x B x K / max-over-ranks time), with no data-path collective.  c5 also reports the gallery-sharded variant
+(all-gather queries, local top-K with idx_offset, all-gather candidates, merge).
+
+After the timed region the same step runs with libfern's HIP-event instrumentation (events on the launch stream around
+every GEMM / attention / sweep launch) to fill `roofline`; on rank 0 at N = 1 the CPU oracle is timed on bounded samples
+for `cpu_baseline` and used as the checker of the GPU result.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -25,55 +37,58 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (the non-scaled fp8 32x32x16 MFMA issues at this rate too)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+XGMI_PEAK_GBS = 7 * 153.0         # 7 point-to-point links x ~153 GB/s per GPU
 
-from fashionern_aaai2024_amd import distributed as fd  # noqa: E402
-from fashionern_aaai2024_amd import synth  # noqa: E402
-from fashionern_aaai2024_amd.clip_model import create_model  # noqa: E402
-from fashionern_aaai2024_amd.model import ERN  # noqa: E402
-from fashionern_aaai2024_amd.pipeline import ComposedQueryPipeline  # noqa: E402
+WORKLOADS = {
+    "c2": dict(clip="ViT-B-16", d=512, batch=64, gallery=46_000, k=50, precision="fp32", cirr=False, bf16_gallery=False,
+               text="FashionIQ ViT-B/16 composed queries: 64-query batch per GPU vs 46k-image fused gallery (BASELINE.json configs[1])"),
+    "c3": dict(clip="RN50x4", d=640, batch=64, gallery=200_000, k=50, precision="fp32", cirr=False, bf16_gallery=False,
+               text="Fashion200k RN50x4 (D=640, 288 px) composed queries: 64-query batch per GPU vs ~200k-image gallery built sharded "
+                    "+ RCCL all-gather (BASELINE.json configs[2])"),
+    "c4": dict(clip="ViT-B-16", d=512, batch=128, gallery=21_552, k=51, precision="fp32", cirr=True, bf16_gallery=False,
+               text="CIRR ViT-B/16 composed queries: 128-query batch per GPU (1024 on 8 GPUs), global top-51 with the reference removed "
+                    "+ subset scores of 6 members (BASELINE.json configs[3])"),
+    "c5": dict(clip="ViT-B-16", d=512, batch=64, gallery=1_000_000, k=50, precision="fp8", cirr=False, bf16_gallery=True,
+               text="FashionIQ ViT-B/16 fp8 MFMA encoder GEMMs + bf16 similarity: 64-query batch per GPU vs 1M-row bf16 gallery "
+                    "(BASELINE.json configs[4])"),
+}
 
-F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
-QUERY_BATCH, GALLERY, TOPK, D = 64, 46000, 50, 512
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=16)
+    ap.add_argument("--gallery", type=int, default=None, help="override the workload's gallery rows")
+    ap.add_argument("--lanes", type=int, default=3, help="query batches kept in flight on separate HIP streams")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "fp8"], default=None,
+                    help="override the encoder operand precision of the TIMED path (fp32 = parity mode, the c2 headline)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the secondary legs (reduced-precision modes, lookup variant, 1M-row bf16 sweep, encode rate): the GEMM "
+                         "dispatches of the run are then the headline step's, for comparing rocprofv3 averages with `roofline`")
+    ap.add_argument("--pmc-mode", action="store_true",
+                    help="for `rocprofv3 --pmc`: warm up, emit a marker dispatch, run exactly --steps steps on one stream, exit (no JSON)")
+    ap.add_argument("--save-tiles", type=str, default=None, help="write the GEMM tuner's choices to this file (FERN_GEMM_TILES format)")
+    return ap.parse_args()
 
 
-def cpu_baseline(clip_sd, fusion_sd, cfg, images, tokens, loc, gallery, sample, gpu_topk, repeats=2):
-    """The CPU oracle (kind "port": this repo's restatement, pinned against the imported reference by tests/golden)
-    on `sample` composed queries: encode image + text, fuse, rank against the same fused gallery."""
-    from oracle import clip as oclip, fusion as ofusion, rank as orank
-    # threads actually used: the host cores this process may run on, capped at 32 (torch's intra-op pool stops
-    # scaling on these small per-query matrices well before that; an uncapped 256-thread pool is ~100x slower)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 32))
-    torch.set_num_threads(threads)
-    csd, fsd = ofusion.as_torch(clip_sd), ofusion.as_torch(fusion_sd)
-    im, tk, lc, gal = images[:sample].cpu(), tokens[:sample].cpu(), loc[:sample].cpu(), gallery.cpu()
-
-    def one():
-        with torch.no_grad():
-            rf = oclip.encode_image(csd, cfg, im)
-            tg, ts = oclip.encode_text(csd, cfg, tk)
-            q = ofusion.dvr_fuse(fsd, lc, ts, rf, tg)
-            return orank.cosine_topk(q, gal, TOPK)
-
-    warm = _timed(one)
-    best = min([warm] + [_timed(one) for _ in range(repeats)]) if warm < 20 else warm      # keep the run bounded
-    # the oracle is the checker as well: same queries, same gallery -> compare the HIP path's top-K with the CPU result
-    o_s, o_i = one()
-    g_s, g_i = gpu_topk[0][:sample].cpu(), gpu_topk[1][:sample].cpu()
-    same_rows = int((g_i == o_i).all(dim=1).sum().item())
-    return {"value": sample / best, "unit": "composed queries/sec", "cores": threads, "kind": "port",
-            "sample": f"{sample} composed queries (ViT-B/16 image + text encode, fusion, top-{TOPK} of {gallery.shape[0]} rows), "
-                      f"torch CPU fp32, best of {repeats}",
-            "parity_vs_hip": {"queries": sample, "rows_with_identical_top%d_order" % TOPK: same_rows,
-                              "positions_equal_frac": float((g_i == o_i).float().mean().item()),
-                              "max_abs_cosine_diff": float((g_s - o_s).abs().max().item())}}
+def spawn_ranks(args) -> None:
+    """`python bench.py --gpus N` outside torchrun: start N rank processes and mirror rank 0's JSON line.  Nothing in THIS process
+    has touched the GPU (torch is not even imported yet), so starting children is safe; the children are fresh interpreters."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required for RCCL across processes on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def _timed(fn):
@@ -82,33 +97,121 @@ def _timed(fn):
     return time.perf_counter() - t0
 
 
+def _cpu_threads():
+    # threads actually used: the host cores this process may run on, capped at 32 (torch's intra-op pool stops scaling on these
+    # small per-query matrices well before that; an uncapped 256-thread pool is ~100x slower)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, 32))
+
+
+def order_parity(o_scores_full, g_idx, o_idx):
+    """How the GPU ranking relates to the oracle's: identical rows / positions, and -- at every position where they differ -- the
+    gap between the ORACLE's own scores of the two rows (a near-tie of the oracle if tiny)."""
+    import torch
+    same_rows = int((g_idx == o_idx).all(dim=1).sum().item())
+    gap = 0.0
+    for r, p in (g_idx != o_idx).nonzero().tolist():
+        gap = max(gap, abs(o_scores_full[r, g_idx[r, p]].item() - o_scores_full[r, o_idx[r, p]].item()))
+    return {"rows_with_identical_order": same_rows, "positions_equal_frac": float((g_idx == o_idx).float().mean().item()),
+            "max_oracle_score_gap_at_mismatching_positions": gap}
+
+
+def cpu_baseline(clip_sd, fusion_sd, cfg, w, images, tokens, loc, gallery, sample, gpu_topk, repeats=3):
+    """The CPU oracle (kind "port": this repo's restatement, pinned against the imported reference by tests/golden) timed on the
+    host cores, on bounded samples of the same workload; it is also the checker of the HIP result (parity_vs_hip).
+      * end to end: `sample` composed queries -- encode image + text, fuse, rank against the same fused gallery;
+      * C2 fuse + rank at full size (B = 64, N = gallery rows), C1 plumbing sizes (D = 640, N = 1000, B = 32): BASELINE.md 3."""
+    import torch
+    from fashionern_aaai2024_amd import synth
+    from oracle import clip as oclip, fusion as ofusion, rank as orank
+    threads = _cpu_threads()
+    torch.set_num_threads(threads)
+    k, d = w["k"], w["d"]
+    csd, fsd = ofusion.as_torch(clip_sd), ofusion.as_torch(fusion_sd)
+    im, tk, lc, gal = images[:sample].cpu(), tokens[:sample].cpu(), loc[:sample].cpu(), gallery.float().cpu()
+
+    def one():
+        with torch.no_grad():
+            rf = oclip.encode_image(csd, cfg, im)
+            tg, ts = oclip.encode_text(csd, cfg, tk)
+            q = ofusion.dvr_fuse(fsd, lc, ts, rf, tg)
+            return q, orank.cosine_topk(q, gal, k)
+
+    warm = _timed(one)
+    best = min([warm] + [_timed(one) for _ in range(repeats)]) if warm < 20 else warm      # keep the run bounded
+    oq, (o_s, o_i) = one()
+    g_s, g_i = gpu_topk[0][:sample].cpu(), gpu_topk[1][:sample].cpu()
+    parity = order_parity(oq @ gal.T, g_i.long(), o_i.long())
+    parity.update({"queries": sample, "max_abs_cosine_diff": float((g_s - o_s).abs().max().item())})
+
+    def stage_rates(dd, n, b, tag):
+        """fuse + rank plumbing on CPU at (D, N, B): mode="index" over the gallery, mode="test" on B queries, cosine top-K."""
+        sd = fsd if dd == d else ofusion.as_torch(synth.fusion_state_dict(dd, seed=0))
+        raw, lcl = torch.from_numpy(synth.global_feats(n, dd, 7, tag)), torch.from_numpy(synth.local_feats(n, dd, 7, tag + "-l"))
+        rg, rl = torch.from_numpy(synth.global_feats(b, dd, 8, tag + "q")), torch.from_numpy(synth.local_feats(b, dd, 8, tag + "ql"))
+        tg, ts = torch.from_numpy(synth.global_feats(b, dd, 9, tag + "t")), torch.from_numpy(synth._normal(9, tag + "ts", (b, 77, dd)))
+        with torch.no_grad():
+            t_index = _timed(lambda: ofusion.index_fuse(sd, torch.nn.functional.normalize(raw, dim=-1), lcl))
+            fused = ofusion.index_fuse(sd, torch.nn.functional.normalize(raw, dim=-1), lcl)
+            ofusion.dvr_fuse(sd, rl, ts, rg, tg)
+            t_test = min(_timed(lambda: ofusion.dvr_fuse(sd, rl, ts, rg, tg)) for _ in range(2))
+            qq = ofusion.dvr_fuse(sd, rl, ts, rg, tg)
+            t_rank = min(_timed(lambda: orank.cosine_topk(qq, fused, k)) for _ in range(2))
+        return {"feature_dim": dd, "gallery_rows": n, "query_batch": b, "index_fuse_rows_per_s": n / t_index, "dvr_fuse_queries_per_s": b / t_test,
+                "rank_ms": t_rank * 1e3, "fuse_plus_rank_queries_per_s": b / (t_test + t_rank)}
+
+    return {"value": sample / best, "unit": "composed queries/sec", "cores": threads, "kind": "port",
+            "sample": f"{sample} composed queries ({cfg.name} image + text encode, fusion, top-{k} of {gal.shape[0]} rows), "
+                      f"torch CPU fp32, best of {repeats + 1}",
+            "parity_vs_hip": parity,
+            "c2_fuse_rank_full_size": stage_rates(d, min(gal.shape[0], 46_000), 64, "cpu-c2") if d == 512 else None,
+            "c1_plumbing": stage_rates(640, 1000, 32, "cpu-c1")}
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8)
-    ap.add_argument("--gallery", type=int, default=GALLERY)
-    ap.add_argument("--lanes", type=int, default=3, help="64-query batches kept in flight on separate HIP streams")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "fp8"], default="fp32",
-                    help="encoder operand precision of the TIMED path: fp32 = parity mode (the headline), bf16 = perf mode")
-    ap.add_argument("--headline-only", action="store_true",
-                    help="skip the secondary legs (reduced-precision modes, lookup variant, 1M-row bf16 sweep, encode rate): the GEMM "
-                         "dispatches of the run are then the headline step's, for comparing rocprofv3 averages with `roofline`")
-    ap.add_argument("--pmc-mode", action="store_true",
-                    help="for `rocprofv3 --pmc`: warm up, emit a marker dispatch, run exactly --steps steps, exit (no JSON)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args)
+
+    import torch
+    import torch.distributed as dist
+    from fashionern_aaai2024_amd import distributed as fd
+    from fashionern_aaai2024_amd import synth
+    from fashionern_aaai2024_amd.clip_model import create_model
+    from fashionern_aaai2024_amd.model import ERN
+    from fashionern_aaai2024_amd.pipeline import ComposedQueryPipeline
 
     rank, world, local = fd.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("FERN_BENCH_SHARE_GPU"):      # debug only: several ranks on one GPU (with FERN_DIST_BACKEND=gloo)
         local = local % torch.cuda.device_count()
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    cfg = synth.CLIP_CONFIGS["ViT-B-16"]
-    n_gal = args.gallery
+    w = dict(WORKLOADS[args.config])
+    if args.gallery:
+        w["gallery"] = args.gallery
+    precision = args.precision or w["precision"]
+    cfg = synth.CLIP_CONFIGS[w["clip"]]
+    D, B, K, n_gal = w["d"], w["batch"], w["k"], w["gallery"]
+    backend = dist.get_backend() if world > 1 else None
+    gloo = backend == "gloo"
+
+    def dev_randn(shape, seed):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        return torch.randn(shape, generator=g, device=device)
+
+    def collective(fn, *tensors):
+        """torch.distributed collective on device tensors; the gloo debug backend (ranks sharing one GPU) goes through the host."""
+        if not gloo:
+            return fn(*tensors)
+        host = [t.cpu() for t in tensors]
+        fn(*host)
+        tensors[0].copy_(host[0])
 
     # ---- weights (random init, real architecture) and synthetic inputs, resident in HBM --------------------
     clip_sd = synth.clip_state_dict(cfg, seed=0)
@@ -117,33 +220,37 @@ def main():
     clip.load_state_dict(clip_sd)
     model = ERN(clip, D, device, engine=clip.engine).load_state_dict(fusion_sd)
     eng = model.engine
-    seed = 42 + rank
-    images = torch.from_numpy(synth.images(QUERY_BATCH, cfg, seed)).to(device)
-    tokens = torch.from_numpy(synth.captions(QUERY_BATCH, cfg, seed)).to(device)
-    loc = torch.from_numpy(synth.local_feats(QUERY_BATCH, D, seed)).to(device)
-    g_raw = torch.from_numpy(synth.global_feats(n_gal, D, 7, "gallery")).to(device)
-    g_loc = torch.from_numpy(synth.local_feats(n_gal, D, 7, "gallery-local")).to(device)
+    n_batches = 3      # distinct input batches, rotated step by step
+    batches = []
+    for j in range(n_batches):
+        seed = 42 + rank + 1000 * j
+        batches.append((torch.from_numpy(synth.images(B, cfg, seed)).to(device), torch.from_numpy(synth.captions(B, cfg, seed)).to(device),
+                        torch.from_numpy(synth.local_feats(B, D, seed)).to(device)))
 
-    # ---- gallery build (not in the step): shard -> mode="index" fuse -> RCCL all_gather ----------------------
-    gallery = fd.build_gallery(eng, g_raw, g_loc)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    gallery = fd.build_gallery(eng, g_raw, g_loc)
-    torch.cuda.synchronize()
-    gallery_build_s = time.perf_counter() - t0
-    del g_loc
+    # ---- gallery build (not in the step): every rank synthesises + fuses ONLY its shard, one RCCL all_gather --------------
+    start, stop, per = fd.shard_rows(n_gal, rank, world)
+    gal_dtype = torch.bfloat16 if w["bf16_gallery"] else torch.float32
 
-    pipe = ComposedQueryPipeline(eng, lanes=args.lanes)
-    pipe.set_precision(args.precision)
+    def build_shard():
+        block = torch.zeros((per, D), dtype=gal_dtype, device=device)
+        ch = 32_768
+        for o in range(start, stop, ch):
+            m = min(ch, stop - o)
+            raw = dev_randn((m, D), (7 + rank) * 1_000_003 + o)
+            lcl = dev_randn((m, 13, D), (11 + rank) * 1_000_003 + o)
+            fused = eng.index_fuse(raw, lcl, normalize_input=True)
+            block[o - start:o - start + m] = eng.gallery_to_bf16(fused) if w["bf16_gallery"] else fused
+        return block
 
-    def step():          # one batch of 64 composed queries; consecutive steps go to consecutive lanes (streams)
-        return pipe.submit(images, tokens, loc, gallery, TOPK)
-
-    def step_serial():   # the same work on the current stream (instrumented / PMC passes)
-        rf = eng.encode_image(images)
-        tg, ts = eng.encode_text(tokens)
-        q = eng.dvr_fuse(rf, loc, tg, ts)
-        return eng.sim_topk(q, gallery, TOPK)
+    def gather(block):
+        if world == 1:
+            return block[:n_gal]
+        if gloo:
+            full = torch.empty((world * per, D), dtype=block.dtype)
+            dist.all_gather_into_tensor(full.view(torch.int16) if block.dtype == torch.bfloat16 else full,
+                                        block.cpu().view(torch.int16) if block.dtype == torch.bfloat16 else block.cpu())
+            return full.to(device)[:n_gal]
+        return fd.all_gather_shards(block, n_gal)
 
     def barrier():
         torch.cuda.synchronize()
@@ -151,104 +258,211 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, args.lanes)):      # every lane's workspace must exist before the timed region
-        step()
+    shard = build_shard()
+    gallery = gather(shard)                    # warm (RCCL connection setup, workspaces)
     barrier()
-    if args.pmc_mode:      # tools/pmc_traffic.py keys on this single-workgroup l2norm dispatch to find the measured steps
-        eng.l2_normalize(torch.zeros(3, 64, device=device))
-        for _ in range(args.steps):
-            step_serial()
-        barrier()
-        return
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    shard = build_shard()
+    torch.cuda.synchronize()
+    fuse_s = time.perf_counter() - t0
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    value = world * QUERY_BATCH * args.steps / elapsed
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    gallery = gather(shard)
+    ev1.record()
+    torch.cuda.synchronize()
+    ag_ms = ev0.elapsed_time(ev1)
+    ag_bytes = (world - 1) * per * D * shard.element_size()      # bytes this rank receives
+    shard_start = start
 
-    # ---- encoder perf mode (bf16 operands, fp32 accumulation) on the same workload: reported beside the fp32 headline,
-    # never as `value` (north_star's parity bar -- scores within 1e-3, identical ordering -- is an fp32 statement)
-    def reduced_precision_leg(prec, ref_scores, ref_idx):
-        pipe.set_precision(prec)
-        for _ in range(max(args.warmup, args.lanes)):
-            step()
+    # CIRR extras (c4): one excluded gallery index (the reference image) and 6 img_set members per query
+    ex_idx = members = None
+    if w["cirr"]:
+        g = torch.Generator().manual_seed(4 + rank)
+        ex_idx = torch.randint(0, n_gal, (B,), generator=g, dtype=torch.int32).to(device)
+        members = torch.randint(0, n_gal, (B, 6), generator=g, dtype=torch.int32).to(device)
+        members[:, 0] = ex_idx
+
+    pipe = ComposedQueryPipeline(eng, lanes=args.lanes, timing=True)
+    pipe.set_precision(precision)
+    step_no = [0]
+
+    def step():          # one batch of composed queries; consecutive steps go to consecutive lanes (streams) and rotate the input batch
+        im, tk, lc = batches[step_no[0] % n_batches]
+        step_no[0] += 1
+        return pipe.submit(im, tk, lc, gallery, K, exclude_idx=ex_idx, members=members)
+
+    def step_serial(j=0):   # the same work on the current stream (instrumented / PMC passes)
+        im, tk, lc = batches[j % n_batches]
+        rf = eng.encode_image(im)
+        tg, ts = eng.encode_text(tk)
+        q = eng.dvr_fuse(rf, lc, tg, ts)
+        out = eng.sim_topk_bf16(q, gallery, K, exclude_idx=ex_idx) if w["bf16_gallery"] else eng.sim_topk(q, gallery, K, exclude_idx=ex_idx)
+        if members is not None:
+            eng.gather_scores(q, gallery, members)
+        return out
+
+    def timed_loop(fn, steps):
+        """`steps` calls of fn bracketed by barrier + synchronize; max over ranks.  Also the median gap between consecutive
+        batches' completion events (hipEvents on the lanes' streams): a per-step figure that one slow step does not move."""
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out_b = step()
+        outs = [fn() for _ in range(steps)]
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            collective(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX), t)
             el = t.item()
-        b_scores, b_idx = out_b.wait()
+        # consecutive batches of ONE lane complete in order on that lane's stream: the gap between batch i and batch i + lanes,
+        # divided by the lanes that interleave with them, is a per-step service time
+        gaps = []
+        evs = [o.done_event for o in outs if hasattr(o, "done_event")]
+        nl = args.lanes
+        for a, b in zip(evs[:-nl], evs[nl:]):
+            gaps.append(a.elapsed_time(b) / nl)
+        return el, outs[-1], (statistics.median(gaps) if gaps else None)
+
+    for _ in range(max(args.warmup, args.lanes, n_batches)):      # every lane's workspace / every tuned shape exists before the timed region
+        step()
+    barrier()
+    if args.pmc_mode:      # tools/pmc_traffic.py keys on this single-workgroup l2norm dispatch to find the measured steps
+        pipe.set_precision(precision)
+        for j in range(n_batches):
+            step_serial(j)
+        torch.cuda.synchronize()
+        eng.l2_normalize(torch.zeros(3, 64, device=device))
+        for j in range(args.steps):
+            step_serial(j)
+        barrier()
+        return
+    elapsed, last, gap_median = timed_loop(step, args.steps)
+    value = world * B * args.steps / elapsed
+
+    # ---- c5 only: gallery-SHARDED ranking (SURVEY 8e alternative): all-gather the fused queries, sweep the local shard for all of
+    # them, all-gather the candidates, merge -- every rank reads N/W gallery rows per batch instead of N
+    sharded_info = None
+    if args.config == "c5":
+        my = shard[: stop - start]
+
+        def step_sharded():
+            im, tk, lc = batches[step_no[0] % n_batches]
+            step_no[0] += 1
+            rf = eng.encode_image(im)
+            tg, ts = eng.encode_text(tk)
+            q = eng.dvr_fuse(rf, lc, tg, ts)
+            if world == 1:
+                return eng.sim_topk_bf16(q, my, K, idx_offset=shard_start)
+            allq = torch.empty((world * B, D), dtype=torch.float32, device=device)
+            collective(lambda o, i: dist.all_gather_into_tensor(o, i), allq, q)
+            s, i = eng.sim_topk_bf16(allq, my, K, idx_offset=shard_start)
+            all_s = torch.empty((world, world * B, K), dtype=torch.float32, device=device)
+            all_i = torch.empty((world, world * B, K), dtype=torch.int32, device=device)
+            collective(lambda o, x: dist.all_gather_into_tensor(o.view(-1, K), x), all_s, s)
+            collective(lambda o, x: dist.all_gather_into_tensor(o.view(-1, K), x), all_i, i)
+            return eng.topk_merge(all_s[:, rank * B:(rank + 1) * B].contiguous(), all_i[:, rank * B:(rank + 1) * B].contiguous())
+
+        for _ in range(3):
+            step_sharded()
+        el, out_sh, _ = timed_loop(step_sharded, args.steps)
+        step_no[0] -= 1
+        ref_s, ref_i = step_serial(step_no[0])          # the replicated path on the same input batch
+        torch.cuda.synchronize()
+        sharded_info = {"value": world * B * args.steps / el, "unit": "queries/sec", "ms_per_step": el / args.steps * 1e3,
+                        "gallery_rows_per_gpu": stop - start, "collectives_per_step": 0 if world == 1 else 3,
+                        "identical_to_replicated": bool(torch.equal(out_sh[1], ref_i) and torch.equal(out_sh[0], ref_s)),
+                        "note": "one stream (collectives between the stages); the replicated variant keeps batches in flight on 3 streams"}
+
+    # ---- reduced-precision encoder modes on the c2 workload: reported beside the fp32 headline, never as its `value`
+    # (north_star's parity bar -- scores within 1e-3, identical ordering -- is an fp32 statement)
+    def reduced_precision_leg(prec, ref_scores, ref_idx):
+        pipe.set_precision(prec)
+        for _ in range(max(args.warmup, args.lanes, n_batches)):
+            step()
+        step_no[0] = 0
+        el, out_b, _ = timed_loop(step, args.steps)
+        step_no[0] = 0
+        b_scores, b_idx = step().wait()
         eng.prof_enable(True)
-        for _ in range(2):
-            step_serial()
+        for j in range(2):
+            step_serial(j)
         sp = eng.prof_collect()
         eng.prof_enable(False)
         key = "gemm_fp8" if prec == "fp8" else "gemm_bf16"
-        peak = BF16_MFMA_PEAK_TFLOPS      # the non-scaled fp8 MFMA (32x32x16) issues at the bf16 rate
         tfl = sp[key + "_flops"] / (sp[key + "_ms"] * 1e-3) / 1e12 if sp[key + "_ms"] > 0 else 0.0
         overlap = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(ref_idx.cpu(), b_idx.cpu())) / ref_idx.numel()
-        info = {"value": world * QUERY_BATCH * args.steps / el, "unit": "queries/sec", "ms_per_step": el / args.steps * 1e3,
+        info = {"value": world * B * args.steps / el, "unit": "queries/sec", "ms_per_step": el / args.steps * 1e3,
                 "dtype": ("bf16" if prec == "bf16" else "fp8 e4m3fn (per-token / per-channel scales)") +
                          " operands, f32 accumulate (encoder block GEMMs; attention and the fusion BERT blocks in bf16 operand form)",
-                "gemm_tflops": tfl, "gemm_peak_tflops": peak, "gemm_frac": tfl / peak, "gemm_ms_per_step": sp[key + "_ms"] / 2,
-                "gemm_f32_ms_per_step": sp["gemm_ms"] / 2, "attention_ms_per_step": sp["attn_ms"] / 2,
+                "gemm_tflops": tfl, "gemm_peak_tflops": BF16_MFMA_PEAK_TFLOPS, "gemm_frac": tfl / BF16_MFMA_PEAK_TFLOPS,
+                "gemm_ms_per_step": sp[key + "_ms"] / 2, "gemm_f32_ms_per_step": sp["gemm_ms"] / 2, "attention_ms_per_step": sp["attn_ms"] / 2,
                 "vs_fp32_top1_same": float((ref_idx[:, 0] == b_idx[:, 0]).float().mean().item()),
                 "vs_fp32_top50_overlap": overlap,
                 "vs_fp32_max_abs_top1_score_diff": float((ref_scores[:, 0] - b_scores[:, 0]).abs().max().item())}
-        pipe.set_precision("fp32")
+        pipe.set_precision(precision)
         return info
 
+    secondary = not args.headline_only and args.config == "c2" and precision == "fp32"
     bf16_info = fp8_info = None
-    if args.precision == "fp32" and not args.headline_only:
+    if secondary:
+        step_no[0] = 0
         ref_scores, ref_idx = step().wait()
         bf16_info = reduced_precision_leg("bf16", ref_scores, ref_idx)
         fp8_info = reduced_precision_leg("fp8", ref_scores, ref_idx)
 
     # ---- roofline: instrumented passes (events around every kernel class), outside the timed region ----------
-    step_serial()
+    for j in range(n_batches):
+        step_serial(j)
     torch.cuda.synchronize()
     eng.prof_enable(True)
-    prof_steps = max(2, min(5, args.steps))
-    for _ in range(prof_steps):
-        step_serial()
+    prof_steps = max(3, min(6, args.steps))
+    for j in range(prof_steps):
+        step_serial(j)
     st = eng.prof_collect()
     eng.prof_enable(False)
-    gkey = {"fp32": "gemm", "bf16": "gemm_bf16", "fp8": "gemm_fp8"}[args.precision]      # the dominant GEMM family of this run
+    gkey = {"fp32": "gemm", "bf16": "gemm_bf16", "fp8": "gemm_fp8"}[precision]      # the dominant GEMM family of this run
     gemm_tflops = st[gkey + "_flops"] / (st[gkey + "_ms"] * 1e-3) / 1e12 if st[gkey + "_ms"] > 0 else 0.0
-    gemm_peak = F32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
-    sweep_gbs = st["sweep_bytes"] / (st["sweep_ms"] * 1e-3) / 1e9 if st["sweep_ms"] > 0 else 0.0
+    gemm_peak = F32_MFMA_PEAK_TFLOPS if precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
     attn_tflops = st["attn_flops"] / (st["attn_ms"] * 1e-3) / 1e12 if st["attn_ms"] > 0 else 0.0
-    enc_ips = lookup_qps = bf16_us = bf16_gbs = bf16_topk_us = None
-    secondary = not args.headline_only
-    # encoder throughput for the gallery side (bounded sample)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3 if secondary else 0):
-        eng.encode_image(images)
-    torch.cuda.synchronize()
+
+    def sweep_block(stats, calls, kernel):
+        """The ranking stage against SURVEY 8d's bytes (N*D*s_g + B*D*4 + B*K*8 per call): `achieved` counts the WHOLE stage
+        (sample pass + bound + sweep + selection + the gated retry pair), `sweep_only_*` the filtered sweep kernel alone."""
+        if calls <= 0 or stats["sweep_ms"] <= 0:
+            return None
+        total_ms = stats["sweep_ms"] + stats["topk_ms"]
+        by = stats["sweep_bytes"]
+        return {"bound": "hbm", "achieved": by / (total_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": by / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+                "algorithmic_bytes_per_call": by / calls, "stage_us": total_ms / calls * 1e3,
+                "sweep_only_us": stats["sweep_ms"] / calls * 1e3, "sweep_only_GBs": by / (stats["sweep_ms"] * 1e-3) / 1e9,
+                "selection_us": stats["topk_ms"] / calls * 1e3}
+
+    sweep_kernel = ("sweep_bf16_kernel<FILTER> (bf16 gallery)" if w["bf16_gallery"] else
+                    "gemm_f32 kernels with the EPI_TOPK_FILTER epilogue (fp32 gallery)") + \
+        " + topk_sample_bound_kernel / topk_candidates_kernel; the [B, N] score matrix is never stored"
+    rank_roof = sweep_block(st, prof_steps, sweep_kernel)
+
+    enc_ips = lookup_qps = None
+    big_roof = None
     if secondary:
-        enc_ips = 3 * QUERY_BATCH / (time.perf_counter() - t0)
+        im, tk, lc = batches[0]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.encode_image(im)
+        torch.cuda.synchronize()
+        enc_ips = 3 * B / (time.perf_counter() - t0)
 
-    # reference-faithful query variant (run/test/test_fiq.py:104-107): the reference image feature is LOOKED UP in the raw
-    # gallery index instead of being encoded per query -> text tower + fusion + rank only
-    ref_rows = torch.arange(QUERY_BATCH, device=device) * 7 % n_gal
+        # reference-faithful query variant (run/test/test_fiq.py:104-107): the reference image feature is LOOKED UP in the raw
+        # gallery index instead of being encoded per query -> text tower + fusion + rank only
+        ref_feats = dev_randn((B, D), 99)
 
-    def step_lookup():
-        tg, ts = eng.encode_text(tokens)
-        qf = eng.dvr_fuse(g_raw[ref_rows], loc, tg, ts)
-        return eng.sim_topk(qf, gallery, TOPK)
+        def step_lookup():
+            tg, ts = eng.encode_text(tk)
+            qf = eng.dvr_fuse(ref_feats, lc, tg, ts)
+            return eng.sim_topk(qf, gallery, K)
 
-    if secondary:
         for _ in range(3):
             step_lookup()
         torch.cuda.synchronize()
@@ -256,73 +470,95 @@ def main():
         for _ in range(args.steps):
             step_lookup()
         torch.cuda.synchronize()
-        lookup_qps = QUERY_BATCH * args.steps / (time.perf_counter() - t0)
+        lookup_qps = B * args.steps / (time.perf_counter() - t0)
 
-        # HBM-bound variant of the sweep (BASELINE config 5 "bf16 similarity"): 1M-row bf16 gallery, same 64 queries
+        # HBM-bound form of the ranking stage (BASELINE config 5 "bf16 similarity"): 1M-row bf16 gallery, 64 queries
         big_n = 1_000_000
-        gal_big = torch.nn.functional.normalize(torch.randn(big_n, D, device=device, generator=torch.Generator(device=device).manual_seed(3)), dim=-1)
+        gal_big = torch.nn.functional.normalize(dev_randn((big_n, D), 3), dim=-1)
         gal_bf16 = eng.gallery_to_bf16(gal_big)
         del gal_big
-        q_unit = torch.nn.functional.normalize(torch.randn(QUERY_BATCH, D, device=device), dim=-1)
-        for _ in range(2):
-            eng.sim_topk_bf16(q_unit, gal_bf16, TOPK)
+        q_unit = torch.nn.functional.normalize(dev_randn((B, D), 5), dim=-1)
+        for _ in range(3):
+            eng.sim_topk_bf16(q_unit, gal_bf16, K)
         eng.prof_enable(True)
-        for _ in range(5):
-            eng.sim_topk_bf16(q_unit, gal_bf16, TOPK)
+        for _ in range(10):
+            eng.sim_topk_bf16(q_unit, gal_bf16, K)
         sb = eng.prof_collect()
         eng.prof_enable(False)
-        bf16_us = sb["sweep_ms"] / max(1, sb["sweep_launches"]) * 1e3
-        bf16_gbs = sb["sweep_bytes"] / max(1, sb["sweep_launches"]) / (bf16_us * 1e-6) / 1e9 if bf16_us > 0 else 0.0
-        bf16_topk_us = sb["topk_ms"] / max(1, sb["topk_launches"]) * 1e3
+        big_roof = sweep_block(sb, 10, "sweep_bf16_kernel<FILTER>: 64 queries x 1M-row bf16 gallery + sample bound / candidate select")
         del gal_bf16
 
     result = None
     if rank == 0:
+        traffic = traffic_src = alg_bytes = sweep_traffic = None
+        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(traffic_file) and precision == "fp32" and args.config == "c2":
+            tr = json.load(open(traffic_file))
+            traffic = tr.get("gemm", {}).get("hbm_bytes_per_launch")
+            alg_bytes = tr.get("gemm", {}).get("algorithmic_bytes_per_launch")
+            sweep_traffic = tr.get("sweep", {}).get("hbm_bytes_per_launch")
+            traffic_src = ("STALE -- not measured in this run: read from profiles/pmc_traffic.json, produced by separate `rocprofv3 --pmc "
+                           "FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `bench.py --pmc-mode` (" + str(tr.get("source")) + ")")
         result = {
             "metric": "composed queries/sec", "value": value, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp8": "fp8"}[args.precision], "data": "synthetic",
-            "config": {"workload": "FashionIQ ViT-B/16 composed queries: 64-query batch per GPU vs 46k-image fused gallery "
-                                   "(BASELINE.json configs[1])",
-                       "query_batch_per_gpu": QUERY_BATCH, "gallery_rows": n_gal, "feature_dim": D, "top_k": TOPK,
-                       "image": "3x224x224", "tokens": 77, "patch_feats": 13, "batches_in_flight": args.lanes,
-                       "parallelism": f"dp{world} queries, gallery sharded for the build then all-gathered (RCCL)"},
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp8": "fp8"}[precision], "data": "synthetic",
+            "config": {"workload": w["text"], "name": args.config, "clip": cfg.name, "query_batch_per_gpu": B, "gallery_rows": n_gal,
+                       "gallery_dtype": "bf16" if w["bf16_gallery"] else "f32", "feature_dim": D, "top_k": K,
+                       "image": f"3x{cfg.image_size}x{cfg.image_size}", "tokens": 77, "patch_feats": 13, "batches_in_flight": args.lanes,
+                       "input_batches_rotated": n_batches,
+                       "parallelism": f"dp{world} queries; gallery built sharded ({per} rows per rank, seed + rank), fused blocks all-gathered once"},
+            "ms_per_step_event_median": gap_median,
+            "rccl_world": world if backend == "nccl" else (1 if world == 1 else f"{world} (debug backend {backend})"),
+            "all_gather": {"ms": ag_ms if world > 1 else 0.0, "bytes_received_per_rank": ag_bytes,
+                           "GBs_per_rank": (ag_bytes / (ag_ms * 1e-3) / 1e9) if world > 1 and ag_ms > 0 else None,
+                           "xgmi_peak_GBs_per_gpu": XGMI_PEAK_GBS,
+                           "frac_of_xgmi": (ag_bytes / (ag_ms * 1e-3) / 1e9 / XGMI_PEAK_GBS) if world > 1 and ag_ms > 0 else None,
+                           "shard_rows": per, "collective": "all_gather_into_tensor of the fused [rows/rank, D] blocks"},
             "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": gemm_peak, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / gemm_peak, "traffic": None,
+                         "frac": gemm_tflops / gemm_peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel": {"fp32": "gemm_f32_glds_kernel / gemm_f32_kernel (fp32 MFMA GEMM, all tile variants)",
                                     "bf16": "gemm_bf16_glds_kernel (bf16 MFMA GEMM of the encoder blocks)",
-                                    "fp8": "gemm_bf16_glds_kernel<FP8> (fp8 MFMA GEMM of the encoder blocks)"}[args.precision],
+                                    "fp8": "gemm_bf16_glds_kernel<FP8> (fp8 MFMA GEMM of the encoder blocks)"}[precision],
                          "gemm_ms_per_step": st[gkey + "_ms"] / prof_steps, "gemm_gflop_per_step": st[gkey + "_flops"] / prof_steps / 1e9,
-                         "gemm_launches_per_step": st[gkey + "_launches"] / prof_steps},
-            "roofline_sim_sweep": {"bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": None,
-                                   "kernel": "gemm_f32_kernel as the cosine sweep inside fern_sim_topk",
-                                   "sweep_us": st["sweep_ms"] / max(1, st["sweep_launches"]) * 1e3,
-                                   "topk_us": st["topk_ms"] / max(1, st["topk_launches"]) * 1e3},
-            "roofline_sim_sweep_bf16_1M": None if bf16_gbs is None else {"bound": "hbm", "achieved": bf16_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": bf16_gbs / HBM_PEAK_GBS, "traffic": None,
-                                           "kernel": "sweep_bf16_kernel: 64 queries x 1M-row bf16 gallery (config 5's similarity mode)",
-                                           "sweep_us": bf16_us, "topk_us": bf16_topk_us},
+                         "gemm_launches_per_step": st[gkey + "_launches"] / prof_steps,
+                         "f32_gemm_ms_per_step": st["gemm_ms"] / prof_steps},
+            "roofline_sim_sweep": rank_roof,
+            "roofline_sim_sweep_bf16_1M": big_roof,
             "encoder_bf16": bf16_info,
             "encoder_fp8": fp8_info,
+            "sharded_merge": sharded_info,
             "attention": {"achieved_tflops": attn_tflops, "ms_per_step": st["attn_ms"] / prof_steps},
             "lookup_variant": None if lookup_qps is None else {"value": lookup_qps * world, "unit": "queries/sec",
                                "note": "reference-faithful query path (test_fiq.py:104-107): reference features looked up in the index, "
                                        "no per-query image encode; one stream"},
-            "gallery_build": {"index_fuse_all_gather_s": gallery_build_s, "rows_per_s": n_gal / gallery_build_s,
+            "gallery_build": {"shard_fuse_s": fuse_s, "rows_per_s_per_gpu": (stop - start) / fuse_s if fuse_s > 0 else None,
+                              "rows_per_s_all_gpus": n_gal / fuse_s if fuse_s > 0 else None,
                               "encode_images_per_s_per_gpu": enc_ips},
+            "gemm_tiles": eng.tuner_export().strip().split("\n"),
+            "gemm_tiles_pinned_from": os.environ.get("FERN_GEMM_TILES"),
         }
-        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(traffic_file) and args.precision == "fp32":      # HBM bytes per launch from a separate `rocprofv3 --pmc` pass of this command
-            tr = json.load(open(traffic_file))
-            result["roofline"]["traffic"] = tr.get("gemm", {}).get("hbm_bytes_per_launch")
-            result["roofline"]["traffic_source"] = tr.get("source")
-            result["roofline"]["algorithmic_bytes_per_launch"] = tr.get("gemm", {}).get("algorithmic_bytes_per_launch")
-            result["roofline_sim_sweep"]["traffic"] = tr.get("sweep", {}).get("hbm_bytes_per_launch")
+        if rank_roof is not None:
+            rank_roof["traffic"] = sweep_traffic
+        if args.save_tiles:
+            with open(args.save_tiles, "w") as f:
+                f.write(eng.tuner_export())
         if world == 1 and not args.no_cpu_baseline:
-            gpu_topk = step_serial()
+            pipe.set_precision("fp32")      # the oracle is an fp32 statement: compare it with the fp32 path, whatever was timed
+            im, tk, lc = batches[0]
+            rf = eng.encode_image(im)
+            tg, ts = eng.encode_text(tk)
+            qf = eng.dvr_fuse(rf, lc, tg, ts)
+            gpu_topk = eng.sim_topk(qf, gallery.float(), K) if w["bf16_gallery"] else eng.sim_topk(qf, gallery, K)
             torch.cuda.synchronize()
-            result["cpu_baseline"] = cpu_baseline(clip_sd, fusion_sd, cfg, images, tokens, loc, gallery, args.cpu_sample, gpu_topk)
+            n_cpu = gallery.shape[0] if gallery.shape[0] <= 200_000 else 200_000      # bound the CPU matmul on the 1M-row config
+            if n_cpu != gallery.shape[0]:
+                gpu_topk = eng.sim_topk(qf, gallery[:n_cpu].float(), K)
+            result["cpu_baseline"] = cpu_baseline(clip_sd, fusion_sd, cfg, w, im, tk, lc, gallery[:n_cpu], args.cpu_sample, gpu_topk)
+            gap = result["cpu_baseline"]["parity_vs_hip"]["max_oracle_score_gap_at_mismatching_positions"]
+            if gap > 2e-6 and not w["bf16_gallery"]:
+                raise SystemExit(f"bench: the HIP top-{K} differs from the CPU oracle's beyond near-ties (oracle score gap {gap:.3e} > 2e-6)")
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

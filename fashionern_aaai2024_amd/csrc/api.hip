@@ -1330,11 +1330,11 @@ extern "C" int fern_text_encode(fern_ctx* c, const int64_t* tokens, const float*
 // rank
 // ------------------------------------------------------------------------------------------------
 // Fused sweep + selection (kernels.h: TopkFilter): plan and workspace of one query chunk.
-//   sample pass   S = N / R rows (R = 64; at least 1024 rows, or all of them), scores stored [m, S]       -> PROF_TOPK
-//   bound         per query the K-th best sample key, a lower bound of the true K-th best                 -> PROF_TOPK
-//   sweep         the full pass: nothing stored, ~K*R survivors per query appended to cand[m][cap]        -> PROF_SWEEP
-//   select        exact top-K of each list; an overflowed list raises its bound and arms the retry pair   -> PROF_TOPK
-//   retry pair    the same sweep + select, gated on flags[0] (empty launches unless a list overflowed)    -> PROF_TOPK
+//   sample pass   S = max(N / 64, min(N, 4096)) rows, one per run of R = N / S rows, scores stored [m, S]   -> PROF_TOPK
+//   bound         per query the K-th best sample key, a lower bound of the true K-th best                   -> PROF_TOPK
+//   sweep         the full pass: nothing stored, ~K*R survivors per query appended to its 256 lists         -> PROF_SWEEP
+//   select        exact top-K of the lists; an overflowed list raises the query's bound, arms the retry pair -> PROF_TOPK
+//   retry pair    the same sweep + select, gated on flags[0] (empty launches unless a list overflowed)       -> PROF_TOPK
 struct RankPlan {
     long S; int R; int cap;
     float* sample; long ld;
@@ -1342,24 +1342,19 @@ struct RankPlan {
     TopkFilter filt;
 };
 static int rank_plan(fern_ctx* c, int m, int64_t N, int K, const int32_t* exclude, int64_t idx_offset, RankPlan* P) {
-    P->R = 64;
-    P->S = N / P->R;
-    if (P->S < 1024) {
-        P->S = std::min<long>(N, 1024);
-        P->R = P->S > 0 ? (int)(N / P->S) : 1;
-    }
-    long cap = 1024;
-    while (cap < 4L * K * P->R) cap *= 2;          // expected survivors per query ~ K * R
+    P->S = std::min<long>(std::max<long>(N / 64, std::min<long>(N, 4096)), 32768);      // the bound kernel holds a query's sample in LDS
+    P->R = P->S > 0 ? (int)(N / P->S) : 1;
+    // a list sees ~K * R / 256 survivors (<= 16 at K = R = 64); 64 entries is what one wave load of the select kernel covers
+    P->cap = 64;
     static const int cap_override = [] { const char* e = std::getenv("FERN_RANK_CAP"); return e ? std::atoi(e) : 0; }();
-    if (cap_override >= 64) cap = cap_override;     // test hook: tiny lists force the overflow / retry / error paths
-    P->cap = (int)cap;
+    if (cap_override >= 1 && cap_override <= 64) P->cap = cap_override;     // test hook: tiny lists force the overflow / retry / error paths
     P->ld = (std::max<long>(P->S, 4) + 3) & ~3L;
     FERN_TRY(ws_get(c, (size_t)m * P->ld, &P->sample));
     FERN_TRY(ws_get(c, (size_t)m, &P->thr));
-    FERN_TRY(ws_get(c, (size_t)m, &P->count));
+    FERN_TRY(ws_get(c, (size_t)m * RANK_SLOTS, &P->count));
     FERN_TRY(ws_get(c, (size_t)4, &P->flags));
     unsigned long long* cand;
-    FERN_TRY(ws_get(c, (size_t)m * P->cap, &cand));
+    FERN_TRY(ws_get(c, (size_t)m * RANK_SLOTS * P->cap, &cand));
     P->filt = TopkFilter{cand, P->thr, P->count, exclude, (long)idx_offset, P->cap};
     return FERN_OK;
 }
@@ -1370,7 +1365,7 @@ static int rank_flag_ready(fern_ctx* c, const char* fn) {
     }
     return check_rank_flag(c, fn);
 }
-static const size_t kRankQueryChunk = 1024;      // queries per plan: bounds cand[m][cap] (128 KiB per query at K = 50, R = 64)
+static const size_t kRankQueryChunk = 1024;      // queries per plan: bounds cand[m][256][64] (128 KiB per query)
 
 extern "C" int fern_sim_topk(fern_ctx* c, const float* q, const float* gallery, int B, int64_t N, int D, int K, float* out_scores,
                              int32_t* out_idx, int64_t idx_offset, const int32_t* exclude_idx, void* stream) {
@@ -1442,7 +1437,7 @@ extern "C" int fern_sim_topk_bf16(fern_ctx* c, const float* q, const uint16_t* g
         // the sweep kernel keeps <= 64 queries resident in LDS: one launch per 64-query block, shared plan buffers
         auto block_filter = [&](long b0) {
             TopkFilter f = P.filt;
-            f.cand += b0 * P.cap; f.thr_key += b0; f.count += b0;
+            f.cand += b0 * RANK_SLOTS * P.cap; f.thr_key += b0; f.count += b0 * RANK_SLOTS;
             if (f.exclude) f.exclude += b0;
             return f;
         };

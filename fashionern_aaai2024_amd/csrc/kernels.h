@@ -11,15 +11,20 @@ namespace fern {
 // ---- fused similarity sweep + top-K selection (shared by the fp32 GEMM sweep and the bf16 sweep) ------------------
 // The sweep never stores the [B, N] score matrix.  A first, small pass scores a jittered 1-in-R row SAMPLE of the gallery
 // and takes each query's K-th best sample key as a lower bound of its true K-th best; the full sweep then appends only
-// the scores that reach that bound (about K*R of N per query) to a per-query candidate list, and the final kernel
-// selects the exact top-K from the list.  Keys order by (score desc, gallery index asc) as one unsigned compare.
+// the scores that reach that bound (about K*R of N per query) to the query's candidate lists, and the final kernel
+// selects the exact top-K from them.  Keys order by (score desc, gallery index asc) as one unsigned compare.
+// A query owns RANK_SLOTS lists; gallery row n appends to list n % RANK_SLOTS.  So the append counters are spread over
+// B * RANK_SLOTS addresses (returning atomics on ONE address serialise chip-wide at ~5 per us: with one counter per query the
+// sweep was 15x slower than its HBM time), the lanes of a tile never collide, and a run of consecutive good rows -- near
+// duplicates sit next to each other in real galleries -- lands in different lists instead of overflowing one.
+constexpr int RANK_SLOTS = 256;
 struct TopkFilter {
-    unsigned long long* cand;             // [B][cap] candidate keys, appended in arrival order
+    unsigned long long* cand;             // [B][RANK_SLOTS][cap] candidate keys, appended in arrival order
     const unsigned long long* thr_key;    // [B] lower bound: keys below it are not in the top-K (0: accept all, ~0: reject all)
-    int* count;                           // [B] candidates offered so far (may exceed cap: overflow, handled by a retry pass)
+    int* count;                           // [B][RANK_SLOTS] candidates offered so far (may exceed cap: overflow -> retry pass)
     const int* exclude;                   // [B] gallery index to drop per query (CIRR reference removal), or null ...
     long exclude_off;                     // ... as a global index: the local row is exclude[q] - exclude_off
-    int cap;
+    int cap;                              // entries per list (<= 64: the select kernel reads a list with one wave load)
 };
 // sample column c -> gallery row: one row out of every run of R consecutive rows, at a hashed offset inside the run (a fixed
 // stride would alias with periodic structure in the gallery order); monotonic in c, so sample order = gallery order
@@ -108,26 +113,33 @@ __device__ __forceinline__ float filter_bound(unsigned long long thr_key) {
     return thr_key == ~0ull ? __builtin_inff() : unorderable((unsigned)(thr_key >> 32));
 }
 // One 32x32 accumulator tile of scores (register r = query q0 + (r & 3) + 8 (r >> 2) + 4 lh, lane = gallery row n): the
-// common case -- no score reaches its query's bound -- is 16 compares and one branch; survivors are appended one lane at a time.
+// common case -- no score reaches its query's bound -- is 16 compares and one branch.  Survivors: the exact key test, then
+// all the tile's list appends are issued back to back (one round trip for the returned positions, not one per register).
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ void topk_filter_tile(const f32x16_t& acc, const float (&bound)[16], int q0, int lh, long n, bool n_ok, int B,
                                                  const TopkFilter& f) {
-    bool hit = false;
+    unsigned hits = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hit |= !(acc[r] < bound[r]);
-    if (!__any(hit && n_ok)) return;
+    for (int r = 0; r < 16; ++r) hits |= (!(acc[r] < bound[r]) ? 1u : 0u) << r;
+    hits = n_ok ? hits : 0u;
+    if (!__any(hits != 0)) return;
+    const long slot = n & (RANK_SLOTS - 1);
+    const bool use_ex = f.exclude != nullptr;
+    int pos[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        if (!(acc[r] < bound[r]) && n_ok) {
-            const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (q < B) {
-                const unsigned long long key = make_key(acc[r], (unsigned)n);
-                if (key >= f.thr_key[q] && !(f.exclude && (long)f.exclude[q] - f.exclude_off == n)) {
-                    const int pos = atomicAdd(&f.count[q], 1);
-                    if (pos < f.cap) f.cand[(long)q * f.cap + pos] = key;
-                }
-            }
+        pos[r] = -1;
+        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if ((hits >> r & 1u) && q < B) {
+            const unsigned long long key = make_key(acc[r], (unsigned)n);
+            if (key >= f.thr_key[q] && !(use_ex && (long)f.exclude[q] - f.exclude_off == n))
+                pos[r] = atomicAdd(&f.count[(long)q * RANK_SLOTS + slot], 1);
         }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (pos[r] >= 0 && pos[r] < f.cap) f.cand[((long)q * RANK_SLOTS + slot) * f.cap + pos[r]] = make_key(acc[r], (unsigned)n);
     }
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
@@ -226,13 +238,13 @@ hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* sco
 
 // ---- top-K (topk.hip) ------------------------------------------------------------------------
 // Fused sweep, step 2: per query the K-th best key of the sample scores [B, ld] (S valid columns; column c is gallery row
-// sample_row(c, R)) -> thr_key[b] (0 when the sample holds fewer than K rows); also resets count[b] and flags[0..1].  A sample
+// sample_row(c, R)) -> thr_key[b] (0 when the sample holds fewer than K rows); also resets count[b][*] and flags[0..1].  A sample
 // row that is the query's excluded gallery index (exclude[b] - exclude_off, exclude may be null) does not count.
 hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S, int R, int K, const int* exclude, long exclude_off,
                                     unsigned long long* thr_key, int* count, int* flags, hipStream_t s);
 // Fused sweep, final step: exact top-K of each query's candidate list -> out (idx = row + idx_offset; unfilled: -inf / -1).
-// A query whose list overflowed (count > cap) is not written in the first pass: its bound is raised to the K-th best of the
-// cap stored candidates, its count reset, flags[0] set, and the sweep + this kernel run again with pass = 1 (gated on
+// A query with an overflowed list (a count > cap) is not written in the first pass: its bound is raised to the K-th best of the
+// stored candidates, its counts reset, flags[0] set, and the sweep + this kernel run again with pass = 1 (gated on
 // flags[0]); queries that did not overflow get bound ~0 (reject all) for that pass.  An overflow in pass 1 sets *error_flag
 // (host-mapped) and writes NaN scores / idx -1.
 hipError_t launch_topk_candidates(const TopkFilter& f, unsigned long long* thr_key_rw, int B, int K, long idx_offset, float* out_scores,

@@ -40,6 +40,10 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* x, u16* y
 constexpr int ROWS_T = 32;              // gallery rows per wave tile
 constexpr int KSTAGE = 64;              // k elements per ring stage (128 bytes per row)
 constexpr int STAGE_BYTES = ROWS_T * KSTAGE * 2;   // 4096
+// Filter form: survivors are queued per wave in LDS and flushed to the candidate lists QFLUSH.. at a time -- the list append is
+// a RETURNING global atomic (~1-2 us round trip); one per finished tile stalled the wave's DMA ring and cost 40 % of the stream
+constexpr int QCAP = 128;                          // queue entries per wave (a register can add up to 64 at once)
+constexpr int QUEUE_BYTES = 4 * QCAP * 12 + 64 * 8;      // 4 waves x (key 8 B + query 4 B) + the 64 bounds as keys
 
 // FILTER = false: the sample pass -- tile rows are the gallery rows sample_row(c, R) of S sample columns, scores are stored
 // ([B, ld], 128-byte coalesced).  FILTER = true: the full sweep -- nothing is stored; every finished 32x32 score tile is
@@ -72,15 +76,60 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
 
     // per-query bounds of the filter, laid out like the accumulator registers (query = tm*32 + (r&3) + 8(r>>2) + 4 lh)
     float bound[2][16];
+    unsigned char* qbase = ring_base + 4 * STAGES * STAGE_BYTES;
+    unsigned long long* thr_lds = reinterpret_cast<unsigned long long*>(qbase + 4 * QCAP * 12);
+    unsigned long long* qkey = reinterpret_cast<unsigned long long*>(qbase + wave * QCAP * 12);
+    int* qq = reinterpret_cast<int*>(qbase + wave * QCAP * 12 + QCAP * 8);
+    int qlen = 0;                                                  // wave-uniform
     if (FILTER) {
+        if (tid < 64) thr_lds[tid] = tid < B ? filt.thr_key[tid] : ~0ull;
+        __syncthreads();
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qi = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                bound[tm][r] = qi < B ? filter_bound(filt.thr_key[qi]) : __builtin_inff();
-            }
+            for (int r = 0; r < 16; ++r) bound[tm][r] = filter_bound(thr_lds[tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]);
     }
+    // append the queued survivors to their lists: one batch of returning atomics per <= 64 entries
+    auto flush = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the queue writes of every lane have landed
+        for (int base = 0; base < qlen; base += 64) {
+            const int i = base + lane;
+            if (i < qlen) {
+                const unsigned long long key = qkey[i];
+                const int qi = qq[i];
+                const long n = (long)(0xFFFFFFFFu - (unsigned)key);
+                const long list = (long)qi * RANK_SLOTS + (n & (RANK_SLOTS - 1));
+                const int pos = atomicAdd(&filt.count[list], 1);
+                if (pos < filt.cap) filt.cand[list * filt.cap + pos] = key;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // queue reads done before the next appends overwrite it
+        qlen = 0;
+    };
+    // one finished accumulator tile (32 queries x 32 gallery rows): fast reject, else queue the survivors
+    auto filter_tile = [&](const f32x16& a, const float (&bd)[16], int tm, long n, bool n_ok) {
+        unsigned hits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hits |= (!(a[r] < bd[r]) ? 1u : 0u) << r;
+        hits = n_ok ? hits : 0u;
+        if (!__any(hits != 0)) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (__any((hits >> r) & 1u)) {                           // wave-uniform
+                const int qi = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const unsigned long long key = make_key(a[r], (unsigned)n);
+                const bool keep = ((hits >> r) & 1u) && key >= thr_lds[qi] &&
+                                  !(filt.exclude && qi < B && (long)filt.exclude[qi] - filt.exclude_off == n);
+                const unsigned long long km = __ballot(keep);
+                if (km) {
+                    if (qlen > QCAP - 64) flush();
+                    const int off = qlen + __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0));
+                    if (keep) { qkey[off] = key; qq[off] = qi; }
+                    qlen += __popcll(km);
+                }
+            }
+        }
+    };
 
     unsigned char* ring = ring_base + wave * (STAGES * STAGE_BYTES);
     const int kchunks = D / KSTAGE;                                // stages per tile
@@ -142,7 +191,7 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
             if (FILTER) {
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) {
-                    topk_filter_tile(acc[tm], bound[tm], tm * 32, lh, n, n < N, B, filt);
+                    filter_tile(acc[tm], bound[tm], tm, n, n < N);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[tm][r] = 0.0f;
                 }
@@ -159,6 +208,7 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
             }
         }
     }
+    if (FILTER) flush();
 }
 
 hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStream_t s) {
@@ -171,7 +221,7 @@ hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStre
 template <int STAGES, bool FILTER>
 static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
                                     const TopkFilter& filt, const int* gate, hipStream_t s) {
-    const size_t lds = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024 + (size_t)4 * STAGES * STAGE_BYTES;
+    const size_t lds = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024 + (size_t)4 * STAGES * STAGE_BYTES + QUEUE_BYTES;
     static size_t attr_set = 0;
     auto kern = sweep_bf16_kernel<STAGES, FILTER>;
     if (lds > attr_set) {
@@ -190,7 +240,7 @@ template <bool FILTER>
 static hipError_t launch_sweep_mode(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
                                     const TopkFilter& filt, const int* gate, hipStream_t s) {
     const size_t qbytes = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024;
-    const size_t room = (size_t)160 * 1024 - qbytes;
+    const size_t room = (size_t)160 * 1024 - qbytes - QUEUE_BYTES;
     const int stages = (int)(room / (4 * STAGE_BYTES));
     if (stages >= 5) return launch_sweep_inst<5, FILTER>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
     if (stages >= 4) return launch_sweep_inst<4, FILTER>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);

@@ -14,6 +14,8 @@
 // (topk_sample_bound_kernel) and select the exact top-K from the lists (topk_candidates_kernel).  kernels.h: TopkFilter.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace fern {
 
 typedef unsigned long long u64;
@@ -124,14 +126,127 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float* scores, con
 }
 
 // ---- fused sweep + selection (kernels.h: TopkFilter) -----------------------------------------------------------------
-// Step 2: one workgroup per query reads that query's SAMPLE scores (S columns; column c is gallery row sample_row(c, R)),
-// keeps the best 64 keys (4 waves, merged through LDS) and publishes the K-th as the query's bound.  Sample columns are in
-// gallery order, so a key built from the column index ranks ties like one built from the row; the published key carries the
-// real row.  Fewer than K sample rows -> bound 0 (accept all).
-__global__ __launch_bounds__(256) void topk_sample_bound_kernel(const float* scores, long ld, long S, int R, int K, const int* exclude,
+// Both kernels here need "the k-th largest of n keys" for n in the thousands, once per query.  Streaming the keys through the
+// sorted wave lists cost 25-55 us (every early candidate is an insertion), a radix select with LDS histograms was no better
+// (cosine scores share their top bytes: thousands of LDS atomics on a handful of bins serialise).  What is used instead is
+// BISECTION BY COUNTING on keys held in registers: each of the 256 threads keeps <= PER keys, a step counts the keys >= a probe
+// (PER compares per thread, a DPP wave sum, four partial sums through LDS, one barrier) and halves the range, which starts at
+// [min, max] of the keys -- so the step count is log2 of the keys' spread, not of the key width.  Keys are 64-bit = hi
+// (orderable score) << 32 | lo (~index): first the hi word, then lo among the keys that share the k-th hi (usually one key).
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);     // row_mirror: every lane holds its 16-lane row's sum
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ int wave_inclusive_sum(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d);
+        v += lane >= d ? t : 0;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned o = __shfl_xor(v, m); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned o = __shfl_xor(v, m); v = o > v ? o : v; }
+    return v;
+}
+// Workgroup helper (NW waves): `red` is 4 * NW words of LDS; `step` alternates the half used so that one barrier per
+// reduction is enough (a wave can only reach step + 2 after every wave has read step's sums).
+template <int NW>
+struct WgReduce {
+    int* red;
+    int step;
+    __device__ __forceinline__ int sum(int local) {
+        const int s = wave_sum_i32(local);
+        int* slot = red + (step & 1) * NW;
+        if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = s;
+        __syncthreads();
+        ++step;
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += slot[w];
+        return t;
+    }
+    __device__ __forceinline__ unsigned min(unsigned local) {
+        const unsigned s = wave_min_u32(local);
+        unsigned* slot = reinterpret_cast<unsigned*>(red) + 2 * NW + (step & 1) * NW;
+        if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = s;
+        __syncthreads();
+        ++step;
+        unsigned t = 0xFFFFFFFFu;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t = slot[w] < t ? slot[w] : t;
+        return t;
+    }
+    __device__ __forceinline__ unsigned max(unsigned local) { return ~min(~local); }
+};
+// k-th largest (k >= 1) of the workgroup's keys: thread-local hi words h[0..PER) (0 = empty slot) and lo words from lo_of(j).
+// Returns 0 when fewer than k keys exist.  Every thread of the workgroup (NW waves) must call it (barriers inside).
+template <int PER, int NW, class LoOf>
+__device__ __forceinline__ u64 select_kth_largest(const unsigned (&h)[PER], LoOf lo_of, int k, int* red) {
+    WgReduce<NW> wg{red, 0};
+    int nv = 0;
+    unsigned mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        nv += h[j] != 0;
+        mn = (h[j] != 0 && h[j] < mn) ? h[j] : mn;
+        mx = h[j] > mx ? h[j] : mx;
+    }
+    if (wg.sum(nv) < k) return 0;
+    unsigned lo = wg.min(mn), hi = wg.max(mx);
+    while (lo < hi) {                                     // largest v with count(h >= v) >= k
+        const unsigned mid = lo + (unsigned)(((u64)hi - lo + 1) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) c += h[j] >= mid;
+        if (wg.sum(c) >= k) lo = mid;
+        else hi = mid - 1;
+    }
+    const unsigned kh = lo;
+    // among the keys with hi == kh, the r-th largest lo (r = k - #keys with a larger hi)
+    int gt = 0;
+    unsigned lmn = 0xFFFFFFFFu, lmx = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        gt += h[j] > kh;
+        if (h[j] == kh) {
+            const unsigned l = lo_of(j);
+            lmn = l < lmn ? l : lmn;
+            lmx = l > lmx ? l : lmx;
+        }
+    }
+    const int r = k - wg.sum(gt);
+    unsigned llo = wg.min(lmn), lhi = wg.max(lmx);
+    while (llo < lhi) {
+        const unsigned mid = llo + (unsigned)(((u64)lhi - llo + 1) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) c += (h[j] == kh) && lo_of(j) >= mid;
+        if (wg.sum(c) >= r) llo = mid;
+        else lhi = mid - 1;
+    }
+    return ((u64)kh << 32) | llo;
+}
+
+// Step 2: one workgroup per query keeps that query's SAMPLE scores (S columns; column c is gallery row sample_row(c, R)) in
+// registers -- 1024 threads, thread t holds columns t, t + 1024, ... (four waves per SIMD keep the compare stream dense) -- and publishes the K-th best key as the query's bound.  Sample columns
+// are in gallery order, so a key built from the column index ranks ties like one built from the row; the published key carries
+// the real row.  Fewer than K sample rows -> bound 0 (accept all).  Also resets the query's list counters.
+template <int PER>
+__global__ __launch_bounds__(1024) void topk_sample_bound_kernel(const float* scores, long ld, long S, int R, int K, const int* exclude,
                                                                 long exclude_off, u64* thr_key, int* count, int* flags) {
-    __shared__ u64 lists[4][64];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int red[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
     const float* row = scores + (long)b * ld;
     // sample column of the excluded gallery row (if it was sampled at all): it must not count towards the K rows of the bound
     long drop = -1;
@@ -139,66 +254,121 @@ __global__ __launch_bounds__(256) void topk_sample_bound_kernel(const float* sco
         const long er = (long)exclude[b] - exclude_off;
         if (er >= 0 && er / R < S && sample_row(er / R, R) == er) drop = er / R;
     }
-    u64 best = 0;
-    for (long base = (long)wave * 64; base < S; base += 256) {
-        const long c = base + lane;
-        u64 cand = 0;
-        if (c < S && c != drop) {
-            const float v = row[c];
-            if (v != -INFINITY) cand = make_key(v, (unsigned)c);      // -inf marks padding
-        }
-        wave_offer(best, cand, K, lane);
+    unsigned h[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const long c = tid + 1024L * j;
+        float v = -INFINITY;
+        if (c < S && c != drop) v = row[c];
+        h[j] = v == -INFINITY ? 0u : orderable(v);                          // -inf marks padding
     }
-    lists[wave][lane] = best;
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll 1
-        for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, lists[w][lane], lane);
-        const u64 kth = shfl64(best, K - 1);
-        if (lane == 0) {
-            u64 out = 0;
-            if (kth != 0) {
-                const long c = (long)(0xFFFFFFFFu - (unsigned)kth);
-                out = (kth & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - (unsigned)sample_row(c, R));
-            }
-            thr_key[b] = out;
-            count[b] = 0;
-            if (b == 0) { flags[0] = 0; flags[1] = 0; }
+    if (tid < RANK_SLOTS) count[(long)b * RANK_SLOTS + tid] = 0;
+    const u64 kth = select_kth_largest<PER, 16>(h, [&](int j) { return 0xFFFFFFFFu - (unsigned)(tid + 1024 * j); }, K, red);
+    if (tid == 0) {
+        u64 out = 0;
+        if (kth != 0) {
+            const long c = (long)(0xFFFFFFFFu - (unsigned)kth);
+            out = (kth & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - (unsigned)sample_row(c, R));
         }
+        thr_key[b] = out;
+        if (b == 0) { flags[0] = 0; flags[1] = 0; }
     }
 }
 
-// Final step: one workgroup per query streams its candidate keys (arrival order, 64-bit) through the same wave lists.
+// Final step: one workgroup per query.  Thread t owns list t; a wave's 64 lists are read with one wave-wide load each and their
+// keys dealt round-robin over the 256 threads' registers (LDS as the exchange), the K-th best key comes from the counting
+// bisection, the K keys that reach it are collected and one bitonic sort of <= 64 keys writes the ranking.  More than CAND_MAX
+// candidates (lists near full) take the streaming path.
+constexpr int CAND_PER = 24;                    // keys per thread
+constexpr int CAND_MAX = CAND_PER * 256;        // 6144 keys x 8 bytes of LDS
 __global__ __launch_bounds__(256) void topk_candidates_kernel(TopkFilter f, u64* thr_key_rw, int K, long idx_offset, float* out_scores,
                                                               int* out_idx, int* flags, int pass, int* error_flag) {
+    __shared__ u64 c_key[CAND_MAX];
+    __shared__ int red[16];
     __shared__ u64 lists[4][64];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int wtotal[4], over[4], nsel;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (pass == 1) {
         if (flags[0] == 0) return;                       // no query overflowed in pass 0: nothing to redo
         if (thr_key_rw[b] == ~0ull) return;              // this query was final after pass 0
     }
-    const int total = f.count[b];
-    const int n = total < f.cap ? total : f.cap;
-    const u64* cand = f.cand + (long)b * f.cap;
-    u64 best = 0;
-    for (int base = wave * 64; base < n; base += 256) {
-        const int c = base + lane;
-        wave_offer(best, c < n ? cand[c] : 0, K, lane);
-    }
-    lists[wave][lane] = best;
+    int* cnt_p = f.count + (long)b * RANK_SLOTS + tid;   // thread t owns list t
+    const int cnt_raw = *cnt_p;
+    const int cnt = cnt_raw < f.cap ? cnt_raw : f.cap;
+    const bool overflow_w = __any(cnt_raw > f.cap);
+    const int incl = wave_inclusive_sum(cnt, lane);
+    if (lane == 63) { wtotal[wave] = incl; over[wave] = overflow_w ? 1 : 0; }
+    if (tid == 0) nsel = 0;
     __syncthreads();
-    if (wave != 0) return;
+    int base = incl - cnt;
+    for (int w = 0; w < wave; ++w) base += wtotal[w];
+    const int total = wtotal[0] + wtotal[1] + wtotal[2] + wtotal[3];
+    const bool overflow = (over[0] | over[1] | over[2] | over[3]) != 0;
+    if (overflow && pass == 0) *cnt_p = 0;               // the retry sweep appends to empty lists
+    const u64* cand = f.cand + (long)b * RANK_SLOTS * f.cap;
+    u64 best = 0;                                        // wave 0 ends up with the sorted top-64 (lane i = i-th best)
+    if (total <= CAND_MAX) {
+        // gather: every thread walks ITS list (thread t = list t), eight independent loads in flight per round -- lists hold
+        // ~K * R / 256 <= 16 keys, so this is one or two round trips -- and drops the keys at its prefix-sum offset in LDS
+        int maxc = cnt;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(maxc, m); maxc = o > maxc ? o : maxc; }
+        const u64* mylist = cand + (long)tid * f.cap;
 #pragma unroll 1
-    for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, lists[w][lane], lane);
-    if (total > f.cap) {
-        // More rows reached the bound than the list holds (a sample that missed a cluster of good rows).  The K-th best of
+        for (int e0 = 0; e0 < maxc; e0 += 8) {
+            u64 key[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) key[u] = e0 + u < cnt ? mylist[e0 + u] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u < cnt) c_key[base + e0 + u] = key[u];
+        }
+        __syncthreads();
+        u64 mine[CAND_PER];
+        unsigned h[CAND_PER];
+#pragma unroll
+        for (int j = 0; j < CAND_PER; ++j) {
+            const int i = tid + 256 * j;
+            mine[j] = i < total ? c_key[i] : 0;
+            h[j] = (unsigned)(mine[j] >> 32);
+        }
+        const int want = total < K ? total : K;          // fewer candidates than K: all of them rank
+        u64 kth = 0;
+        if (total > 64) kth = select_kth_largest<CAND_PER, 4>(h, [&](int j) { return (unsigned)mine[j]; }, want, red);
+#pragma unroll
+        for (int j = 0; j < CAND_PER; ++j) {
+            if (mine[j] != 0 && mine[j] >= kth) {
+                const int p = atomicAdd(&nsel, 1);
+                if (p < 64) lists[0][p] = mine[j];
+            }
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        const int ns = nsel < 64 ? nsel : 64;
+        best = sort64_desc(lane < ns ? lists[0][lane] : 0, lane);
+    } else {
+        // streaming path (lists near full: > CAND_MAX candidates): the sorted wave lists of wave_offer
+#pragma unroll 1
+        for (int j = 0; j < 64; ++j) {
+            const int n = __builtin_amdgcn_readlane(cnt, j);
+            wave_offer(best, lane < n ? cand[(long)(wave * 64 + j) * f.cap + lane] : 0, K, lane);
+        }
+        lists[wave][lane] = best;
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll 1
+        for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, lists[w][lane], lane);
+    }
+    if (overflow) {
+        // More rows reached the bound than a list holds (a sample that missed a cluster of good rows).  The K-th best of
         // what WAS stored is still a valid -- and much tighter -- bound (K distinct rows reach it): sweep once more with it.
-        if (pass == 0) {
-            const u64 kth = shfl64(best, K - 1);
-            if (lane == 0) { thr_key_rw[b] = kth; f.count[b] = 0; flags[0] = 1; }
+        const u64 kth = shfl64(best, K - 1);
+        if (pass == 0 && kth != 0) {
+            if (lane == 0) { thr_key_rw[b] = kth; flags[0] = 1; }
             return;
         }
         if (lane == 0 && error_flag) __hip_atomic_store(error_flag, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (pass == 0 && lane == 0) thr_key_rw[b] = ~0ull;
         if (lane < K) { out_scores[(long)b * K + lane] = __builtin_nanf(""); out_idx[(long)b * K + lane] = -1; }
         return;
     }
@@ -219,14 +389,19 @@ hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S,
                                     u64* thr_key, int* count, int* flags, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (K < 1 || K > 64 || S < 0 || R < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(topk_sample_bound_kernel, dim3(B), dim3(256), 0, s, scores, ld, S, R, K, exclude, exclude_off, thr_key, count, flags);
+    // keys per thread of the bisection (registers): the plan caps S at 32768 (api.hip: rank_plan)
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(B), dim3(1024), 0, s, scores, ld, S, R, K, exclude, exclude_off, thr_key, count, flags); };
+    if (S <= 4 * 1024) go(topk_sample_bound_kernel<4>);
+    else if (S <= 16 * 1024) go(topk_sample_bound_kernel<16>);
+    else if (S <= 32 * 1024) go(topk_sample_bound_kernel<32>);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 hipError_t launch_topk_candidates(const TopkFilter& f, u64* thr_key_rw, int B, int K, long idx_offset, float* out_scores, int* out_idx,
                                   int* flags, int pass, int* error_flag, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (K < 1 || K > 64 || f.cap < 64) return hipErrorInvalidValue;
+    if (K < 1 || K > 64 || f.cap < 1 || f.cap > 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(topk_candidates_kernel, dim3(B), dim3(256), 0, s, f, thr_key_rw, K, idx_offset, out_scores, out_idx, flags, pass,
                        error_flag);
     return hipGetLastError();

@@ -75,6 +75,33 @@ def build_gallery(engine, index_features: torch.Tensor, index_local: torch.Tenso
     return full[:n]
 
 
+def all_gather_shards(block: torch.Tensor, n_total: int) -> torch.Tensor:
+    """ONE all_gather of equally sized per-rank blocks [per, ...] (``per = ceil(n_total / world)``, short shards zero-padded by
+    the caller) -> the first ``n_total`` rows of their concatenation on every rank.  This is the path's only data-path
+    collective: one shard per xGMI link, nothing to bucket."""
+    rank, world = world_info()
+    if world == 1:
+        return block[:n_total]
+    full = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(full, block.contiguous())
+    return full[:n_total]
+
+
+def build_gallery_from_shard(engine, shard_features: torch.Tensor, shard_local: torch.Tensor, n_total: int,
+                             normalize_input: bool = True) -> torch.Tensor:
+    """Sharded gallery build: this rank holds ONLY its own rows [start, stop) of the raw index
+    (``shard_rows(n_total, rank, world)``), fuses them with ``mode="index"`` and the fused blocks are all-gathered.  Unlike
+    ``build_gallery`` no rank ever needs the whole raw index (6.6 GB of local features at C3, 27 GB at C5)."""
+    rank, world = world_info()
+    start, stop, per = shard_rows(n_total, rank, world)
+    if shard_features.shape[0] != stop - start:
+        raise ValueError(f"rank {rank} must hold rows [{start}, {stop}) of the index, got {shard_features.shape[0]} rows")
+    block = torch.zeros((per, shard_features.shape[1]), dtype=torch.float32, device=engine.device)
+    if stop > start:
+        block[: stop - start] = engine.index_fuse(shard_features, shard_local, normalize_input=normalize_input)
+    return all_gather_shards(block, n_total)
+
+
 def rank_replicated(engine, queries: torch.Tensor, gallery: torch.Tensor, k: int, exclude_idx=None):
     """Query-data-parallel ranking: this rank's queries against the replicated gallery.  No collective."""
     return engine.sim_topk(queries, gallery, k, exclude_idx=exclude_idx)

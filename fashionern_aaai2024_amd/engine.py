@@ -8,6 +8,7 @@ engine without a ROCm device or without the library raises.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 from typing import Dict, Mapping, Optional
 
 import numpy as np
@@ -79,6 +80,10 @@ class FernEngine:
             self._h = None
 
     def __del__(self):
+        # At interpreter shutdown the HIP runtime (and a profiler's tool library) may already be finalised: calling
+        # hipDeviceSynchronize / hipFree then can block forever.  The OS reclaims the context with the process.
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

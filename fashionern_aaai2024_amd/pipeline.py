@@ -18,8 +18,14 @@ from .engine import FernEngine
 class QueryResult:
     """Top-K of one submitted batch; `scores` / `idx` are valid on the caller's stream after `wait()`."""
 
-    def __init__(self, scores: torch.Tensor, idx: torch.Tensor, fused: torch.Tensor, event: torch.cuda.Event):
-        self.scores, self.idx, self.fused, self._event = scores, idx, fused, event
+    def __init__(self, scores: torch.Tensor, idx: torch.Tensor, fused: torch.Tensor, event: torch.cuda.Event, member_scores=None):
+        self.scores, self.idx, self.fused, self._event, self.member_scores = scores, idx, fused, event, member_scores
+
+    @property
+    def done_event(self) -> torch.cuda.Event:
+        """Recorded on the batch's lane when its last kernel was queued (timing-enabled when the pipeline was built with
+        ``timing=True``: gaps between consecutive batches' events are per-batch service times)."""
+        return self._event
 
     def wait(self) -> Tuple[torch.Tensor, torch.Tensor]:
         cur = torch.cuda.current_stream()
@@ -30,7 +36,8 @@ class QueryResult:
 
 
 class ComposedQueryPipeline:
-    def __init__(self, engine: FernEngine, lanes: int = 3):
+    def __init__(self, engine: FernEngine, lanes: int = 3, timing: bool = False):
+        self.timing = bool(timing)
         if lanes < 1:
             raise ValueError("lanes must be >= 1")
         if engine.clip_cfg is None or engine.feature_dim is None:
@@ -40,8 +47,11 @@ class ComposedQueryPipeline:
         self._next = 0
 
     def submit(self, images: torch.Tensor, tokens: torch.Tensor, local: torch.Tensor, gallery: torch.Tensor, k: int,
-               exclude_idx=None) -> QueryResult:
-        """images [B,3,S,S], tokens [B,77] int64, local [B,13,D] (device tensors), fused gallery [N,D] -> QueryResult."""
+               exclude_idx=None, members=None, idx_offset: int = 0) -> QueryResult:
+        """images [B,3,S,S], tokens [B,77] int64, local [B,13,D] (device tensors), fused gallery [N,D] fp32 -- or bf16, which
+        selects the bf16 sweep -- -> QueryResult.  `exclude_idx` [B] drops one gallery index per query and `members` [B,m]
+        (fp32 gallery) also returns the scores of those rows: CIRR's reference removal and subset ranking
+        (run/test/test_cirr.py:55-66)."""
         lane = self._next
         self._next = (self._next + 1) % len(self.engines)
         eng, stream = self.engines[lane], self.streams[lane]
@@ -50,10 +60,14 @@ class ComposedQueryPipeline:
             ref = eng.encode_image(images)
             tg, ts = eng.encode_text(tokens)
             fused = eng.dvr_fuse(ref, local, tg, ts)
-            scores, idx = eng.sim_topk(fused, gallery, k, exclude_idx=exclude_idx)
-            ev = torch.cuda.Event()
+            if gallery.dtype == torch.bfloat16:
+                scores, idx = eng.sim_topk_bf16(fused, gallery, k, idx_offset=idx_offset, exclude_idx=exclude_idx)
+            else:
+                scores, idx = eng.sim_topk(fused, gallery, k, idx_offset=idx_offset, exclude_idx=exclude_idx)
+            member_scores = eng.gather_scores(fused, gallery, members) if members is not None else None
+            ev = torch.cuda.Event(enable_timing=self.timing)
             ev.record(stream)
-        return QueryResult(scores, idx, fused, ev)
+        return QueryResult(scores, idx, fused, ev, member_scores)
 
     def set_precision(self, precision) -> None:
         """Encoder operand precision of every lane ("fp32" parity mode / "bf16" perf mode, FernEngine.set_precision)."""

@@ -23,11 +23,11 @@ def _rng(seed, tag):
     return np.random.default_rng([seed, zlib.crc32(tag.encode())])
 
 
-def stub_tokenizer(texts, context_length=77):
-    """Deterministic stand-in for open_clip.get_tokenizer(name): (list[str] | str, context_length) -> int64 [B, ctx]."""
+def stub_tokenizer(texts, context_length=77, vocab=1000):
+    """Deterministic stand-in for open_clip.get_tokenizer(name): (list[str] | str, context_length) -> int64 [B, ctx].
+    `vocab` must not exceed the model's vocabulary: out-of-range ids raise (IndexError / FERN_ERR_ARG), as nn.Embedding does."""
     if isinstance(texts, str):
         texts = [texts]
-    vocab = 1000
     out = torch.zeros(len(texts), context_length, dtype=torch.long)
     for i, t in enumerate(texts):
         ids = [1 + zlib.crc32(w.encode()) % (vocab - 3) for w in t.lower().split()][: context_length - 2]

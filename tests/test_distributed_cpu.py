@@ -42,6 +42,12 @@ def _worker(rank, world, port, n, out_dir):
     s, i = fd.rank_replicated(eng, q_mine, gallery, 7)
     s_all, i_all = fd.gather_rows(s), fd.gather_rows(i)
     start, stop, _ = fd.shard_rows(n, rank, world)
+    # the sharded build proper: this rank holds ONLY its rows of the raw index (what bench.py does at C3 / C5 sizes)
+    from_shard = fd.build_gallery_from_shard(eng, raw[start:stop], loc[start:stop], n)
+    assert torch.equal(from_shard, gallery)
+    wrong = 0 if stop > start else 1                                             # any row count but the shard's own is refused
+    with pytest.raises(ValueError):
+        fd.build_gallery_from_shard(eng, raw[:wrong], loc[:wrong], n)
     ex = torch.tensor([3, -1, n - 1, 0, 5, -1, 7, 8, 9, 1], dtype=torch.int32)
     s_sh, i_sh = fd.rank_sharded(eng, q_all, gallery[start:stop], start, 7, exclude_idx=ex)
     # sharded gallery ENCODE: every rank ends up with the same (features, names, local features) as the single-process loop

@@ -173,7 +173,7 @@ def test_full_pipeline_in_bf16_perf_mode_stays_within_the_score_budget():
     > 0.95, recall@K within two queries."""
     cfg = synth.CLIP_CONFIGS["tiny-hd64"]
     d = cfg.embed_dim
-    register_tokenizer("tiny-hd64", sdata.stub_tokenizer)
+    register_tokenizer("tiny-hd64", lambda texts, context_length=77: sdata.stub_tokenizer(texts, context_length, vocab=cfg.vocab_size))
     gal = sdata.Gallery(300, d, seed=31, image_size=cfg.image_size)
     rel = sdata.RelativeDataset(gal, 40, "fiq", seed=32)
     outs = []

@@ -35,23 +35,20 @@ def sample_row(c, r):
 
 def plan(n):
     """Restatement of api.hip:rank_plan -- (sample columns S, ratio R)."""
-    r = 64
-    s = n // r
-    if s < 1024:
-        s = min(n, 1024)
-        r = n // s if s else 1
-    return s, r
+    s = max(n // 64, min(n, 4096))
+    return s, (n // s if s else 1)
 
 
 def test_sample_misses_every_good_row_overflow_then_retry(engine):
-    """Query 0 scores its lowest on exactly the sampled rows, so its bound is useless and ~N rows reach it: the candidate list
-    (cap 16384) overflows, the select kernel raises the bound to the K-th best of what was stored and the gated retry sweep
-    finishes the job.  The other queries take the normal path in the same launch."""
+    """Query 0 scores its lowest on exactly the sampled rows, so its bound is useless and ~N rows reach it: the candidate lists
+    overflow, the select kernel raises the bound to the K-th best of what was stored and the gated retry sweep
+    finishes the job.  The other queries take the normal path in the same launch.  (A query's candidates live in 256 lists of
+    64 entries, list = row % 256: ~96k survivors are ~375 per list.)"""
     n, d, k = 100_000, 64, 50
     q, g = _int_unit(4, d, 21), _int_unit(n, d, 22)
     q[0] = torch.where(q[0] == 0, torch.full_like(q[0], 0.125), q[0])
     s, r = plan(n)
-    assert r == 64 and 4 * k * r <= 16384 < n
+    assert r == 24 and (n - s) // 256 > 64
     rows = torch.tensor([sample_row(c, r) for c in range(s)])
     g[rows] = -torch.sign(q[0]) / 8.0                     # the worst possible score for query 0
     rs, ri = orank.cosine_topk(q, g, k)
@@ -140,31 +137,44 @@ from oracle import rank as orank
 eng = FernEngine("cuda:0")
 g = torch.Generator().manual_seed(1)
 unit = lambda n, d: torch.randint(-1, 2, (n, d), generator=g).float() / 8.0
-# (a) lists of 64 entries overflow all the time; one retry with the raised bound is enough at this size
-q, gal = unit(16, 64), unit(5000, 64)
-rs, ri = orank.cosine_topk(q, gal, 10)
-s, i = eng.sim_topk(q, gal, 10)
-eng.sync()
-assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs), "retry path"
-# (b) all-equal scores, K = cap = 64: the raised bound still lets ~N rows through -> second overflow -> loud failure
-gal = unit(1, 64).repeat(200000, 1)
-s, i = eng.sim_topk(q[:2], gal, 64)
-try:
+mode = {mode!r}
+if mode == "retry":
+    # lists of 4 entries; rows 4096.. are outside the sample (N = 5000 -> the sample is rows 0..4095) and all of them beat it for
+    # query 0: ~3.5 survivors per list -> overflow; the bound raised to the 10th best of what was stored lets ~11 rows through
+    q, gal = unit(16, 64), unit(5000, 64)
+    q[0] = torch.where(q[0] == 0, torch.full_like(q[0], 0.125), q[0])
+    gal[:4096] = torch.where(gal[:4096] * q[0] > 0, -gal[:4096], gal[:4096])       # sampled rows: never positive against query 0
+    gal[4096:] = torch.sign(q[0]) / 8.0 * (torch.rand(904, 64, generator=g) < 0.9)  # the rest: strongly positive, all different
+    rs, ri = orank.cosine_topk(q, gal, 10)
+    s, i = eng.sim_topk(q, gal, 10)
     eng.sync()
-except FernError as e:
-    assert "overflowed a candidate list twice" in str(e), str(e)
-    assert torch.isnan(s.cpu()).all() and (i.cpu() == -1).all()
-    eng.sync()                      # the flag is reported once
+    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs), "retry path"
     print("OK")
 else:
-    raise SystemExit("second overflow went unreported")
+    # lists of ONE entry, all scores equal, K = 64: the raised bound still lets ~3 rows per list through -> second overflow -> loud failure
+    q, gal = unit(2, 64), unit(1, 64).repeat(200000, 1)
+    s, i = eng.sim_topk(q, gal, 64)
+    try:
+        eng.sync()
+    except FernError as e:
+        assert "overflowed a candidate list twice" in str(e), str(e)
+        rs, ri = orank.cosine_topk(q, gal, 64)
+        failed = [b for b in range(2) if torch.isnan(s[b].cpu()).all() and (i[b].cpu() == -1).all()]
+        assert failed, "the reported query's row must hold NaN / -1"
+        for b in set(range(2)) - set(failed):       # a query whose retry happened to fit is still exact
+            assert torch.equal(i[b].cpu(), ri[b]) and torch.equal(s[b].cpu(), rs[b])
+        eng.sync()                      # the flag is reported once
+        print("OK")
+    else:
+        raise SystemExit("second overflow went unreported")
 """
 
 
-def test_forced_tiny_lists_retry_then_report(tmp_path):
-    """FERN_RANK_CAP (test hook, read once per process) shrinks the candidate lists to 64 entries."""
-    env = dict(os.environ, FERN_RANK_CAP="64")
-    r = subprocess.run([sys.executable, "-c", _SCRIPT.format(root=ROOT)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+@pytest.mark.parametrize("cap,mode", [("4", "retry"), ("1", "error")])
+def test_forced_tiny_lists_retry_then_report(cap, mode):
+    """FERN_RANK_CAP (test hook, read once per process) shrinks the candidate lists."""
+    env = dict(os.environ, FERN_RANK_CAP=cap)
+    r = subprocess.run([sys.executable, "-c", _SCRIPT.format(root=ROOT, mode=mode)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
