@@ -51,7 +51,15 @@ struct HostTensor {
 struct LinearW { const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0; const unsigned short* wb = nullptr; /* bf16 copy of w (encoder blocks) */
                  const unsigned char* w8 = nullptr; const float* sw = nullptr; /* fp8 copy + per-output-channel scales */ };
 struct LNW { const float* g = nullptr; const float* b = nullptr; };
-struct CombinerW { LinearW text, image, hidden; const float* w2 = nullptr; const float* b2 = nullptr; };
+struct CombinerW {
+    LinearW text, image, hidden;
+    const float* w2 = nullptr;
+    const float* b2 = nullptr;
+    // query-side combiners (DVR.*): their hidden layer runs at M = batch (64) where an unsplit k chain of 4096 leaves 192 CUs
+    // idle, so K is cut into 512-wide slices -- for EVERY batch size (kernels.h: GemmParams.ksplit): the split belongs to the
+    // module, not to M.  The gallery-side combiner (M = thousands of rows per tile) stays unsplit.
+    int ksplit = 1;
+};
 struct SRW {
     LinearW local, global;
     const float *bn13_mean = nullptr, *bn13_inv = nullptr, *bn13_beta = nullptr;   // per patch
@@ -482,6 +490,10 @@ extern "C" int fern_finalize_fusion(fern_ctx* c, int D, int parts) {
         FERN_TRY(up_combiner(c, "DVR.combiner_global", D, &F.comb[FERN_COMBINER_DVR_GLOBAL]));
         FERN_TRY(up_combiner(c, "DVR.combiner_local", D, &F.comb[FERN_COMBINER_DVR_LOCAL]));
         FERN_TRY(up_combiner(c, "DVR.combiner", D, &F.comb[FERN_COMBINER_DVR_FINAL]));
+        for (int w : {FERN_COMBINER_DVR_GLOBAL, FERN_COMBINER_DVR_LOCAL, FERN_COMBINER_DVR_FINAL}) {
+            CombinerW& Cw = F.comb[w];      // a function of the layer's (N, K) only
+            Cw.ksplit = (Cw.hidden.in >= 2048 && Cw.hidden.in % 512 == 0 && Cw.hidden.out % 32 == 0) ? Cw.hidden.in / 512 : 1;
+        }
         F.parts |= FERN_PART_DVR;
     }
     if (parts & FERN_PART_TARGET_SR) {
@@ -709,7 +721,15 @@ static int run_combiner(fern_ctx* c, const CombinerW& W, const float* image, con
     FERN_TRY(ws_get(c, (size_t)n * nb, &partial));
     GemmParams ph = gemm_desc(cat, H, W.hidden, nullptr, H, (int)n, EPI_RELU_DOT);
     ph.aux0 = W.w2; ph.partial = partial;
-    FERN_TRY(run_gemm(c, ph, s));
+    if (W.ksplit > 1) {
+        float* kpart;
+        FERN_TRY(ws_get(c, (size_t)W.ksplit * n * W.hidden.out, &kpart));
+        ph.ksplit = W.ksplit; ph.kpart = kpart; ph.epi = EPI_BIAS;      // slices store raw sums; bias + ReLU + dot happen in the reduce
+        FERN_TRY(run_gemm(c, ph, s));
+        HIP_TRY(launch_splitk_relu_dot(kpart, W.ksplit, n, W.hidden.out, W.hidden.b, W.w2, partial, s));
+    } else {
+        FERN_TRY(run_gemm(c, ph, s));
+    }
     HIP_TRY(launch_combiner_finalize(partial, nb, W.b2, image, text, out, n, D, s));
     return FERN_OK;
 }

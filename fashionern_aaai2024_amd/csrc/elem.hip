@@ -552,6 +552,32 @@ hipError_t launch_bert_embed(const float* cls, const float* local, const float* 
                        beta, X, B, P, T, d, eps);
     return hipGetLastError();
 }
+// Split-K tail of the CombinerSimple hidden layer (kernels.h): one thread per (row, column); a 32-lane half wave owns one
+// 32-column group and reduces it with the same xor tree as the GEMM's reduce epilogue.
+__global__ __launch_bounds__(256) void splitk_relu_dot_kernel(const float* kpart, int S, long M, int N, const float* bias, const float* w2,
+                                                              float* partial) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const long row = blockIdx.y;
+    float v = 0.0f;
+    if (col < N) {
+        const float* src = kpart + row * N + col;
+        for (int sl = 0; sl < S; ++sl) v += src[(long)sl * M * N];      // slices in ascending order, always
+        v = fmaxf(v + bias[col], 0.0f) * w2[col];
+    }
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    if ((threadIdx.x & 31) == 0 && col < N) partial[row * (N / 32) + col / 32] = v;
+}
+hipError_t launch_splitk_relu_dot(const float* kpart, int S, long M, int N, const float* bias, const float* w2, float* partial, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    if (S < 1 || (N & 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(splitk_relu_dot_kernel, dim3((N + 255) / 256, (unsigned)M), dim3(256), 0, s, kpart, S, M, N, bias, w2, partial);
+    return hipGetLastError();
+}
+
 hipError_t launch_text_embed(const int64_t* text, const float* tok_emb, const float* pos_emb, float* X, int* eot, int B, int T, int d,
                              int vocab, int* bad_flag, hipStream_t s) {
     if (B <= 0) return hipSuccess;

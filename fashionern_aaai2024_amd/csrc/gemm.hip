@@ -43,6 +43,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
     __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDS_S];
     __shared__ __attribute__((aligned(16))) float Ws[NBUF][BN * LDS_S];
     if (p.gate && *p.gate == 0) return;
+    int kbeg = 0, klen = p.K;
+    if (p.ksplit > 1) {      // split-K slice: raw accumulators to kpart[slice]
+        klen = p.K / p.ksplit;
+        kbeg = blockIdx.y * klen;
+        p.C = p.kpart + (long)blockIdx.y * p.M * p.N; p.ldc = p.N; p.epi = EPI_BIAS; p.bias = nullptr;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -85,7 +91,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
 
     f32x4 a_stage[AJ], w_stage[WJ];
     auto stage_load = [&](int k0) {
-        const int k = k0 + c4 * 4;
+        const int k = kbeg + k0 + c4 * 4;
         long a_off = k;
         if (p.aload == ALOAD_IM2COL) {
             const int pp = p.patch * p.patch;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
         }
     };
 
-    const int nk = p.K / BKT;
+    const int nk = klen / BKT;
     stage_load(0);
     stage_write(0);
     __syncthreads();
@@ -167,7 +173,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
 // 16 consecutive 64-byte tile rows, lane-linear, so the bank-conflict swizzle is applied on the per-lane SOURCE
 // address: the 16-byte chunk c of tile row r is stored at chunk position c ^ ((r >> 2) & 3), and the fragment reads
 // XOR the same value (conflict-free for the 16-lane groups of ds_read_b128).
-template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool CONV = false, int SYNC = 0 /* 0: wait+barrier free to sink below the tail MFMAs (fastest), 1: drain copy first, 2: pinned after all MFMAs */>
+// FILT: the cosine sweep of the fused top-K (EPI_TOPK_FILTER epilogue).  A separate instantiation with a looser register
+// bound (MINW = 2): compiled into the general kernel, the filter epilogue made the 128-VGPR builds spill.
+template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool CONV = false, int SYNC = 0 /* 0: wait+barrier free to sink below the tail MFMAs (fastest), 1: drain copy first, 2: pinned after all MFMAs */,
+          bool FILT = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_glds_kernel(GemmParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
@@ -189,6 +198,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
     constexpr int TILE = ROWS * BKT;
     __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
     if (p.gate && *p.gate == 0) return;
+    int kbeg = 0, klen = p.K;
+    if (p.ksplit > 1) {      // split-K slice: raw accumulators to kpart[slice]
+        klen = p.K / p.ksplit;
+        kbeg = blockIdx.y * klen;
+        p.C = p.kpart + (long)blockIdx.y * p.M * p.N; p.ldc = p.N; p.epi = EPI_BIAS; p.bias = nullptr;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -223,12 +238,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
                 cx[j] = rem - cy[j] * p.conv_w;
                 src[j] = p.A + chunk * 4;
             } else {
-                src[j] = p.A + (long)row * p.lda + chunk * 4;
+                src[j] = p.A + (long)row * p.lda + chunk * 4 + kbeg;
             }
         } else {
             int row = bn * BN + (trow - BM);
             row = row < p.N ? row : p.N - 1;
-            src[j] = p.W + sample_row(row, p.w_sample) * p.ldw + chunk * 4;
+            src[j] = p.W + sample_row(row, p.w_sample) * p.ldw + chunk * 4 + kbeg;
         }
     }
     auto stage = [&](int buf, int k0) {
@@ -287,7 +302,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
     // fragment reads and MFMAs of tile kt; hipcc is left free to sink the wait + barrier below the last fragment read, so a
     // wave still has ~16 register-only MFMAs to issue while it waits at the barrier and for the next tile's first reads
     // (A/B on MI355X: +3..6 % over draining the copy first, +6 % over pinning the barrier after all MFMAs).
-    const int nk = p.K / BKT;
+    const int nk = klen / BKT;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -299,7 +314,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my DMA pieces landed, my fragment reads are done
         __builtin_amdgcn_s_barrier();
     }
-    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
+    if (FILT) filter_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, bm, bn, wm, wn, l31, lh);
+    else gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
 }
 
 // ---- small-M variant on v_mfma_f32_16x16x4_f32 ----------------------------------------------------------------------
@@ -324,6 +340,12 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmParams p) {
     constexpr int TILE = ROWS * BKT;                     // floats per stage
     __shared__ __attribute__((aligned(1024))) float smem[STAGES * TILE];
     if (p.gate && *p.gate == 0) return;
+    int kbeg = 0, klen = p.K;
+    if (p.ksplit > 1) {      // split-K slice: raw accumulators to kpart[slice]
+        klen = p.K / p.ksplit;
+        kbeg = blockIdx.y * klen;
+        p.C = p.kpart + (long)blockIdx.y * p.M * p.N; p.ldc = p.N; p.epi = EPI_BIAS; p.bias = nullptr;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -342,11 +364,11 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmParams p) {
         if (trow < BM) {
             int row = bm * BM + trow;
             row = row < p.M ? row : p.M - 1;
-            src[j] = p.A + (long)row * p.lda + chunk * 4;
+            src[j] = p.A + (long)row * p.lda + chunk * 4 + kbeg;
         } else {
             int row = bn * BN + (trow - BM);
             row = row < p.N ? row : p.N - 1;
-            src[j] = p.W + sample_row(row, p.w_sample) * p.ldw + chunk * 4;
+            src[j] = p.W + sample_row(row, p.w_sample) * p.ldw + chunk * 4 + kbeg;
         }
     }
     auto stage = [&](int buf, int k0) {
@@ -382,7 +404,7 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmParams p) {
         }
     };
 
-    const int nk = p.K / BKT;
+    const int nk = klen / BKT;
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
         if (t < nk) stage(t, t * BKT);
@@ -509,26 +531,38 @@ int gemm_num_col_blocks(int M, int N, int K) {
 
 static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((p.N + kCfgs[c].bn - 1) / kCfgs[c].bn);
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    if (p.epi == EPI_TOPK_FILTER) {      // the filtered sweep: LDS-DMA family, own instantiations
+        if (p.aload != ALOAD_PLAIN) return hipErrorInvalidValue;
+        switch (c) {
+            case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (p.aload == ALOAD_CONV3) {      // 3x3 window loader exists for the LDS-DMA family only
         switch (c) {
-            case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
-            case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
-            case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
-            case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+            case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
     }
     switch (c) {
-        case 0: hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 64, 64, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_f32_kernel<64, 128, 32, 64, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_f32_kernel<128, 64, 64, 32, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, 32, 32, false>), dim3(nb), dim3(256), 0, s, p); break;
-        case 6: hipLaunchKernelGGL((gemm_f32_skinny_kernel<5, 64>), dim3(nb), dim3(256), 0, s, p); break;
-        case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 0: hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 64, 64, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_f32_kernel<64, 128, 32, 64, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_f32_kernel<128, 64, 64, 32, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, 32, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 6: hipLaunchKernelGGL((gemm_f32_skinny_kernel<5, 64>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -553,10 +587,16 @@ struct ShapeKey {
         return aload < o.aload;
     }
 };
-static std::map<ShapeKey, int> g_tuned;
+// What the tuner picks for a shape: one tile configuration for the whole matrix, or -- plain row-independent epilogues only -- a
+// BULK + REMAINDER pair: rows [0, rows_a) in configuration cfg, the rest in cfg_b.  rows_a is the largest row count whose tiles
+// fill whole rounds of the 256 CUs; the ragged last round (e.g. 72 of 2 376 tiles at 12608 x 3072: every CU waits for the
+// 72 that got a tenth tile) is recut into small tiles that spread over all CUs.  Every configuration produces bit-identical
+// results, so the split changes nothing but the time.
+struct Plan { int cfg, rows_a, cfg_b; };
+static std::map<ShapeKey, Plan> g_tuned;
 static std::mutex g_tuned_mu;
 
-// FERN_GEMM_TILES=<file>: pin the per-shape choices (lines "f32 M N K epi aload cfg", as written by gemm_tuner_export /
+// FERN_GEMM_TILES=<file>: pin the per-shape choices (lines "f32 M N K epi aload cfg [rows_a cfg_b]", as written by gemm_tuner_export /
 // fern_tuner_export): listed shapes are never timed again, so a run's kernels -- and its HBM / L2 traffic -- are reproducible
 // from box to box.  Loaded once, before the first tuned launch.
 static void load_pinned_tiles() {
@@ -565,12 +605,16 @@ static void load_pinned_tiles() {
         const char* path = getenv("FERN_GEMM_TILES");
         FILE* f = path ? fopen(path, "r") : nullptr;
         if (!f) return;
-        char kind[16];
-        int M, N, K, epi, aload, cfg;
+        char line[256], kind[16];
         std::lock_guard<std::mutex> lock(g_tuned_mu);
-        while (fscanf(f, "%15s %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &aload, &cfg) == 7)
-            if (!strcmp(kind, "f32") && cfg >= 0 && cfg < kNumCfgs && kCfgs[cfg].bk && K % kCfgs[cfg].bk == 0)
-                g_tuned[ShapeKey{M, N, K, epi, aload}] = cfg;
+        auto ok = [](int cfg, int K) { return cfg >= 0 && cfg < kNumCfgs && kCfgs[cfg].bk && K % kCfgs[cfg].bk == 0; };
+        while (fgets(line, sizeof line, f)) {
+            int M, N, K, epi, aload, cfg, rows_a = 0, cfg_b = 0;
+            const int got = sscanf(line, "%15s %d %d %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &aload, &cfg, &rows_a, &cfg_b);
+            if (got < 7 || strcmp(kind, "f32") || !ok(cfg, K)) continue;
+            if (got < 9 || rows_a <= 0 || rows_a >= M || !ok(cfg_b, K)) { rows_a = 0; cfg_b = cfg; }
+            g_tuned[ShapeKey{M, N, K, epi, aload}] = Plan{cfg, rows_a, cfg_b};
+        }
         fclose(f);
     });
 }
@@ -578,7 +622,8 @@ void gemm_tuner_export(std::string& out) {
     std::lock_guard<std::mutex> lock(g_tuned_mu);
     for (const auto& kv : g_tuned) {
         char line[128];
-        snprintf(line, sizeof line, "f32 %d %d %d %d %d %d\n", kv.first.M, kv.first.N, kv.first.K, kv.first.epi, kv.first.aload, kv.second);
+        snprintf(line, sizeof line, "f32 %d %d %d %d %d %d %d %d\n", kv.first.M, kv.first.N, kv.first.K, kv.first.epi, kv.first.aload, kv.second.cfg,
+                 kv.second.rows_a, kv.second.cfg_b);
         out += line;
     }
 }
@@ -591,8 +636,32 @@ static bool tuning_enabled() {
     return v;
 }
 
-static int tune_shape(const GemmParams& p, hipStream_t s) {
-    const int fallback = choose_cfg(p.M, p.N, p.K);
+static bool split_ok(const GemmParams& p) {      // row-independent epilogue and loader: the rows can be cut anywhere
+    return p.aload == ALOAD_PLAIN && p.w_sample <= 1 && p.ksplit <= 1 &&
+           (p.epi == EPI_BIAS || p.epi == EPI_BIAS_GELU || p.epi == EPI_BIAS_RELU || p.epi == EPI_BIAS_RESIDUAL ||
+            p.epi == EPI_BIAS_RESIDUAL_RELU || p.epi == EPI_COLAFFINE_TANH);
+}
+// the rows [rows_a, M) of a plain-epilogue GEMM as a GEMM of their own
+static GemmParams tail_rows(const GemmParams& p, int rows_a) {
+    GemmParams t = p;
+    t.A = p.A + (long)rows_a * p.lda;
+    t.C = p.C + (long)rows_a * p.ldc;
+    if (p.R) t.R = p.R + (long)rows_a * p.ldc;
+    t.M = p.M - rows_a;
+    return t;
+}
+static hipError_t launch_plan(const Plan& pl, const GemmParams& p, hipStream_t s) {
+    if (pl.rows_a <= 0 || pl.rows_a >= p.M) return launch_cfg(pl.cfg, p, s);
+    GemmParams head = p;
+    head.M = pl.rows_a;
+    hipError_t e = launch_cfg(pl.cfg, head, s);
+    if (e != hipSuccess) return e;
+    return launch_cfg(pl.cfg_b, tail_rows(p, pl.rows_a), s);
+}
+
+static Plan tune_shape(const GemmParams& p, hipStream_t s) {
+    const int fallback_cfg = choose_cfg(p.M, p.N, p.K);
+    const Plan fallback{fallback_cfg, 0, fallback_cfg};
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return fallback;
     long out_rows = p.M;
@@ -604,16 +673,17 @@ static int tune_shape(const GemmParams& p, hipStream_t s) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    GemmParams q = p;
+    GemmParams q = p;      // split-K launches write only to kpart, which is scratch already
     q.gate = nullptr;
     if (reduce) q.partial = scratch;
     else q.C = scratch;       // residual input (p.R) is only read: tuning has no side effects on the caller's buffers
     if (p.epi == EPI_TOPK_FILTER) q.filt.thr_key = nullptr;      // trial launches reject every score: nothing is appended
-    int best = fallback;
+    Plan best = fallback;
     float best_ms = 1e30f;
     static const int cands[] = {0, 1, 2, 3, 6, 8, 9, 10, 11};
     for (int c : cands) {
         if (c == 6 && !skinny_ok(p)) continue;
+        if (c < 8 && p.epi == EPI_TOPK_FILTER) continue;
         if (c >= 8 && p.aload == ALOAD_IM2COL) continue;
         if (c < 8 && p.aload == ALOAD_CONV3) continue;
         if (p.K % kCfgs[c].bk) continue;
@@ -625,7 +695,27 @@ static int tune_shape(const GemmParams& p, hipStream_t s) {
         if (hipEventSynchronize(e1) != hipSuccess) continue;
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best_ms) { best_ms = ms; best = c; }
+        if (ms < best_ms) { best_ms = ms; best = Plan{c, 0, c}; }
+    }
+    // bulk + remainder: only worth a look when the matrix is several rounds of tiles deep
+    if (split_ok(p) && p.M >= 2048 && p.K % 16 == 0) {
+        static const int pairs[][2] = {{8, 11}, {8, 9}, {9, 11}, {10, 11}};
+        for (const auto& pr : pairs) {
+            const int bm = kCfgs[pr[0]].bm, bn = kCfgs[pr[0]].bn;
+            const long nbn = (p.N + bn - 1) / bn, tiles = (long)((p.M + bm - 1) / bm) * nbn;
+            const int rows_a = (int)((tiles / 256) * 256 / nbn) * bm;
+            if (rows_a < bm || rows_a >= p.M) continue;
+            const Plan pl{pr[0], rows_a, pr[1]};
+            if (launch_plan(pl, q, s) != hipSuccess) continue;                // warm
+            (void)hipEventRecord(e0, s);
+            (void)launch_plan(pl, q, s);
+            (void)launch_plan(pl, q, s);
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) continue;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best_ms * 0.99f) { best_ms = ms; best = pl; }             // two launches must earn their keep
+        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -639,6 +729,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.aload == ALOAD_CONV3 && (p.conv_c % 16 || p.K != 9 * p.conv_c || !p.zeros || p.M % (p.conv_h * p.conv_w))) return hipErrorInvalidValue;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return hipErrorInvalidValue;
     if (p.aload == ALOAD_IM2COL && ((p.patch & 3) || (p.img & 3))) return hipErrorInvalidValue;
+    if (p.ksplit > 1 && (p.aload != ALOAD_PLAIN || !p.kpart || p.K % (p.ksplit * 64) || (p.N & 3))) return hipErrorInvalidValue;
     int c = choose_cfg(p.M, p.N, p.K);
     // tuned: problems big enough to matter and small enough that ~30 trial launches are cheap (beyond ~0.2 TFLOP per launch
     // -- the gallery-side GEMMs over tens of thousands of rows -- every candidate fills the chip and the heuristic is used)
@@ -646,15 +737,17 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     const bool tunable = forced_cfg() < 0 && tuning_enabled() && flops >= 2.5e8 && flops <= 2e11;
     if (tunable) {
         load_pinned_tiles();
-        const ShapeKey key{p.M, p.N, p.K, p.epi, p.aload};
+        const ShapeKey key{p.M, p.N, p.K, p.epi, p.aload + 1000 * (p.ksplit > 1 ? p.ksplit : 0)};
         std::lock_guard<std::mutex> lock(g_tuned_mu);
         auto it = g_tuned.find(key);
         if (it == g_tuned.end()) it = g_tuned.emplace(key, tune_shape(p, s)).first;
-        c = it->second;
+        const Plan pl = it->second;
+        if (pl.rows_a > 0 && split_ok(p)) return launch_plan(pl, p, s);
+        c = pl.cfg;
     }
     if (c == 6 && !skinny_ok(p)) c = (p.K & 31) ? best_of(p.M, p.N, 8, 12) : best_of(p.M, p.N, 0, kNumAuto);   // forced but not applicable
     if (c != 6 && forced_cfg() < 0 && !tunable && p.M <= 64 && p.N >= 256 && skinny_ok(p)) c = 6;     // untuned small-M GEMMs
-    if (p.aload == ALOAD_CONV3 && (c < 8 || c > 11)) c = 8 + (c & 3);     // 3x3 window: LDS-DMA family only
+    if ((p.aload == ALOAD_CONV3 || p.epi == EPI_TOPK_FILTER) && (c < 8 || c > 11)) c = 8 + (c & 3);     // 3x3 window / filtered sweep: LDS-DMA family only
     if (c >= 8 && p.aload == ALOAD_IM2COL) c -= 8;                        // patch loader: register-staged family only
     return launch_cfg(c, p, s);
 }

@@ -102,34 +102,38 @@ __device__ __forceinline__ void plain_epilogue(const GemmParams& p, f32x16 (&acc
         }
 }
 
+// The cosine sweep of the fused top-K (rows = queries, columns = gallery rows): no score is stored.  Each 32x32 tile is
+// compared with its 16 queries' bounds (kernels.h: topk_filter_tile); thr_key == null rejects everything (tuner trials).
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void filter_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int bm, int bn, int wm, int wn, int l31, int lh) {
+    if (!p.filt.thr_key) return;
+    const int row_w = bm * BM + wm * WM;
+    const int col_w = bn * BN + wn * WN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int q0 = row_w + i * 32;
+        if (q0 >= p.M) continue;
+        float bound[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            bound[r] = qi < p.M ? filter_bound(p.filt.thr_key[qi]) : __builtin_inff();
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const long n = col_w + j * 32 + l31;
+            topk_filter_tile(acc[i][j], bound, q0, lh, n, n < p.N, p.M, p.filt);
+            __builtin_amdgcn_sched_barrier(0);      // one tile at a time (see plain_epilogue)
+        }
+    }
+}
+
 // Shared epilogue of the fp32 and bf16 GEMM kernels (ALLOW_BF16_OUT: only the bf16 kernel stores bf16 outputs).
 template <int BM, int BN, int WM, int WN, int TM, int TN, int WAVES_N, bool ALLOW_BF16_OUT = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int bm, int bn, int nbn,
                                               int wm, int wn, int l31, int lh, int tid) {
     const int row_w = bm * BM + wm * WM;
     const int col_w = bn * BN + wn * WN;
-    if (!ALLOW_BF16_OUT && p.epi == EPI_TOPK_FILTER) {      // fp32 kernels only (the bf16 gallery has its own sweep kernel)
-        // The cosine sweep of the fused top-K (rows = queries, columns = gallery rows): no score is stored.  Each 32x32 tile
-        // is compared with its 16 queries' bounds (kernels.h: topk_filter_tile); thr_key == null rejects everything (tuner trials).
-        if (!p.filt.thr_key) return;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int q0 = row_w + i * 32;
-            if (q0 >= p.M) continue;
-            float bound[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                bound[r] = qi < p.M ? filter_bound(p.filt.thr_key[qi]) : __builtin_inff();
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const long n = col_w + j * 32 + l31;
-                topk_filter_tile(acc[i][j], bound, q0, lh, n, n < p.N, p.M, p.filt);
-            }
-        }
-        return;
-    }
     if (!epi_is_reduce(p.epi)) {
         if (ALLOW_BF16_OUT && p.scale_a) {      // fp8 operands: scales folded back here; bias / GELU / residual forms
             if (p.out_bf16) {

@@ -72,6 +72,13 @@ struct GemmParams {
     int img, patch, grid;  // ALOAD_IM2COL: image side, patch side, patches per side; EPI_PATCH_EMBED uses grid*grid
     int conv_h, conv_w, conv_c;   // ALOAD_CONV3
     const float* zeros;           // ALOAD_CONV3: >= 64 bytes of zeros (16-byte aligned)
+    // ksplit > 1: the k range is cut into ksplit equal slices (K % (ksplit * 64) == 0), blockIdx.y = slice; every slice stores its
+    // raw accumulators (no bias / activation) to kpart[slice][M][N] and a reduce kernel adds the slices in ascending order and
+    // applies the epilogue (launch_splitk_relu_dot).  The split is a property of the CALL SITE (a function of N and K only,
+    // never of M), so a row's bits do not depend on the batch it travels in; every tile configuration walks a slice in the
+    // same k order, so the tuner stays free.  Plain loader only.
+    int ksplit;
+    float* kpart;
     int w_sample;                 // > 1: W row r is gallery row sample_row(r, w_sample) (the sample pass of the fused top-K sweep)
     TopkFilter filt;              // EPI_TOPK_FILTER
     const int* gate;              // when set: the launch does nothing unless *gate != 0 (retry pass of the fused top-K sweep)
@@ -125,21 +132,29 @@ __device__ __forceinline__ void topk_filter_tile(const f32x16_t& acc, const floa
     if (!__any(hits != 0)) return;
     const long slot = n & (RANK_SLOTS - 1);
     const bool use_ex = f.exclude != nullptr;
-    int pos[16];
+    // eight registers at a time: their appends are issued back to back (one round trip for the returned positions), and the
+    // live state stays small -- with all 16 positions live the 128-VGPR GEMM kernels spilled
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        pos[r] = -1;
-        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if ((hits >> r & 1u) && q < B) {
-            const unsigned long long key = make_key(acc[r], (unsigned)n);
-            if (key >= f.thr_key[q] && !(use_ex && (long)f.exclude[q] - f.exclude_off == n))
-                pos[r] = atomicAdd(&f.count[(long)q * RANK_SLOTS + slot], 1);
+    for (int r0 = 0; r0 < 16; r0 += 8) {
+        if (!__any((hits >> r0) & 0xFFu)) continue;
+        int pos[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u;
+            pos[u] = -1;
+            const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if ((hits >> r & 1u) && q < B) {
+                const unsigned long long key = make_key(acc[r], (unsigned)n);
+                if (key >= f.thr_key[q] && !(use_ex && (long)f.exclude[q] - f.exclude_off == n))
+                    pos[u] = atomicAdd(&f.count[(long)q * RANK_SLOTS + slot], 1);
+            }
         }
-    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (pos[r] >= 0 && pos[r] < f.cap) f.cand[((long)q * RANK_SLOTS + slot) * f.cap + pos[r]] = make_key(acc[r], (unsigned)n);
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u;
+            const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (pos[u] >= 0 && pos[u] < f.cap) f.cand[((long)q * RANK_SLOTS + slot) * f.cap + pos[u]] = make_key(acc[r], (unsigned)n);
+        }
     }
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
@@ -219,6 +234,10 @@ hipError_t launch_attnpool_tokens(const float* x, float* mean, const float* pos,
 // scores[b, j] = q[b] . gallery[idx[b, j]]  (idx < 0 -> -inf)
 hipError_t launch_gather_scores(const float* q, const float* gallery, const int* idx, float* out, int B, int m, int d,
                                 hipStream_t s);
+
+// split-K tail of the CombinerSimple hidden layer: partial[row][g] = sum over the 32 columns of group g of
+// relu(sum_s kpart[s][row][col] + bias[col]) * w2[col]  -- the layout launch_combiner_finalize reads (N % 32 == 0)
+hipError_t launch_splitk_relu_dot(const float* kpart, int S, long M, int N, const float* bias, const float* w2, float* partial, hipStream_t s);
 
 // ---- 8-bit image resampling / tensor conversion (image.hip) -------------------------------------------------------
 hipError_t launch_resample_h(const unsigned char* src, long src_ld, int x0, int y0, int rows, unsigned char* dst, int ow, const int* bounds,
