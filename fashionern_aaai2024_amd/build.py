@@ -21,6 +21,26 @@ HEADERS = ["kernels.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DFERN_BUILD"]
 
 
+RESOURCE_REPORT = os.path.join(CSRC, "build", "resource_usage.txt")
+
+
+def parse_resource_usage(stderr: str) -> dict:
+    """`-Rpass-analysis=kernel-resource-usage` remarks -> {kernel: {field: value}}."""
+    out: dict = {}
+    cur = None
+    for line in stderr.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].split("[-Rpass-analysis", 1)[0].strip()
+        if body.startswith("Function Name:"):
+            cur = body.split(":", 1)[1].strip()
+            out[cur] = {}
+        elif cur is not None and ":" in body:
+            k, v = body.rsplit(":", 1)
+            out[cur][k.strip()] = v.strip()
+    return out
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -43,16 +63,32 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
 
+    usage: dict = {}
+
     def compile_one(src: str) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        usage[src] = parse_resource_usage(r.stderr)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    # Every kernel's registers / scratch / LDS as the compiler reports them.  A kernel that SPILLS is a build error: scratch
+    # traffic inside an MFMA loop (or an epilogue that drags the whole kernel's occupancy down) is a silent 2x, and it has
+    # happened twice -- an epilogue added to a 128-VGPR GEMM, a 16-wave attention kernel -- without any test noticing.
+    with open(RESOURCE_REPORT, "w") as f:
+        for src in SOURCES:
+            for name, u in sorted(usage.get(src, {}).items()):
+                f.write(f"{src} {name} vgpr={u.get('VGPRs', '?')} sgpr={u.get('TotalSGPRs', '?')} scratch={u.get('ScratchSize [bytes/lane]', '?')} "
+                        f"vgpr_spill={u.get('VGPRs Spill', '?')} sgpr_spill={u.get('SGPRs Spill', '?')} lds={u.get('LDS Size [bytes/block]', '?')} "
+                        f"occupancy={u.get('Occupancy [waves/SIMD]', '?')}\n")
+    spilled = [(src, n, u) for src in SOURCES for n, u in usage.get(src, {}).items() if int(u.get("VGPRs Spill", 0)) or int(u.get("ScratchSize [bytes/lane]", 0))]
+    if spilled and not os.environ.get("FERN_ALLOW_SPILLS"):
+        lines = "\n".join(f"  {src}: {n}: {u.get('VGPRs Spill')} VGPRs spilled, {u.get('ScratchSize [bytes/lane]')} B/lane scratch" for src, n, u in spilled)
+        raise RuntimeError("kernels spill registers (restructure them, or set FERN_ALLOW_SPILLS=1 to build anyway):\n" + lines)
     tmp = LIB + ".tmp"
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp], capture_output=True, text=True)
     if r.returncode != 0:
