@@ -15,6 +15,9 @@
 // appends only the survivors (~K*R of N per query) to per-query candidate lists (kernels.h: TopkFilter, topk.hip).
 #include "kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace fern {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -48,13 +51,17 @@ constexpr int QUEUE_BYTES = 4 * QCAP * 12 + 64 * 8;      // 4 waves x (key 8 B +
 // FILTER = false: the sample pass -- tile rows are the gallery rows sample_row(c, R) of S sample columns, scores are stored
 // ([B, ld], 128-byte coalesced).  FILTER = true: the full sweep -- nothing is stored; every finished 32x32 score tile is
 // compared with the per-query bounds held in registers and only survivors are appended to the candidate lists.
-template <int STAGES, bool FILTER>
+// KCH > 0 (D = 64 * KCH known at compile time): the queries' MFMA fragments live in REGISTERS (2 x 4 KCH fragments of 4 VGPRs: 256
+// VGPRs at D = 512 -- the kernel runs one wave per SIMD, so it owns the whole 512-entry file), and the LDS the query image
+// occupied goes to the ring: 9 stages per wave, 128 KiB in flight per CU instead of 64.  HBM latency under this load is ~4 us,
+// and 64 KiB in flight per CU is then 16 GB/s per CU (3.8 TB/s on the chip) by Little's law.  KCH = 0: queries stay in LDS (any D).
+template <int STAGES, bool FILTER, int KCH>
 __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u16* g, float* scores, long ld, int B, long N, int D, long S, int R,
                                                          TopkFilter filt, const int* gate) {
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int q_stride = D * 2 + 16;                               // bytes; +16 spreads rows over the banks
-    unsigned char* ring_base = smem + ((64 * q_stride + 1023) & ~1023);
+    unsigned char* ring_base = KCH > 0 ? smem : smem + ((64 * q_stride + 1023) & ~1023);      // KCH > 0: the ring overlays the query image
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,6 +80,17 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
         *reinterpret_cast<bf16x8*>(smem + row * q_stride + c8 * 2) = v;
     }
     __syncthreads();
+    constexpr int NFR = KCH > 0 ? 8 * KCH : 1;
+    bf16x8 afr[NFR];
+    if (KCH > 0) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int kidx = 0; kidx < 4 * KCH; ++kidx)
+                afr[tm * 4 * KCH + kidx] = *reinterpret_cast<const bf16x8*>(smem + (tm * 32 + l31) * q_stride + (kidx * 16 + lh * 8) * 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                           // every wave holds its fragments: the image may be overwritten
+    }
 
     // per-query bounds of the filter, laid out like the accumulator registers (query = tm*32 + (r&3) + 8(r>>2) + 4 lh)
     float bound[2][16];
@@ -154,7 +172,7 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
             const u16* src = g + n * D + kc * KSTAGE + chunk * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 2);      // aux 2 = nt: every gallery byte is read once
         }
     };
 
@@ -166,7 +184,8 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
 
     for (long s = 0; s < STAGES - 1 && s < nstages; ++s) issue(s);
     const int sw = (l31 >> 1) & 7;
-    for (long s = 0; s < nstages; ++s) {
+    // one ring stage: refill the slot that was just read, wait for stage s (the newer ones stay in flight), 4 k-steps of MFMAs
+    auto stage_step = [&](long s, int kc) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot about to be refilled has been read
         if (s + STAGES - 1 < nstages) {
             issue(s + STAGES - 1);
@@ -175,37 +194,50 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         const unsigned char* st = ring + (int)(s % STAGES) * STAGE_BYTES;
-        const int kc = (int)(s % kchunks);
 #pragma unroll
         for (int ks = 0; ks < KSTAGE / 16; ++ks) {
             const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(st + l31 * 128 + (((2 * ks + lh) ^ sw) * 16));
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
-                const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(smem + (tm * 32 + l31) * q_stride + (kc * KSTAGE + ks * 16 + lh * 8) * 2);
+                bf16x8 afrag;
+                if (KCH > 0) afrag = afr[KCH > 0 ? tm * 4 * KCH + kc * 4 + ks : 0];      // kc is a compile-time constant on this path
+                else afrag = *reinterpret_cast<const bf16x8*>(smem + (tm * 32 + l31) * q_stride + (kc * KSTAGE + ks * 16 + lh * 8) * 2);
                 acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[tm], 0, 0, 0);
             }
         }
-        if (kc == kchunks - 1) {                                     // tile finished
-            const long t = gw + (s / kchunks) * GW;
-            const long n = t * ROWS_T + l31;
-            if (FILTER) {
+    };
+    auto tile_done = [&](long t) {
+        const long n = t * ROWS_T + l31;
+        if (FILTER) {
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    filter_tile(acc[tm], bound[tm], tm, n, n < N);
+            for (int tm = 0; tm < 2; ++tm) {
+                filter_tile(acc[tm], bound[tm], tm, n, n < N);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tm][r] = 0.0f;
-                }
-            } else {                                                 // sample pass: 128-byte coalesced score stores
-                const long grow = sample_row(n < S ? n : S - 1, R);
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int qi = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (qi < B && n < S) scores[(long)qi * ld + n] = grow < N ? acc[tm][r] : -__builtin_inff();
-                        acc[tm][r] = 0.0f;
-                    }
+                for (int r = 0; r < 16; ++r) acc[tm][r] = 0.0f;
             }
+        } else {                                                 // sample pass: 128-byte coalesced score stores
+            const long grow = sample_row(n < S ? n : S - 1, R);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qi = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (qi < B && n < S) scores[(long)qi * ld + n] = grow < N ? acc[tm][r] : -__builtin_inff();
+                    acc[tm][r] = 0.0f;
+                }
+        }
+    };
+    if (KCH > 0) {
+        for (long ti = 0; ti < my_tiles; ++ti) {
+#pragma unroll
+            for (int kc = 0; kc < (KCH > 0 ? KCH : 1); ++kc) stage_step(ti * KCH + kc, kc);
+            tile_done(gw + ti * GW);
+        }
+    } else {
+        for (long s = 0; s < nstages; ++s) {
+            const int kc = (int)(s % kchunks);
+            stage_step(s, kc);
+            if (kc == kchunks - 1) tile_done(gw + (s / kchunks) * GW);
         }
     }
     if (FILTER) flush();
@@ -218,12 +250,14 @@ hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStre
     return hipGetLastError();
 }
 
-template <int STAGES, bool FILTER>
+template <int STAGES, bool FILTER, int KCH>
 static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
                                     const TopkFilter& filt, const int* gate, hipStream_t s) {
-    const size_t lds = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024 + (size_t)4 * STAGES * STAGE_BYTES + QUEUE_BYTES;
+    const size_t qbytes = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024;
+    const size_t ringq = (size_t)4 * STAGES * STAGE_BYTES + QUEUE_BYTES;
+    const size_t lds = KCH > 0 ? std::max(qbytes, ringq) : qbytes + ringq;
     static size_t attr_set = 0;
-    auto kern = sweep_bf16_kernel<STAGES, FILTER>;
+    auto kern = sweep_bf16_kernel<STAGES, FILTER, KCH>;
     if (lds > attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -239,12 +273,22 @@ static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, flo
 template <bool FILTER>
 static hipError_t launch_sweep_mode(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
                                     const TopkFilter& filt, const int* gate, hipStream_t s) {
+    static const bool regq = [] { const char* e = getenv("FERN_SWEEP_REGQ"); return !(e && e[0] == '0'); }();      // A/B switch
+    if (regq) {      // register-resident queries, 9-stage ring
+        switch (D) {
+            case 64: return launch_sweep_inst<9, FILTER, 1>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+            case 128: return launch_sweep_inst<9, FILTER, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+            case 256: return launch_sweep_inst<9, FILTER, 4>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+            case 512: return launch_sweep_inst<9, FILTER, 8>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+            default: break;
+        }
+    }
     const size_t qbytes = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024;
     const size_t room = (size_t)160 * 1024 - qbytes - QUEUE_BYTES;
     const int stages = (int)(room / (4 * STAGE_BYTES));
-    if (stages >= 5) return launch_sweep_inst<5, FILTER>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
-    if (stages >= 4) return launch_sweep_inst<4, FILTER>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
-    if (stages >= 3) return launch_sweep_inst<3, FILTER>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+    if (stages >= 5) return launch_sweep_inst<5, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+    if (stages >= 4) return launch_sweep_inst<4, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+    if (stages >= 3) return launch_sweep_inst<3, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
     return hipErrorInvalidValue;
 }
 
