@@ -517,12 +517,14 @@ def main():
                            "shard_rows": per, "collective": "all_gather_into_tensor of the fused [rows/rank, D] blocks"},
             "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": gemm_peak, "unit": "TFLOP/s",
                          "frac": gemm_tflops / gemm_peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_launch": st["gemm_alg_bytes"] / max(1, st["gemm_launches"]) if precision == "fp32" else alg_bytes,
                          "kernel": {"fp32": "gemm_f32_glds_kernel / gemm_f32_kernel (fp32 MFMA GEMM, all tile variants)",
                                     "bf16": "gemm_bf16_glds_kernel (bf16 MFMA GEMM of the encoder blocks)",
                                     "fp8": "gemm_bf16_glds_kernel<FP8> (fp8 MFMA GEMM of the encoder blocks)"}[precision],
                          "gemm_ms_per_step": st[gkey + "_ms"] / prof_steps, "gemm_gflop_per_step": st[gkey + "_flops"] / prof_steps / 1e9,
                          "gemm_launches_per_step": st[gkey + "_launches"] / prof_steps,
+                         "gemm_dispatches_per_step": (st["gemm_dispatches"] / prof_steps) if precision == "fp32" else None,
+                         "gemm_us_per_dispatch": (st["gemm_ms"] * 1e3 / max(1, st["gemm_dispatches"])) if precision == "fp32" else None,
                          "f32_gemm_ms_per_step": st["gemm_ms"] / prof_steps},
             "roofline_sim_sweep": rank_roof,
             "roofline_sim_sweep_bf16_1M": big_roof,

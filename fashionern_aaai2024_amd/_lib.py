@@ -23,7 +23,8 @@ class ProfStats(C.Structure):
                 ("topk_ms", C.c_double), ("topk_launches", c_i64),
                 ("sweep_ms", C.c_double), ("sweep_bytes", C.c_double), ("sweep_launches", c_i64),
                 ("gemm_fp8_ms", C.c_double), ("gemm_fp8_flops", C.c_double), ("gemm_fp8_launches", c_i64),
-                ("gemm_bf16_ms", C.c_double), ("gemm_bf16_flops", C.c_double), ("gemm_bf16_launches", c_i64)]
+                ("gemm_bf16_ms", C.c_double), ("gemm_bf16_flops", C.c_double), ("gemm_bf16_launches", c_i64),
+                ("gemm_alg_bytes", C.c_double), ("gemm_dispatches", c_i64)]
 
 
 # name -> (restype, argtypes); must list every symbol include/fern.h declares (tests check this)

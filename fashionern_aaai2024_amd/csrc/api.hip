@@ -100,7 +100,7 @@ struct ClipW {
 };
 
 enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_TOPK = 2, PROF_SWEEP = 3 };
-struct ProfRec { hipEvent_t a, b; int kind; double work; int m, n, k, tag; };
+struct ProfRec { hipEvent_t a, b; int kind; double work; int m, n, k, tag; int dispatches; };
 
 struct fern_ctx {
     int device = 0;
@@ -178,7 +178,7 @@ static int prof_open(fern_ctx* c, int kind, double work, hipStream_t s, int* slo
         else HIP_TRY(hipEventCreate(&ev[i]));
     }
     HIP_TRY(hipEventRecord(ev[0], s));
-    c->recs.push_back({ev[0], ev[1], kind, work, m, n, k, tag});
+    c->recs.push_back({ev[0], ev[1], kind, work, m, n, k, tag, 1});
     *slot = (int)c->recs.size() - 1;
     return FERN_OK;
 }
@@ -192,6 +192,7 @@ static int run_gemm(fern_ctx* c, const GemmParams& p, hipStream_t s, int kind = 
     int slot;
     FERN_TRY(prof_open(c, kind, work >= 0 ? work : 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, p.epi));
     HIP_TRY(launch_gemm(p, s));
+    if (slot >= 0) c->recs[slot].dispatches = gemm_last_dispatches();
     return prof_close(c, slot, s);
 }
 static GemmParams gemm_desc(const float* A, long lda, const LinearW& L, float* C, long ldc, int M, int epi) {
@@ -1657,7 +1658,9 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
             case PROF_GEMM:
                 if (r.tag >= 200) { out->gemm_fp8_ms += ms; out->gemm_fp8_flops += r.work; out->gemm_fp8_launches++; }
                 else if (r.tag >= 100) { out->gemm_bf16_ms += ms; out->gemm_bf16_flops += r.work; out->gemm_bf16_launches++; }
-                else { out->gemm_ms += ms; out->gemm_flops += r.work; out->gemm_launches++; }
+                else { out->gemm_ms += ms; out->gemm_flops += r.work; out->gemm_launches++;
+                       out->gemm_alg_bytes += 4.0 * ((double)r.m * r.k + (double)r.n * r.k + (double)r.m * r.n);
+                       out->gemm_dispatches += r.dispatches; }
                 break;
             case PROF_ATTN: out->attn_ms += ms; out->attn_flops += r.work; out->attn_launches++; break;
             case PROF_TOPK: out->topk_ms += ms; out->topk_launches++; break;

@@ -650,8 +650,12 @@ static GemmParams tail_rows(const GemmParams& p, int rows_a) {
     t.M = p.M - rows_a;
     return t;
 }
+static thread_local int g_last_dispatches = 1;
+int gemm_last_dispatches() { return g_last_dispatches; }
+
 static hipError_t launch_plan(const Plan& pl, const GemmParams& p, hipStream_t s) {
     if (pl.rows_a <= 0 || pl.rows_a >= p.M) return launch_cfg(pl.cfg, p, s);
+    g_last_dispatches = 2;
     GemmParams head = p;
     head.M = pl.rows_a;
     hipError_t e = launch_cfg(pl.cfg, head, s);
@@ -724,6 +728,7 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s) {
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
+    g_last_dispatches = 1;
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (p.K <= 0 || (p.K % 16) != 0 || (p.ldw & 3) || (p.aload == ALOAD_PLAIN && (p.lda & 3))) return hipErrorInvalidValue;
     if (p.aload == ALOAD_CONV3 && (p.conv_c % 16 || p.K != 9 * p.conv_c || !p.zeros || p.M % (p.conv_h * p.conv_w))) return hipErrorInvalidValue;

@@ -95,6 +95,7 @@ struct GemmParams {
 // Number of column blocks the reduce epilogues write per row (depends on the tile chosen for this shape).
 int gemm_num_col_blocks(int M, int N, int K);
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+int gemm_last_dispatches();      // kernel dispatches of the calling thread's last launch_gemm (2 for a bulk + remainder plan)
 // bf16 x bf16 -> fp32-accumulate GEMM (v_mfma_f32_32x32x16_bf16); plain epilogues only, K % 32 == 0, ALOAD_PLAIN
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s);
 // the per-shape tile choices made so far, one text line per shape (the format FERN_GEMM_TILES=<file> reads back)

@@ -121,10 +121,10 @@ typedef struct {
     double attn_ms;
     double attn_flops;
     int64_t attn_launches;
-    double topk_ms;        /* top-K selection kernels */
+    double topk_ms;        /* the rest of the ranking stage: sample pass, bound, candidate selection, gated retry pair */
     int64_t topk_launches;
-    double sweep_ms;       /* similarity sweep (scores GEMM inside fern_sim_topk) */
-    double sweep_bytes;    /* algorithmic bytes of those sweeps: N*D*4 + B*D*4 + B*N*4 */
+    double sweep_ms;       /* the filtered similarity sweep inside fern_sim_topk / fern_sim_topk_bf16 */
+    double sweep_bytes;    /* algorithmic bytes of those sweeps: N*D*s_g + B*D*4 + B*K*8 */
     int64_t sweep_launches;
     double gemm_fp8_ms;    /* fp8-operand GEMM launches (FERN_PREC_FP8, fern_gemm_fp8): not included in gemm_* / gemm_bf16_* */
     double gemm_fp8_flops;
@@ -132,6 +132,8 @@ typedef struct {
     double gemm_bf16_ms;   /* bf16-operand GEMM launches (FERN_PREC_BF16 encoder blocks, fern_gemm_bf16): NOT included in gemm_* */
     double gemm_bf16_flops;
     int64_t gemm_bf16_launches;
+    double gemm_alg_bytes; /* algorithmic bytes of the fp32 GEMM launches counted in gemm_*: 4 (M K + N K + M N) each */
+    int64_t gemm_dispatches; /* kernel dispatches behind gemm_launches (a bulk + remainder plan is two dispatches per launch) */
 } fern_prof_stats;
 
 FERN_API int fern_abi_version(void);

@@ -1,15 +1,17 @@
 #!/usr/bin/env python
 """Turn two `rocprofv3 --pmc` passes of `bench.py --pmc-mode` (one with FETCH_SIZE, one with WRITE_SIZE) into
-profiles/pmc_traffic.json: HBM bytes per launch for the GEMM family and for the similarity sweep.
+profiles/pmc_traffic.json: HBM-side bytes per launch for the fp32 GEMM family and per call for the ranking stage
+(sample GEMM + bound + filtered sweep + candidate select + the gated retry pair).
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE reports exactly 1/2 of
 the bytes of a wide coalesced streaming read (TCC_EA0_RDREQ x 64 B with 128-B requests tallied at 64 B) -> doubled;
-WRITE_SIZE is exact for 16-B-per-lane streaming stores (our epilogue stores 4 B per lane: uncalibrated, reported as is).
+WRITE_SIZE is exact for 16-B-per-lane streaming stores (the GEMM epilogues store 4 B per lane: uncalibrated, reported as is).
 
 Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> [out.json]
 """
 import csv
 import json
+import re
 import sys
 
 
@@ -23,31 +25,56 @@ def per_dispatch(path, counter):
     return rows[marker + 1:]
 
 
+def is_filter_gemm(name):      # gemm_f32_glds_kernel<BM, BN, WM, WN, BKT, MINW, CONV, SYNC, FILT = true>
+    return "gemm_f32_glds_kernel" in name and re.search(r",\s*true>", name) is not None
+
+
 def summarise(rows, scale):
-    gemm = [r for r in rows if "gemm_f32" in r[1]]
-    sweep = [rows[i - 1] for i, r in enumerate(rows) if "topk_rows_kernel" in r[1] and i > 0 and "gemm_f32" in rows[i - 1][1]]
-    sweep_ids = {r[0] for r in sweep}
-    gemm = [r for r in gemm if r[0] not in sweep_ids]
+    rank_ids, sweep_ids = set(), set()
+    for i, r in enumerate(rows):
+        if "topk_sample_bound_kernel" in r[1]:
+            rank_ids.add(r[0])
+            if i > 0 and "gemm_f32" in rows[i - 1][1]:
+                rank_ids.add(rows[i - 1][0])                      # the sample pass: the GEMM right before the bound kernel
+            seen = 0
+            for nxt in rows[i + 1:i + 6]:                          # filtered sweep, select, gated sweep, gated select
+                if is_filter_gemm(nxt[1]) or "topk_candidates_kernel" in nxt[1]:
+                    rank_ids.add(nxt[0])
+                    if is_filter_gemm(nxt[1]) and seen == 0:
+                        sweep_ids.add(nxt[0])
+                        seen = 1
+    gemm = [r for r in rows if "gemm_f32" in r[1] and r[0] not in rank_ids]
+    rank = [r for r in rows if r[0] in rank_ids]
+    sweep = [r for r in rows if r[0] in sweep_ids]
     tot = lambda rs: sum(r[4] for r in rs) * 1024 * scale  # noqa: E731
-    return {"gemm_launches": len(gemm), "gemm_bytes": tot(gemm), "sweep_launches": len(sweep), "sweep_bytes": tot(sweep)}
+    return {"gemm_launches": len(gemm), "gemm_bytes": tot(gemm), "rank_calls": len(sweep), "rank_bytes": tot(rank), "sweep_bytes": tot(sweep)}
 
 
 def main():
     fetch = summarise(per_dispatch(sys.argv[1], "FETCH_SIZE"), 2.0)
     write = summarise(per_dispatch(sys.argv[2], "WRITE_SIZE"), 1.0)
     steps = int(sys.argv[3])
+    calls = max(1, fetch["rank_calls"])
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --pmc-mode`; FETCH_SIZE x2 (gfx950), KiB -> B",
         "steps": steps,
         "gemm": {"launches_per_step": fetch["gemm_launches"] / steps,
                  "fetch_bytes_per_launch": fetch["gemm_bytes"] / max(1, fetch["gemm_launches"]),
                  "write_bytes_per_launch": write["gemm_bytes"] / max(1, write["gemm_launches"])},
-        "sweep": {"launches_per_step": fetch["sweep_launches"] / steps,
-                  "fetch_bytes_per_launch": fetch["sweep_bytes"] / max(1, fetch["sweep_launches"]),
-                  "write_bytes_per_launch": write["sweep_bytes"] / max(1, write["sweep_launches"])},
+        "sweep": {"calls_per_step": fetch["rank_calls"] / steps,
+                  "stage_fetch_bytes_per_call": fetch["rank_bytes"] / calls,
+                  "stage_write_bytes_per_call": write["rank_bytes"] / max(1, write["rank_calls"]),
+                  "sweep_kernel_fetch_bytes": fetch["sweep_bytes"] / calls,
+                  "sweep_kernel_write_bytes": write["sweep_bytes"] / max(1, write["rank_calls"]),
+                  "note": "stage = sample GEMM + bound + filtered sweep + candidate select + gated retry pair of one fern_sim_topk call; the "
+                          "[B, N] score matrix (B*N*4 bytes) is never written: the stage's writes are the sample scores, the surviving "
+                          "candidates and the [B, K] result"},
+        "note": "FETCH_SIZE counts L2->fabric read requests (Infinity-Cache hits included), i.e. the sum over the 8 private XCD L2s: every XCD "
+                "streams the weight panels of its tiles once per generation of resident tiles, so for the GEMM family this is L2-miss traffic "
+                "(largely served by the 256 MiB Infinity Cache), not DRAM traffic.",
     }
-    for k in ("gemm", "sweep"):
-        out[k]["hbm_bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
+    out["gemm"]["hbm_bytes_per_launch"] = out["gemm"]["fetch_bytes_per_launch"] + out["gemm"]["write_bytes_per_launch"]
+    out["sweep"]["hbm_bytes_per_launch"] = out["sweep"]["stage_fetch_bytes_per_call"] + out["sweep"]["stage_write_bytes_per_call"]
     print(json.dumps(out, indent=1))
     if len(sys.argv) > 4:
         json.dump(out, open(sys.argv[4], "w"), indent=1)
