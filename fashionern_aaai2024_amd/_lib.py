@@ -68,6 +68,9 @@ SIGNATURES = {
     "fern_quantize_rows_fp8": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),
     "fern_gemm_fp8": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
                               c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fern_quantize_mx8": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p]),
+    "fern_gemm_mx8": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
+                              c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fern_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_void_p]),
     "fern_attention": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),

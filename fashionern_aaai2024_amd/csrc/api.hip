@@ -219,7 +219,7 @@ static GemmParams gemm_desc_f8(const unsigned char* A8, const float* sa, long ld
 }
 static int run_gemm_b(fern_ctx* c, const GemmParams& p, hipStream_t s) {
     int slot;
-    FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, (p.fp8 ? 200 : 100) + p.epi));
+    FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, (p.fp8 == 2 ? 300 : p.fp8 ? 200 : 100) + p.epi));
     HIP_TRY(launch_gemm_bf16(p, s));
     return prof_close(c, slot, s);
 }
@@ -1590,6 +1590,36 @@ extern "C" int fern_gemm_fp8(fern_ctx* c, const uint8_t* A, int64_t lda, const f
     p.Ab = reinterpret_cast<const unsigned short*>(A); p.lda = lda; p.Wb = reinterpret_cast<const unsigned short*>(W); p.ldw = ldw;
     p.bias = bias; p.R = residual; p.C = reinterpret_cast<float*>(C); p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epilogue;
     p.aload = ALOAD_PLAIN; p.out_bf16 = out_bf16 ? 1 : 0; p.fp8 = 1; p.scale_a = scale_a; p.scale_w = scale_w;
+    return run_gemm_b(c, p, (hipStream_t)stream);
+}
+
+extern "C" int fern_quantize_mx8(fern_ctx* c, const void* x, int x_is_bf16, int64_t ldx, uint8_t* y, int64_t ldy, uint8_t* scales,
+                                 int64_t scale_rows, int64_t rows, int d, void* stream) {
+    if (!c || rows < 0 || (rows && (!x || !y || !scales))) return fail(FERN_ERR_ARG, "fern_quantize_mx8: bad argument");
+    if (d <= 0 || d % 128 || d > 4096 || ldx % 8 || ldy % 8 || scale_rows < rows)
+        return fail(FERN_ERR_ARG, "fern_quantize_mx8: need d % 128 == 0, d <= 4096, ld % 8 == 0, scale_rows >= rows");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_quantize_mx8(x_is_bf16 ? static_cast<const unsigned short*>(x) : nullptr, x_is_bf16 ? nullptr : static_cast<const float*>(x), ldx,
+                                y, ldy, scales, scale_rows, rows, d, (hipStream_t)stream));
+    return FERN_OK;
+}
+
+extern "C" int fern_gemm_mx8(fern_ctx* c, const uint8_t* A, int64_t lda, const uint8_t* scales_a, int64_t scale_rows_a, const uint8_t* W,
+                             int64_t ldw, const uint8_t* scales_w, int64_t scale_rows_w, const float* bias, const float* residual, void* C,
+                             int64_t ldc, int M, int N, int K, int epilogue, int out_bf16, void* stream) {
+    if (!c || M < 0 || N < 0 || K <= 0) return fail(FERN_ERR_ARG, "fern_gemm_mx8: bad argument");
+    if (M == 0 || N == 0) return FERN_OK;
+    if (!A || !W || !C || !scales_a || !scales_w) return fail(FERN_ERR_ARG, "fern_gemm_mx8: NULL argument");
+    if (epilogue != FERN_EPI_BIAS && epilogue != FERN_EPI_BIAS_GELU && epilogue != FERN_EPI_BIAS_RESIDUAL)
+        return fail(FERN_ERR_ARG, "fern_gemm_mx8: epilogue must be BIAS, BIAS_GELU or BIAS_RESIDUAL");
+    if (epilogue == FERN_EPI_BIAS_RESIDUAL && (!residual || out_bf16)) return fail(FERN_ERR_ARG, "fern_gemm_mx8: the residual epilogue needs a residual and fp32 output");
+    if (K % 128 || lda % 16 || ldw % 16 || scale_rows_a < M || scale_rows_w < N)
+        return fail(FERN_ERR_ARG, "fern_gemm_mx8: K % 128, lda % 16 and ldw % 16 must be 0, scale_rows >= rows");
+    HIP_TRY(hipSetDevice(c->device));
+    GemmParams p{};
+    p.Ab = reinterpret_cast<const unsigned short*>(A); p.lda = lda; p.Wb = reinterpret_cast<const unsigned short*>(W); p.ldw = ldw;
+    p.bias = bias; p.R = residual; p.C = reinterpret_cast<float*>(C); p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epilogue;
+    p.aload = ALOAD_PLAIN; p.out_bf16 = out_bf16 ? 1 : 0; p.fp8 = 2; p.mxa = scales_a; p.mxa_rows = scale_rows_a; p.mxw = scales_w; p.mxw_rows = scale_rows_w;
     return run_gemm_b(c, p, (hipStream_t)stream);
 }
 

@@ -190,6 +190,82 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const unsigned s
     }
 }
 
+// ---- MX (block-scaled) e4m3fn quantisers: one E8M0 byte per 32 consecutive k, the operand form of
+// v_mfma_scale_f32_32x32x64_f8f6f4 (gemm_bf16.hip: gemm_mx8_kernel).  e = the smallest power of two that brings the block's
+// maximum to <= 448, read off the maximum's exponent / mantissa bits (448 = 1.75 * 2^8); the scaling x * 2^(127-e) is exact.
+__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
+    const unsigned u = __float_as_uint(amax);
+    const int e = (int)(u >> 23) - 8 + ((u & 0x7FFFFFu) > 0x600000u ? 1 : 0);
+    return (unsigned)min(max(e, 1), 253);
+}
+__device__ __forceinline__ float mx_inv_scale(unsigned e) { return __uint_as_float((254u - e) << 23); }
+
+// LayerNorm fused with the MX quantiser (a lane holds 4 consecutive elements: a 32-block is 8 lanes)
+__global__ __launch_bounds__(256) void layernorm_mx8_kernel(const float* x, const float* gamma, const float* beta, unsigned char* y,
+                                                            unsigned char* scales, long srows, long rows, int d, long ldx, long ldy, float eps) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    RowRegs r;
+    row_load(r, x + row * ldx, d, lane);
+    row_layernorm(r, gamma, beta, d, lane, eps);
+    unsigned char* yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        float am = fmaxf(fmaxf(fabsf(r.v[i][0]), fabsf(r.v[i][1])), fmaxf(fabsf(r.v[i][2]), fabsf(r.v[i][3])));
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
+        if (c < d) {
+            const unsigned e = mx_scale_byte(am);
+            const float inv = mx_inv_scale(e);
+            *reinterpret_cast<unsigned*>(yr + c) = pack4_fp8(r.v[i][0] * inv, r.v[i][1] * inv, r.v[i][2] * inv, r.v[i][3] * inv);
+            if ((lane & 7) == 0) scales[mx_scale_offset(row, c >> 5, srows)] = (unsigned char)e;
+        }
+    }
+}
+
+// bf16 or fp32 rows up to 4096 wide (a lane holds 8 consecutive elements: a 32-block is 4 lanes)
+__global__ __launch_bounds__(256) void quantize_mx8_kernel(const unsigned short* xb, const float* xf, long ldx, unsigned char* y, long ldy,
+                                                           unsigned char* scales, long srows, long rows, int d) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (c < d) {
+            if (xb) {
+                const uint4 t = *reinterpret_cast<const uint4*>(xb + row * ldx + c);
+                const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xf + row * ldx + c), b = *reinterpret_cast<const f32x4*>(xf + row * ldx + c + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+            }
+        }
+        float am = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(v[e]));
+        am = fmaxf(am, __shfl_xor(am, 1));
+        am = fmaxf(am, __shfl_xor(am, 2));
+        if (c < d) {
+            const unsigned e8 = mx_scale_byte(am);
+            const float inv = mx_inv_scale(e8);
+            uint2 o;
+            o.x = pack4_fp8(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+            o.y = pack4_fp8(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv);
+            *reinterpret_cast<uint2*>(y + row * ldy + c) = o;
+            if ((lane & 3) == 0) scales[mx_scale_offset(row, c >> 5, srows)] = (unsigned char)e8;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* x, const float* x2, long ldx, float* y, long ldy, long rows, int d,
                                                      float eps, int mode) {
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -508,6 +584,20 @@ hipError_t launch_layernorm_fp8(const float* x, const float* gamma, const float*
     if (rows <= 0) return hipSuccess;
     if (bad_width(d) || (ldx & 3) || (ldy & 3)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(layernorm_fp8_kernel, row_grid(rows), dim3(256), 0, s, x, gamma, beta, y, scale, rows, d, ldx, ldy, eps);
+    return hipGetLastError();
+}
+hipError_t launch_layernorm_mx8(const float* x, const float* gamma, const float* beta, unsigned char* y, unsigned char* scales, long srows,
+                                long rows, int d, long ldx, long ldy, float eps, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (d <= 0 || d % 128 || d > 256 * MAXV || (ldx & 3) || (ldy & 3) || srows < rows) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_mx8_kernel, row_grid(rows), dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps);
+    return hipGetLastError();
+}
+hipError_t launch_quantize_mx8(const unsigned short* x_bf16, const float* x_f32, long ldx, unsigned char* y, long ldy, unsigned char* scales,
+                               long srows, long rows, int d, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (d <= 0 || d % 128 || d > 4096 || (ldx & 7) || (ldy & 7) || srows < rows || (x_bf16 == nullptr) == (x_f32 == nullptr)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quantize_mx8_kernel, row_grid(rows), dim3(256), 0, s, x_bf16, x_f32, ldx, y, ldy, scales, srows, rows, d);
     return hipGetLastError();
 }
 hipError_t launch_quantize_rows_fp8(const unsigned short* x_bf16, const float* x_f32, long ldx, unsigned char* y, long ldy, float* scale,

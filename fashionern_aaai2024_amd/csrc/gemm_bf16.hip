@@ -160,6 +160,165 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
     gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N, true>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
 }
 
+// ---- MX (block-scaled) fp8: v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands --------------------------------------------
+// One instruction is a 32x32 tile over 64 k: lane (r = lane & 31, h = lane >> 5) supplies 32 bytes of its row of A (8 VGPRs) and of
+// W -- bytes 0-15 are k = 16h .. 16h+15, bytes 16-31 are k = 32 + 16h .. +15 -- plus ONE E8M0 scale byte per operand: the byte of
+// the h = 0 lane scales k = 0..31 of that row (bytes 0-15 of BOTH halves), the h = 1 lane's byte k = 32..63
+// (tools/probe/mfma_scale_probe2.hip maps byte -> k and byte -> scale on hardware; mfma_scale_probe.hip the opsel byte select).
+// It issues in twice the cycles of the 32x32x16 bf16 form at 4x the k: twice the bf16 / plain-fp8 rate.
+//
+// Tiles: 128-byte rows (128 k = two MFMA k steps), the LDS-DMA staging and chunk swizzle of the kernel above; a lane's 32 bytes are
+// two swizzled 16-byte chunks.  Scales travel with the tile: the mx_scale_offset layout holds one dword per (128-k tile, row) =
+// bytes (step 0, h 0), (step 0, h 1), (step 1, h 0), (step 1, h 1), so a tile's scales are (BM + BN) consecutive dwords per operand
+// block, staged by 4-byte LDS-DMA pieces of 64 rows behind the tile's data.  A lane reads its row's dword, shifts it right by 8h
+// and opsel (0 / 2) picks the step's byte; its data are the two swizzled 16-byte chunks h and 2 + h of the step.  Every configuration adds the 64-wide k steps in ascending order.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WM, int WN, int STAGES, int MINW>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_kernel(GemmParams p) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int WAVES_M = BM / WM;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int ROWS = BM + BN;
+    constexpr int RB = 128;                              // bytes (= k) per tile row
+    constexpr int RPP = 8;                               // tile rows per 1 KiB piece
+    constexpr int PIECES = ROWS / RPP;
+    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+    constexpr int PPW = PIECES / NW;
+    constexpr int SP = ROWS / 64;                        // 256-byte scale pieces (64 rows x 1 dword)
+    constexpr int SPW = (SP + NW - 1) / NW;              // per wave (the surplus re-stages a piece: same bytes, same place)
+    constexpr int DATA = ROWS * RB;
+    constexpr int TILE = (DATA + ROWS * 4 + 1023) / 1024 * 1024;   // bytes per stage: rows, then one scale dword per row
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+
+    __shared__ __attribute__((aligned(1024))) char smem[STAGES * TILE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nwg = nbm * nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int bm = swz / nbn, bn = swz % nbn;
+
+    const char* src[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave + NW * j;
+        const int trow = piece * RPP + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((trow >> 1) & 7);
+        if (trow < BM) {
+            int row = bm * BM + trow;
+            row = row < p.M ? row : p.M - 1;
+            src[j] = reinterpret_cast<const char*>(p.Ab) + (long)row * p.lda + chunk * 16;
+        } else {
+            int row = bn * BN + (trow - BM);
+            row = row < p.N ? row : p.N - 1;
+            src[j] = reinterpret_cast<const char*>(p.Wb) + (long)row * p.ldw + chunk * 16;
+        }
+    }
+    const char* ssrc[SPW];
+    long sstep[SPW];                                      // bytes between consecutive k tiles of that operand's scales
+#pragma unroll
+    for (int j = 0; j < SPW; ++j) {
+        const int sp = (wave + NW * j) % SP;
+        const int trow = sp * 64 + lane;
+        if (trow < BM) {
+            int row = bm * BM + trow;
+            row = row < p.M ? row : p.M - 1;
+            ssrc[j] = reinterpret_cast<const char*>(p.mxa) + (long)row * 4;
+            sstep[j] = p.mxa_rows * 4;
+        } else {
+            int row = bn * BN + (trow - BM);
+            row = row < p.N ? row : p.N - 1;
+            ssrc[j] = reinterpret_cast<const char*>(p.mxw) + (long)row * 4;
+            sstep[j] = p.mxw_rows * 4;
+        }
+    }
+    auto stage = [&](int buf, int kt) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int piece = wave + NW * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long)kt * RB),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * TILE + piece * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < SPW; ++j) {
+            const int sp = (wave + NW * j) % SP;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc[j] + kt * sstep[j]),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * TILE + DATA + sp * 256), 4, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int sw = (l31 >> 1) & 7;
+    auto compute = [&](int buf) {
+        const char* As = smem + buf * TILE;
+        const char* Ws = As + BM * RB;
+        const unsigned* Ss = reinterpret_cast<const unsigned*>(As + DATA);
+        int sa[TM], sb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) sa[i] = (int)(Ss[wm * WM + i * 32 + l31] >> (8 * lh));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) sb[j] = (int)(Ss[BM + wn * WN + j * 32 + l31] >> (8 * lh));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                           // the two 64-k MFMA steps of a 128-k tile
+            const int pc0 = ((4 * e + lh) ^ sw) * 16, pc1 = ((4 * e + 2 + lh) ^ sw) * 16;     // k = 16h .. +15 and 32 + 16h .. +15
+            i32x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const char* r = As + (wm * WM + i * 32 + l31) * RB;
+                af[i] = __builtin_shufflevector(*reinterpret_cast<const i32x4*>(r + pc0), *reinterpret_cast<const i32x4*>(r + pc1), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const char* r = Ws + (wn * WN + j * 32 + l31) * RB;
+                bf[j] = __builtin_shufflevector(*reinterpret_cast<const i32x4*>(r + pc0), *reinterpret_cast<const i32x4*>(r + pc1), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (e == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf[j], acc[i][j], 0, 0, 0, sa[i], 0, sb[j]);
+                    else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf[j], acc[i][j], 0, 0, 2, sa[i], 2, sb[j]);
+                }
+        }
+    };
+
+    const int nk = p.K / RB;
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) stage(t, t);
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (STAGES == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + SPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < nk) {
+            int fill = slot + STAGES - 1;
+            fill = fill >= STAGES ? fill - STAGES : fill;
+            stage(fill, kt + STAGES - 1);
+        }
+        compute(slot);
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N, true>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
+}
+
 struct TileCfgB { int bm, bn, bk; };
 // The tuner's candidates.  Retired after A/B runs on MI355X: 3- and 4-stage rings of the 128x128 tile and
 // 128x64 / 128x128 per-wave tiles -- fewer resident workgroups cost more than the deeper prefetch or the saved LDS reads gain.
@@ -206,6 +365,34 @@ static hipError_t launch_cfg_f8(int c, const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// MX tile family (k tile = 128 bytes).  LDS per stage = (bm + bn) * 132 bytes.
+static const TileCfgB kCfgsMx[] = {
+    {128, 128, 128},   // 0: 4 waves of 64x64, 2 stages (66 KiB: 2 workgroups per CU)
+    {256, 128, 128},   // 1: 8 waves of 64x64, 2 stages (99 KiB)
+    {256, 128, 128},   // 2: 4 waves of 128x64, 2 stages: 12 LDS reads per 8 MFMAs instead of 8 per 4
+    {128, 128, 128},   // 3: as 0 with a 3-stage ring (99 KiB)
+    {64, 128, 128},    // 4: 4 waves of 32x64
+    {128, 64, 128},    // 5: 4 waves of 64x32
+    {64, 64, 128},     // 6: 4 waves of 32x32
+    {256, 256, 128},   // 7: 16 waves of 64x64, 2 stages (132 KiB)
+};
+constexpr int kNumCfgsMx = 8;
+static hipError_t launch_cfg_mx(int c, const GemmParams& p, hipStream_t s) {
+    const int nb = ((p.M + kCfgsMx[c].bm - 1) / kCfgsMx[c].bm) * ((p.N + kCfgsMx[c].bn - 1) / kCfgsMx[c].bn);
+    switch (c) {
+        case 0: hipLaunchKernelGGL((gemm_mx8_kernel<128, 128, 64, 64, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_mx8_kernel<256, 128, 64, 64, 2, 2>), dim3(nb), dim3(512), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_mx8_kernel<256, 128, 128, 64, 2, 1>), dim3(nb), dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_mx8_kernel<128, 128, 64, 64, 3, 1>), dim3(nb), dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((gemm_mx8_kernel<64, 128, 32, 64, 2, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 5: hipLaunchKernelGGL((gemm_mx8_kernel<128, 64, 64, 32, 2, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 6: hipLaunchKernelGGL((gemm_mx8_kernel<64, 64, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 7: hipLaunchKernelGGL((gemm_mx8_kernel<256, 256, 64, 64, 2, 1>), dim3(nb), dim3(1024), 0, s, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 static int forced_cfg_b() {
     static int v = [] {
         const char* e = getenv("FERN_GEMM_BF16_CFG");
@@ -217,7 +404,7 @@ static int forced_cfg_b() {
 // Per-shape tile selection, as in gemm.hip: every configuration produces bit-identical results, so the choice is purely a
 // speed choice; each new (M, N, K, epilogue) is timed once on scratch outputs (outside stream capture).
 struct ShapeKeyB {
-    int M, N, K, epi, ob;      // ob: bit 0 = bf16 output, bit 1 = fp8 operands
+    int M, N, K, epi, ob;      // ob: bit 0 = bf16 output, bit 1 = fp8 operands, bit 2 = MX fp8 operands
     bool operator<(const ShapeKeyB& o) const {
         if (M != o.M) return M < o.M;
         if (N != o.N) return N < o.N;
@@ -229,7 +416,7 @@ struct ShapeKeyB {
 static std::map<ShapeKeyB, int> g_tuned_b;
 static std::mutex g_tuned_b_mu;
 
-// FERN_GEMM_TILES=<file>: lines "bf16 M N K epi ob cfg" / "fp8 M N K epi ob cfg" pin the choices (see gemm.hip)
+// FERN_GEMM_TILES=<file>: lines "bf16 M N K epi ob cfg" / "fp8 M N K epi ob cfg" / "mx8 M N K epi ob cfg" pin the choices (see gemm.hip)
 static void load_pinned_tiles_b() {
     static std::once_flag once;
     std::call_once(once, [] {
@@ -240,8 +427,9 @@ static void load_pinned_tiles_b() {
         int M, N, K, epi, ob, cfg;
         std::lock_guard<std::mutex> lock(g_tuned_b_mu);
         while (fscanf(f, "%15s %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &ob, &cfg) == 7) {
-            const bool f8 = !strcmp(kind, "fp8");
-            if ((f8 || !strcmp(kind, "bf16")) && cfg >= 0 && cfg < (f8 ? kNumCfgsF8 : kNumCfgsB) && (f8 || K % kCfgsB[cfg].bk == 0))
+            const bool f8 = !strcmp(kind, "fp8"), mx = !strcmp(kind, "mx8");
+            if ((f8 || mx || !strcmp(kind, "bf16")) && cfg >= 0 && cfg < (mx ? kNumCfgsMx : f8 ? kNumCfgsF8 : kNumCfgsB) &&
+                (f8 || mx || K % kCfgsB[cfg].bk == 0))
                 g_tuned_b[ShapeKeyB{M, N, K, epi, ob}] = cfg;
         }
         fclose(f);
@@ -251,7 +439,7 @@ void gemm_bf16_tuner_export(std::string& out) {
     std::lock_guard<std::mutex> lock(g_tuned_b_mu);
     for (const auto& kv : g_tuned_b) {
         char line[128];
-        snprintf(line, sizeof line, "%s %d %d %d %d %d %d\n", (kv.first.ob & 2) ? "fp8" : "bf16", kv.first.M, kv.first.N, kv.first.K, kv.first.epi,
+        snprintf(line, sizeof line, "%s %d %d %d %d %d %d\n", (kv.first.ob & 4) ? "mx8" : (kv.first.ob & 2) ? "fp8" : "bf16", kv.first.M, kv.first.N, kv.first.K, kv.first.epi,
                  kv.first.ob, kv.second);
         out += line;
     }
@@ -269,7 +457,7 @@ static int heuristic_b(int M, int N) {
 
 static int tune_shape_b(const GemmParams& p, hipStream_t s) {
     const bool f8 = p.fp8 != 0;
-    auto launch = f8 ? launch_cfg_f8 : launch_cfg_b;
+    auto launch = p.fp8 == 2 ? launch_cfg_mx : f8 ? launch_cfg_f8 : launch_cfg_b;
     const int fallback = f8 ? 0 : heuristic_b(p.M, p.N);
     const char* e = getenv("FERN_GEMM_TUNE");
     if (e && e[0] == '0') return fallback;
@@ -284,7 +472,7 @@ static int tune_shape_b(const GemmParams& p, hipStream_t s) {
     q.C = scratch;            // the residual input is only read: tuning has no side effects on the caller's buffers
     int best = fallback;
     float best_ms = 1e30f;
-    const int ncand = f8 ? kNumCfgsF8 : kNumCfgsB;
+    const int ncand = p.fp8 == 2 ? kNumCfgsMx : f8 ? kNumCfgsF8 : kNumCfgsB;
     for (int c = 0; c < ncand; ++c) {
         if (!f8 && p.K % kCfgsB[c].bk) continue;
         if (launch(c, q, s) != hipSuccess) continue;                       // warm
@@ -306,10 +494,27 @@ static int tune_shape_b(const GemmParams& p, hipStream_t s) {
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     load_pinned_tiles_b();
-    const int kq = p.fp8 ? 64 : 32, aq = p.fp8 ? 15 : 7;
+    const int kq = p.fp8 == 2 ? 128 : p.fp8 ? 64 : 32, aq = p.fp8 ? 15 : 7;
     if (p.K <= 0 || (p.K % kq) != 0 || (p.lda & aq) || (p.ldw & aq) || p.aload != ALOAD_PLAIN || epi_is_reduce(p.epi)) return hipErrorInvalidValue;
     if (!p.Ab || !p.Wb || ((uintptr_t)p.Ab & 15) || ((uintptr_t)p.Wb & 15)) return hipErrorInvalidValue;
     if ((p.scale_a == nullptr) != (p.scale_w == nullptr)) return hipErrorInvalidValue;
+    if (p.fp8 == 2) {
+        if (!p.mxa || !p.mxw || p.scale_a || ((uintptr_t)p.mxa & 3) || ((uintptr_t)p.mxw & 3) || p.mxa_rows < p.M || p.mxw_rows < p.N)
+            return hipErrorInvalidValue;
+        static int forced = [] { const char* e = getenv("FERN_GEMM_MX8_CFG"); return e ? atoi(e) : -1; }();
+        int c = forced;
+        if (c < 0 || c >= kNumCfgsMx) {
+            c = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) >= 256 ? 0 : 6;
+            if (2.0 * p.M * (double)p.N * p.K >= 2.5e8) {
+                const ShapeKeyB key{p.M, p.N, p.K, p.epi, p.out_bf16 | 4};
+                std::lock_guard<std::mutex> lock(g_tuned_b_mu);
+                auto it = g_tuned_b.find(key);
+                if (it == g_tuned_b.end()) it = g_tuned_b.emplace(key, tune_shape_b(p, s)).first;
+                c = it->second;
+            }
+        }
+        return launch_cfg_mx(c, p, s);
+    }
     if (p.fp8) {
         static int forced = [] { const char* e = getenv("FERN_GEMM_FP8_CFG"); return e ? atoi(e) : -1; }();
         int c = forced;

@@ -91,7 +91,19 @@ struct GemmParams {
     int fp8;
     const float* scale_a;         // [M] per-row (token) activation scales, or null
     const float* scale_w;         // [N] per-output-channel weight scales, or null
+    // fp8 == 2: block-scaled (MX) form -- one E8M0 scale byte per (row, 32 consecutive k) instead of scale_a / scale_w, applied
+    // inside v_mfma_scale_f32_32x32x64_f8f6f4.  mxa / mxw use the tile layout mx_scale_offset() below; K % 128 == 0.
+    const unsigned char* mxa;     // A's scales, mxa_rows >= M rows per 128-k tile
+    const unsigned char* mxw;     // W's scales, mxw_rows >= N
+    long mxa_rows, mxw_rows;
 };
+// MX scale layout of a [rows, K] fp8 matrix: scale byte of (row r, 32-k block b) lives at
+//   ((b / 4) * srows + r) * 4 + (b % 4)      (srows >= rows: the array's row count)
+// i.e. one dword per (128-k tile, row) -- what one GEMM workgroup stages per k tile is contiguous over its rows.
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline long mx_scale_offset(long r, long b, long srows) { return ((b >> 2) * srows + r) * 4 + (b & 3); }
 // Number of column blocks the reduce epilogues write per row (depends on the tile chosen for this shape).
 int gemm_num_col_blocks(int M, int N, int K);
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
@@ -198,6 +210,13 @@ hipError_t launch_layernorm_fp8(const float* x, const float* gamma, const float*
                                 long ldx, long ldy, float eps, hipStream_t s);
 hipError_t launch_quantize_rows_fp8(const unsigned short* x_bf16, const float* x_f32, long ldx, unsigned char* y, long ldy, float* scale,
                                     long rows, int d, hipStream_t s);
+// MX (block-scaled) e4m3fn quantisation: per (row, 32 consecutive k) one E8M0 byte e = smallest power of two with
+// max|block| * 2^-(e-127) <= 448 (clamped to [1, 253]; an all-zero block gets 1), y = fp8(x * 2^(127-e)) (exact scaling, RNE cast).
+// Scales in the mx_scale_offset layout with `srows` rows.  d % 128 == 0, d <= 4096.  LayerNorm-fused, bf16-row and fp32-row forms.
+hipError_t launch_layernorm_mx8(const float* x, const float* gamma, const float* beta, unsigned char* y, unsigned char* scales, long srows,
+                                long rows, int d, long ldx, long ldy, float eps, hipStream_t s);
+hipError_t launch_quantize_mx8(const unsigned short* x_bf16, const float* x_f32, long ldx, unsigned char* y, long ldy, unsigned char* scales,
+                               long srows, long rows, int d, hipStream_t s);
 // mode 0: x / max(||x||, eps) (F.normalize); mode 1: x / (||x|| + eps) (VisualSR.l2norm)
 hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s,
                          const float* x2 = nullptr);   // x2: optional addend (normalize(x + x2))

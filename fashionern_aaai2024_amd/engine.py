@@ -360,6 +360,28 @@ class FernEngine:
                                           m, n, k, int(epilogue), int(bool(out_bf16)), _stream()), "fern_gemm_fp8")
         return out
 
+    def quantize_mx8(self, x):
+        """[R,C] fp32 or bf16 (C % 128 == 0) -> (e4m3fn bytes [R,C] as uint8, E8M0 block scales as uint8 [C/128, R, 4]):
+        scale byte of (row r, 32-k block b) = scales[b // 4, r, b % 4] (include/fern.h: fern_quantize_mx8)."""
+        x = x.to(self.device).contiguous() if x.dtype == torch.bfloat16 else self._f32(x)
+        rows, d = x.shape
+        y = torch.empty(rows, d, dtype=torch.uint8, device=self.device)
+        sc = torch.empty(d // 128, rows, 4, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.fern_quantize_mx8(self._h, _ptr(x), int(x.dtype == torch.bfloat16), d, _ptr(y), d, _ptr(sc), rows, rows, d,
+                                              _stream()), "fern_quantize_mx8")
+        return y, sc
+
+    def gemm_mx8(self, a8, sa, w8, sw, bias=None, residual=None, epilogue=EPI_BIAS, out_bf16=False) -> torch.Tensor:
+        """Block-scaled fp8 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4; operands and scales as quantize_mx8 returns them."""
+        m, k = a8.shape
+        n = w8.shape[0]
+        bias = None if bias is None else self._f32(bias, (n,))
+        residual = None if residual is None else self._f32(residual, (m, n))
+        out = torch.empty(m, n, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=self.device)
+        _lib.check(self.lib.fern_gemm_mx8(self._h, _ptr(a8), k, _ptr(sa), sa.shape[1], _ptr(w8), k, _ptr(sw), sw.shape[1], _ptr(bias),
+                                          _ptr(residual), _ptr(out), n, m, n, k, int(epilogue), int(bool(out_bf16)), _stream()), "fern_gemm_mx8")
+        return out
+
     def layernorm(self, x, gamma, beta, eps: float, residual=None) -> torch.Tensor:
         x = self._f32(x)
         rows, d = x.shape

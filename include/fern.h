@@ -269,6 +269,18 @@ FERN_API int fern_quantize_rows_fp8(fern_ctx* ctx, const void* x, int x_is_bf16,
 FERN_API int fern_gemm_fp8(fern_ctx* ctx, const uint8_t* A, int64_t lda, const float* scale_a, const uint8_t* W, int64_t ldw,
                   const float* scale_w, const float* bias, const float* residual, void* C, int64_t ldc, int M, int N, int K,
                   int epilogue, int out_bf16, void* stream);
+/* MX (block-scaled) fp8 operand form, the operand format of gfx950's v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 / plain-fp8
+ * matrix rate): OCP e4m3fn bytes with ONE E8M0 scale byte per (row, 32 consecutive k).  fern_quantize_mx8 produces both from a
+ * bf16 or fp32 [rows, d] matrix: e = the smallest power-of-two exponent with max|block| * 2^-(e-127) <= 448 (clamped to [1, 253];
+ * an all-zero block gets 1), y = fp8(x * 2^(127-e)) -- the scaling is exact, the cast rounds to nearest even.
+ * Scale layout (uint8, (d / 128) * scale_rows * 4 bytes): byte of (row r, block b = k / 32) at ((b / 4) * scale_rows + r) * 4 + b % 4,
+ * scale_rows >= rows.  fern_gemm_mx8: C = sum over blocks of 2^(ea-127) 2^(ew-127) (A8 . W8) + bias (+ GELU | + residual), fp32
+ * accumulation, scales applied inside the MFMA.  K % 128 == 0, d % 128 == 0, d <= 4096, lda / ldw % 16 == 0, ldx / ldy % 8 == 0. */
+FERN_API int fern_quantize_mx8(fern_ctx* ctx, const void* x, int x_is_bf16, int64_t ldx, uint8_t* y, int64_t ldy, uint8_t* scales,
+                      int64_t scale_rows, int64_t rows, int d, void* stream);
+FERN_API int fern_gemm_mx8(fern_ctx* ctx, const uint8_t* A, int64_t lda, const uint8_t* scales_a, int64_t scale_rows_a, const uint8_t* W,
+                  int64_t ldw, const uint8_t* scales_w, int64_t scale_rows_w, const float* bias, const float* residual, void* C,
+                  int64_t ldc, int M, int N, int K, int epilogue, int out_bf16, void* stream);
 /* y = LayerNorm(x (+ residual)) * gamma + beta, rows of width d */
 FERN_API int fern_layernorm(fern_ctx* ctx, const float* x, const float* residual, const float* gamma,
                    const float* beta, float* y, int64_t rows, int d, float eps, void* stream);

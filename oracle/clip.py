@@ -44,9 +44,33 @@ def _q8(x):
     return q, sc
 
 
+def mx8_quantize(x):
+    """MX (block-scaled) e4m3fn quantisation as the product does it (csrc/elem.hip: quantize_mx8_kernel / layernorm_mx8_kernel;
+    include/fern.h: fern_quantize_mx8): per (row, 32 consecutive k) one E8M0 byte e = the smallest power-of-two exponent with
+    max|block| * 2^-(e-127) <= 448, read off the maximum's exponent and mantissa bits (448 = 1.75 * 2^8), clamped to [1, 253];
+    q = e4m3fn(x * 2^(127-e)) -- exact scaling, round-to-nearest-even cast.  Returns (q [.., D] float8_e4m3fn, e [.., D/32] uint8)."""
+    shp = x.shape
+    blocks = x.float().reshape(*shp[:-1], shp[-1] // 32, 32)
+    u = blocks.abs().amax(dim=-1).contiguous().view(torch.int32)
+    e = ((u >> 23) - 8 + ((u & 0x7FFFFF) > 0x600000).int()).clamp(1, 253)
+    inv = ((254 - e) << 23).view(torch.float32)
+    q = (blocks * inv.unsqueeze(-1)).to(torch.float8_e4m3fn)
+    return q.reshape(shp), e.to(torch.uint8)
+
+
+def mx8_dequantize(q, e, dtype=torch.float32):
+    """The values the block-scaled MFMA multiplies: q * 2^(e-127) per 32-k block (exact in fp32)."""
+    shp = q.shape
+    sc = torch.ldexp(torch.ones((), dtype=dtype), e.int() - 127)
+    return (q.to(dtype).reshape(*shp[:-1], shp[-1] // 32, 32) * sc.unsqueeze(-1)).reshape(shp)
+
+
 def _linear(x, w, b, prec):
     """prec None / "fp32": plain; "bf16": bf16-rounded operands; "fp8": e4m3fn operands with per-token and per-output-channel
     scales folded back after the fp32-accumulated product (the product's epilogue: acc * (sa * sw) + bias)."""
+    if prec == "mx8":
+        y = mx8_dequantize(*mx8_quantize(x)) @ mx8_dequantize(*mx8_quantize(w)).transpose(-1, -2)
+        return y if b is None else y + b
     if prec == "fp8":
         qa, sa = _q8(x)
         qw, sw = _q8(w)

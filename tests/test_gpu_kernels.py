@@ -348,15 +348,85 @@ def test_gemm_fp8(engine, m, n, k, epi, out_bf16):
         assert torch.equal(gi.cpu(), ai @ wi.T)
 
 
+def _mx_scales_by_block(sc):
+    """engine.quantize_mx8's [D/128, R, 4] scale array -> [R, D/32] (block b = k // 32)."""
+    return sc.permute(1, 0, 2).reshape(sc.shape[1], -1)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("var,cfg", [("FERN_GEMM_BF16_CFG", c) for c in range(7)] + [("FERN_GEMM_FP8_CFG", c) for c in range(6)])
+@pytest.mark.parametrize("rows,d,bf16", [(5, 128, False), (197, 768, True), (64, 3072, True), (33, 4096, False), (1000, 512, True)])
+def test_quantize_mx8_is_bit_exact(engine, rows, d, bf16):
+    """Block-scaled quantiser: scale bytes, e4m3fn bytes and the scale layout against the oracle's restatement."""
+    from oracle.clip import mx8_quantize, mx8_dequantize
+    g = torch.Generator().manual_seed(rows + d)
+    x = torch.randn(rows, d, generator=g) * torch.logspace(-3, 3, rows).unsqueeze(1)
+    x[:, 32:64] *= 50.0                                   # an outlier block: its neighbours keep their own scales
+    x[rows // 2, :32] = 0                                  # an all-zero block
+    x[0, 64] = 448.0; x[0, 65:96] = 0                      # maximum exactly 448 * 2^0: scale byte 127, element byte 0x7E
+    x[1, 64] = 480.0; x[1, 65:96] = 0                      # above (and a bf16 value): the next power of two
+    if bf16:
+        x = x.bfloat16()
+    y, sc = engine.quantize_mx8(x.cuda())
+    q_ref, e_ref = mx8_quantize(x.float())
+    assert torch.equal(_mx_scales_by_block(sc.cpu()), e_ref)
+    assert torch.equal(y.cpu(), q_ref.view(torch.uint8))
+    e = _mx_scales_by_block(sc.cpu())
+    assert e[rows // 2, 0] == 1 and int(y[rows // 2, :32].max()) == 0
+    assert e[0, 2] == 127 and y[0, 64] == 0x7E and e[1, 2] == 128
+    # no element is clipped: dequantised values stay within half an e4m3 step (2^-4 relative) of the input, block maximum included
+    dq = mx8_dequantize(q_ref, e_ref)
+    blk = x.float().reshape(rows, d // 32, 32)
+    assert ((dq.reshape(rows, d // 32, 32) - blk).abs() <= blk.abs().amax(-1, keepdim=True) * 2.0 ** -4).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(64, 128, 128), (197, 384, 256), (1000, 520, 640), (4096, 768, 768), (333, 2304, 768)])
+@pytest.mark.parametrize("epi,out_bf16", [(0, False), (0, True), (1, True), (3, False)])
+def test_gemm_mx8(engine, m, n, k, epi, out_bf16):
+    """Block-scaled fp8 GEMM (v_mfma_scale_f32_32x32x64_f8f6f4) against fp64 math on the SAME quantised operands and scales."""
+    from oracle.clip import mx8_dequantize
+    g = torch.Generator().manual_seed(m + n + k + epi)
+    a = torch.randn(m, k, generator=g) * torch.logspace(-1, 1, k // 32).repeat_interleave(32)     # blocks of different magnitude
+    w = torch.randn(n, k, generator=g) * k ** -0.5
+    b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g)
+    a8, sa = engine.quantize_mx8(a)
+    w8, sw = engine.quantize_mx8(w)
+    qa = mx8_dequantize(a8.cpu().view(torch.float8_e4m3fn), _mx_scales_by_block(sa.cpu()), torch.float64)
+    qw = mx8_dequantize(w8.cpu().view(torch.float8_e4m3fn), _mx_scales_by_block(sw.cpu()), torch.float64)
+    ref = qa @ qw.T + b.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 3:
+        ref = ref + r.double()
+    got = engine.gemm_mx8(a8, sa, w8, sw, b, residual=r if epi == 3 else None, epilogue=epi, out_bf16=out_bf16)
+    if out_bf16:
+        assert got.dtype == torch.bfloat16 and torch.allclose(got.float().cpu().double(), ref, rtol=2 ** -7, atol=1e-3)
+    else:
+        assert (got.cpu().double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    if epi == 0 and not out_bf16:
+        # integer data, power-of-two block scales: every product and partial sum is exact in fp32
+        ai = torch.randint(-4, 5, (m, k), generator=g).float()
+        wi = torch.randint(-4, 5, (n, k), generator=g).float()
+        ea = torch.randint(125, 130, (k // 128, m, 4), generator=g, dtype=torch.uint8)
+        ew = torch.randint(125, 130, (k // 128, n, 4), generator=g, dtype=torch.uint8)
+        gi = engine.gemm_mx8(ai.to(torch.float8_e4m3fn).view(torch.uint8).cuda(), ea.cuda(), wi.to(torch.float8_e4m3fn).view(torch.uint8).cuda(),
+                             ew.cuda(), None)
+        da = mx8_dequantize(ai, _mx_scales_by_block(ea))
+        dw = mx8_dequantize(wi, _mx_scales_by_block(ew))
+        assert torch.equal(gi.cpu(), da @ dw.T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("var,cfg", [("FERN_GEMM_BF16_CFG", c) for c in range(7)] + [("FERN_GEMM_FP8_CFG", c) for c in range(6)] +
+                         [("FERN_GEMM_MX8_CFG", c) for c in range(8)])
 def test_every_reduced_precision_gemm_tile_variant(var, cfg):
     """The bf16 / fp8 launchers pick (or tune) a tile per shape; each variant is also forced over its shape suite."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    key = {"FERN_GEMM_BF16_CFG": "test_gemm_bf16", "FERN_GEMM_FP8_CFG": "test_gemm_fp8"}[var]
+    key = {"FERN_GEMM_BF16_CFG": "test_gemm_bf16", "FERN_GEMM_FP8_CFG": "test_gemm_fp8", "FERN_GEMM_MX8_CFG": "test_gemm_mx8"}[var]
     env = dict(os.environ, **{var: str(cfg)})
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "-m", "gpu", "-q", "-x", "-k", key, "-p", "no:cacheprovider"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
@@ -375,7 +445,11 @@ def test_reduced_precision_gemms_are_batch_invariant(engine):
     a8, sa = engine.quantize_rows_fp8(a)
     w8, sw = engine.quantize_rows_fp8(w)
     full8 = engine.gemm_fp8(a8, sa, w8, sw, b, epilogue=0).cpu()
+    am, sam = engine.quantize_mx8(a)
+    wq, swm = engine.quantize_mx8(w)
+    fullm = engine.gemm_mx8(am, sam, wq, swm, b, epilogue=0).cpu()
     for lo, hi in ((0, 1), (0, 64), (100, 1124), (2990, 3000)):
+        assert torch.equal(engine.gemm_mx8(am[lo:hi].contiguous(), sam[:, lo:hi].contiguous(), wq, swm, b, epilogue=0).cpu(), fullm[lo:hi])
         assert torch.equal(engine.gemm_bf16(ab[lo:hi].contiguous(), wb, b, epilogue=1, out_bf16=True).cpu(), full[lo:hi])
         assert torch.equal(engine.gemm_fp8(a8[lo:hi].contiguous(), sa[lo:hi].contiguous(), w8, sw, b, epilogue=0).cpu(), full8[lo:hi])
 
