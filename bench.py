@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MX8_MFMA_PEAK_TFLOPS = 5000.0     # MI355X_MICROARCH.md: dense fp8 on the block-scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4), 2x the bf16 rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (the non-scaled fp8 32x32x16 MFMA issues at this rate too)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 XGMI_PEAK_GBS = 7 * 153.0         # 7 point-to-point links x ~153 GB/s per GPU
@@ -51,7 +52,7 @@ WORKLOADS = {
     "c4": dict(clip="ViT-B-16", d=512, batch=128, gallery=21_552, k=51, precision="fp32", cirr=True, bf16_gallery=False,
                text="CIRR ViT-B/16 composed queries: 128-query batch per GPU (1024 on 8 GPUs), global top-51 with the reference removed "
                     "+ subset scores of 6 members (BASELINE.json configs[3])"),
-    "c5": dict(clip="ViT-B-16", d=512, batch=64, gallery=1_000_000, k=50, precision="fp8", cirr=False, bf16_gallery=True,
+    "c5": dict(clip="ViT-B-16", d=512, batch=64, gallery=1_000_000, k=50, precision="mx8", cirr=False, bf16_gallery=True,
                text="FashionIQ ViT-B/16 fp8 MFMA encoder GEMMs + bf16 similarity: 64-query batch per GPU vs 1M-row bf16 gallery "
                     "(BASELINE.json configs[4])"),
 }
@@ -67,7 +68,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--gallery", type=int, default=None, help="override the workload's gallery rows")
     ap.add_argument("--lanes", type=int, default=3, help="query batches kept in flight on separate HIP streams")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "fp8"], default=None,
+    ap.add_argument("--precision", choices=["fp32", "bf16", "fp8", "mx8"], default=None,
                     help="override the encoder operand precision of the TIMED path (fp32 = parity mode, the c2 headline)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary legs (reduced-precision modes, lookup variant, 1M-row bf16 sweep, encode rate): the GEMM "
@@ -388,13 +389,15 @@ def main():
             step_serial(j)
         sp = eng.prof_collect()
         eng.prof_enable(False)
-        key = "gemm_fp8" if prec == "fp8" else "gemm_bf16"
+        key = {"fp8": "gemm_fp8", "mx8": "gemm_mx8", "bf16": "gemm_bf16"}[prec]
+        peak = MX8_MFMA_PEAK_TFLOPS if prec == "mx8" else BF16_MFMA_PEAK_TFLOPS
         tfl = sp[key + "_flops"] / (sp[key + "_ms"] * 1e-3) / 1e12 if sp[key + "_ms"] > 0 else 0.0
         overlap = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(ref_idx.cpu(), b_idx.cpu())) / ref_idx.numel()
         info = {"value": world * B * args.steps / el, "unit": "queries/sec", "ms_per_step": el / args.steps * 1e3,
-                "dtype": ("bf16" if prec == "bf16" else "fp8 e4m3fn (per-token / per-channel scales)") +
+                "dtype": {"bf16": "bf16", "fp8": "fp8 e4m3fn (per-token / per-channel scales)",
+                          "mx8": "fp8 e4m3fn, one E8M0 scale per 32-element block (block-scaled MFMA)"}[prec] +
                          " operands, f32 accumulate (encoder block GEMMs; attention and the fusion BERT blocks in bf16 operand form)",
-                "gemm_tflops": tfl, "gemm_peak_tflops": BF16_MFMA_PEAK_TFLOPS, "gemm_frac": tfl / BF16_MFMA_PEAK_TFLOPS,
+                "gemm_tflops": tfl, "gemm_peak_tflops": peak, "gemm_frac": tfl / peak,
                 "gemm_ms_per_step": sp[key + "_ms"] / 2, "gemm_f32_ms_per_step": sp["gemm_ms"] / 2, "attention_ms_per_step": sp["attn_ms"] / 2,
                 "vs_fp32_top1_same": float((ref_idx[:, 0] == b_idx[:, 0]).float().mean().item()),
                 "vs_fp32_top50_overlap": overlap,
@@ -403,12 +406,29 @@ def main():
         return info
 
     secondary = not args.headline_only and args.config == "c2" and precision == "fp32"
-    bf16_info = fp8_info = None
+    bf16_info = fp8_info = mx8_info = accuracy = None
     if secondary:
         step_no[0] = 0
         ref_scores, ref_idx = step().wait()
         bf16_info = reduced_precision_leg("bf16", ref_scores, ref_idx)
         fp8_info = reduced_precision_leg("fp8", ref_scores, ref_idx)
+        mx8_info = reduced_precision_leg("mx8", ref_scores, ref_idx)
+    elif not args.headline_only and precision in ("fp8", "mx8"):
+        # c5: what the timed fp8 form costs in ranking agreement with the fp32 encoder on the same gallery, and the other fp8 form
+        pipe.set_precision("fp32")
+        step_no[0] = 0
+        ref_scores, ref_idx = step().wait()
+        pipe.set_precision(precision)
+        step_no[0] = 0
+        t_scores, t_idx = step().wait()
+        accuracy = {"vs_fp32_top1_same": float((ref_idx[:, 0] == t_idx[:, 0]).float().mean().item()),
+                    "vs_fp32_top50_overlap": sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(ref_idx.cpu(), t_idx.cpu())) / ref_idx.numel(),
+                    "vs_fp32_max_abs_top1_score_diff": float((ref_scores[:, 0] - t_scores[:, 0]).abs().max().item())}
+        other = reduced_precision_leg("fp8" if precision == "mx8" else "mx8", ref_scores, ref_idx)
+        if precision == "mx8":
+            fp8_info = other
+        else:
+            mx8_info = other
 
     # ---- roofline: instrumented passes (events around every kernel class), outside the timed region ----------
     for j in range(n_batches):
@@ -420,9 +440,9 @@ def main():
         step_serial(j)
     st = eng.prof_collect()
     eng.prof_enable(False)
-    gkey = {"fp32": "gemm", "bf16": "gemm_bf16", "fp8": "gemm_fp8"}[precision]      # the dominant GEMM family of this run
+    gkey = {"fp32": "gemm", "bf16": "gemm_bf16", "fp8": "gemm_fp8", "mx8": "gemm_mx8"}[precision]      # the dominant GEMM family of this run
     gemm_tflops = st[gkey + "_flops"] / (st[gkey + "_ms"] * 1e-3) / 1e12 if st[gkey + "_ms"] > 0 else 0.0
-    gemm_peak = F32_MFMA_PEAK_TFLOPS if precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
+    gemm_peak = {"fp32": F32_MFMA_PEAK_TFLOPS, "mx8": MX8_MFMA_PEAK_TFLOPS}.get(precision, BF16_MFMA_PEAK_TFLOPS)
     attn_tflops = st["attn_flops"] / (st["attn_ms"] * 1e-3) / 1e12 if st["attn_ms"] > 0 else 0.0
 
     def sweep_block(stats, calls, kernel):
@@ -502,7 +522,7 @@ def main():
         result = {
             "metric": "composed queries/sec", "value": value, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp8": "fp8"}[precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp8": "fp8", "mx8": "fp8"}[precision], "data": "synthetic",
             "config": {"workload": w["text"], "name": args.config, "clip": cfg.name, "query_batch_per_gpu": B, "gallery_rows": n_gal,
                        "gallery_dtype": "bf16" if w["bf16_gallery"] else "f32", "feature_dim": D, "top_k": K,
                        "image": f"3x{cfg.image_size}x{cfg.image_size}", "tokens": 77, "patch_feats": 13, "batches_in_flight": args.lanes,
@@ -520,7 +540,8 @@ def main():
                          "algorithmic_bytes_per_launch": st["gemm_alg_bytes"] / max(1, st["gemm_launches"]) if precision == "fp32" else alg_bytes,
                          "kernel": {"fp32": "gemm_f32_glds_kernel / gemm_f32_kernel (fp32 MFMA GEMM, all tile variants)",
                                     "bf16": "gemm_bf16_glds_kernel (bf16 MFMA GEMM of the encoder blocks)",
-                                    "fp8": "gemm_bf16_glds_kernel<FP8> (fp8 MFMA GEMM of the encoder blocks)"}[precision],
+                                    "fp8": "gemm_bf16_glds_kernel<FP8> (fp8 MFMA GEMM of the encoder blocks)",
+                                    "mx8": "gemm_mx8_kernel (block-scaled fp8 GEMM of the encoder blocks, v_mfma_scale_f32_32x32x64_f8f6f4)"}[precision],
                          "gemm_ms_per_step": st[gkey + "_ms"] / prof_steps, "gemm_gflop_per_step": st[gkey + "_flops"] / prof_steps / 1e9,
                          "gemm_launches_per_step": st[gkey + "_launches"] / prof_steps,
                          "gemm_dispatches_per_step": (st["gemm_dispatches"] / prof_steps) if precision == "fp32" else None,
@@ -530,6 +551,9 @@ def main():
             "roofline_sim_sweep_bf16_1M": big_roof,
             "encoder_bf16": bf16_info,
             "encoder_fp8": fp8_info,
+            "encoder_mx8": mx8_info,
+            "encoder_precision": precision,
+            "accuracy_vs_fp32_encoder": accuracy,
             "sharded_merge": sharded_info,
             "attention": {"achieved_tflops": attn_tflops, "ms_per_step": st["attn_ms"] / prof_steps},
             "lookup_variant": None if lookup_qps is None else {"value": lookup_qps * world, "unit": "queries/sec",

@@ -24,7 +24,8 @@ class ProfStats(C.Structure):
                 ("sweep_ms", C.c_double), ("sweep_bytes", C.c_double), ("sweep_launches", c_i64),
                 ("gemm_fp8_ms", C.c_double), ("gemm_fp8_flops", C.c_double), ("gemm_fp8_launches", c_i64),
                 ("gemm_bf16_ms", C.c_double), ("gemm_bf16_flops", C.c_double), ("gemm_bf16_launches", c_i64),
-                ("gemm_alg_bytes", C.c_double), ("gemm_dispatches", c_i64)]
+                ("gemm_alg_bytes", C.c_double), ("gemm_dispatches", c_i64),
+                ("gemm_mx8_ms", C.c_double), ("gemm_mx8_flops", C.c_double), ("gemm_mx8_launches", c_i64)]
 
 
 # name -> (restype, argtypes); must list every symbol include/fern.h declares (tests check this)
@@ -71,6 +72,8 @@ SIGNATURES = {
     "fern_quantize_mx8": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "fern_gemm_mx8": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
                               c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fern_gemm_mx8_quant": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_i64,
+                                    c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
     "fern_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_void_p]),
     "fern_attention": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),

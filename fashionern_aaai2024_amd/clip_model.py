@@ -42,7 +42,8 @@ class FernCLIP:
     def set_precision(self, precision: str):
         """"fp32": parity mode (default, the reference's arithmetic).  "bf16": perf mode of the transformer towers --
         bf16 operands / fp32 accumulation on the block GEMMs and attention; "fp8": e4m3fn operands on those GEMMs
-        (BASELINE config 5) -- include/fern.h:fern_precision; no reference counterpart (the reference evaluates in fp32, test_fiq.py:141-149)."""
+        with per-token / per-channel scales; "mx8": e4m3fn operands with one power-of-two scale per 32-element block on the
+        block-scaled MFMA (BASELINE config 5) -- include/fern.h:fern_precision; no reference counterpart (the reference evaluates in fp32, test_fiq.py:141-149)."""
         if precision != "fp32" and self.cfg.v_arch == "resnet":
             raise ValueError("reduced precisions cover the transformer towers; RN50x4's image tower has no bf16 / fp8 path")
         self.engine.set_precision(precision)

@@ -49,7 +49,8 @@ struct HostTensor {
 };
 
 struct LinearW { const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0; const unsigned short* wb = nullptr; /* bf16 copy of w (encoder blocks) */
-                 const unsigned char* w8 = nullptr; const float* sw = nullptr; /* fp8 copy + per-output-channel scales */ };
+                 const unsigned char* w8 = nullptr; const float* sw = nullptr; /* fp8 copy + per-output-channel scales */
+                 const unsigned char* wm = nullptr; const unsigned char* swm = nullptr; long swm_rows = 0; /* MX fp8 copy + E8M0 block scales */ };
 struct LNW { const float* g = nullptr; const float* b = nullptr; };
 struct CombinerW {
     LinearW text, image, hidden;
@@ -215,6 +216,15 @@ static GemmParams gemm_desc_f8(const unsigned char* A8, const float* sa, long ld
     p.Ab = reinterpret_cast<const unsigned short*>(A8); p.lda = lda; p.Wb = reinterpret_cast<const unsigned short*>(L.w8); p.ldw = L.in;
     p.bias = L.b; p.C = reinterpret_cast<float*>(C); p.ldc = ldc; p.M = M; p.N = L.out; p.K = L.in; p.epi = epi; p.aload = ALOAD_PLAIN;
     p.out_bf16 = out_bf16 ? 1 : 0; p.fp8 = 1; p.scale_a = sa; p.scale_w = L.sw;
+    return p;
+}
+// block-scaled (MX) fp8 GEMM: A8 [M, K] e4m3fn with E8M0 block scales sa (srows rows), the layer's MX weight copy
+static GemmParams gemm_desc_mx(const unsigned char* A8, const unsigned char* sa, long srows, long lda, const LinearW& L, void* C, long ldc, int M,
+                               int epi, bool out_bf16) {
+    GemmParams p{};
+    p.Ab = reinterpret_cast<const unsigned short*>(A8); p.lda = lda; p.Wb = reinterpret_cast<const unsigned short*>(L.wm); p.ldw = L.in;
+    p.bias = L.b; p.C = reinterpret_cast<float*>(C); p.ldc = ldc; p.M = M; p.N = L.out; p.K = L.in; p.epi = epi; p.aload = ALOAD_PLAIN;
+    p.out_bf16 = out_bf16 ? 1 : 0; p.fp8 = 2; p.mxa = sa; p.mxa_rows = srows; p.mxw = L.swm; p.mxw_rows = L.swm_rows;
     return p;
 }
 static int run_gemm_b(fern_ctx* c, const GemmParams& p, hipStream_t s) {
@@ -538,6 +548,21 @@ static int make_fp8(fern_ctx* c, LinearW* L) {
     return FERN_OK;
 }
 
+// MX (block-scaled) e4m3fn device copy: one E8M0 byte per (output channel, 32 consecutive k), kernels.h: mx_scale_offset layout
+static int make_mx8(fern_ctx* c, LinearW* L) {
+    if (L->in % 128 || L->in > 4096) return FERN_OK;     // shape outside the MX GEMM
+    unsigned char *d = nullptr, *sc = nullptr;
+    HIP_TRY(hipMalloc(&d, (size_t)L->out * L->in));
+    c->owned[c->cur_group].push_back(d);
+    HIP_TRY(hipMalloc(&sc, (size_t)L->out * (L->in / 32)));
+    c->owned[c->cur_group].push_back(sc);
+    HIP_TRY(launch_quantize_mx8(nullptr, L->w, L->in, d, L->in, sc, L->out, L->out, L->in, nullptr));
+    L->wm = d;
+    L->swm = sc;
+    L->swm_rows = L->out;
+    return FERN_OK;
+}
+
 static int up_clip_block(fern_ctx* c, const std::string& p, int width, int mlp, ClipBlockW* B) {
     FERN_TRY(up_ln(c, p + ".ln_1", width, &B->ln1));
     FERN_TRY(up_key(c, p + ".attn.in_proj_weight", {3 * width, width}, &B->qkv.w));
@@ -554,7 +579,11 @@ static int up_clip_block(fern_ctx* c, const std::string& p, int width, int mlp, 
     FERN_TRY(make_fp8(c, &B->qkv));
     FERN_TRY(make_fp8(c, &B->out));
     FERN_TRY(make_fp8(c, &B->fc));
-    return make_fp8(c, &B->proj);
+    FERN_TRY(make_fp8(c, &B->proj));
+    FERN_TRY(make_mx8(c, &B->qkv));
+    FERN_TRY(make_mx8(c, &B->out));
+    FERN_TRY(make_mx8(c, &B->fc));
+    return make_mx8(c, &B->proj);
 }
 
 // conv (no bias) + BatchNorm(eval) -> [cout_pad][kh*kw*cin_pad] weights in (ky, kx, ci) order (or the original (ci, ky, kx)
@@ -673,8 +702,14 @@ extern "C" int fern_finalize_clip(fern_ctx* c, const fern_clip_config* cfg) {
 
 extern "C" int fern_set_precision(fern_ctx* c, int precision) {
     if (!c) return fail(FERN_ERR_ARG, "fern_set_precision: ctx is NULL");
-    if (precision != FERN_PREC_FP32 && precision != FERN_PREC_BF16 && precision != FERN_PREC_FP8)
+    if (precision != FERN_PREC_FP32 && precision != FERN_PREC_BF16 && precision != FERN_PREC_FP8 && precision != FERN_PREC_MX8)
         return fail(FERN_ERR_ARG, "fern_set_precision: unknown precision");
+    if (precision == FERN_PREC_MX8 && c->clip.ready) {
+        for (const auto* blocks : {&c->clip.vblocks, &c->clip.tblocks})
+            for (const auto& b : *blocks)
+                if (!b.qkv.wm || !b.out.wm || !b.fc.wm || !b.proj.wm)
+                    return fail(FERN_ERR_ARG, "fern_set_precision: mx8 needs tower widths and MLP widths that are multiples of 128 (<= 4096)");
+    }
     if (precision == FERN_PREC_FP8 && c->clip.ready) {
         for (const auto* blocks : {&c->clip.vblocks, &c->clip.tblocks})
             for (const auto& b : *blocks)
@@ -1066,6 +1101,34 @@ static int clip_block_fp8(fern_ctx* c, const ClipBlockW& Bk, float* X, unsigned 
     return run_gemm_b(c, p2, s);
 }
 
+// MX block (FERN_PREC_MX8): clip_block_fp8 with block-scaled operands -- one E8M0 scale per (token, 32 channels) and per (output
+// channel, 32 inputs), applied inside v_mfma_scale_f32_32x32x64_f8f6f4 (twice the MFMA rate of the plain fp8 form, and an outlier
+// channel costs its own 32-block precision, not the whole token row).  SM: the activation scales of the operand in flight.
+static int clip_block_mx8(fern_ctx* c, const ClipBlockW& Bk, float* X, unsigned char* XN8, unsigned char* SM, unsigned short* QKVb,
+                          unsigned short* ATTb, unsigned char* ATT8, unsigned char* H8, int batch, int S, int width,
+                          int heads, int causal, hipStream_t s) {
+    const long R = (long)batch * S;
+    const int hd = width / heads, mlp = Bk.fc.out;
+    HIP_TRY(launch_layernorm_mx8(X, Bk.ln1.g, Bk.ln1.b, XN8, SM, R, R, width, width, width, 1e-5f, s));
+    FERN_TRY(run_gemm_b(c, gemm_desc_mx(XN8, SM, R, width, Bk.qkv, QKVb, 3 * width, (int)R, EPI_BIAS, true), s));
+    AttnParams a{nullptr, nullptr, nullptr, nullptr, 3L * width, 3L * width, 3L * width, (long)width,
+                 batch, heads, hd, S, S, causal, 1.0f / std::sqrt((float)hd), ATTb, QKVb, QKVb + width, QKVb + 2 * width};
+    FERN_TRY(run_attention(c, a, s));
+    HIP_TRY(launch_quantize_mx8(ATTb, nullptr, width, ATT8, width, SM, R, R, width, s));
+    GemmParams po = gemm_desc_mx(ATT8, SM, R, width, Bk.out, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
+    po.R = X;
+    FERN_TRY(run_gemm_b(c, po, s));
+    HIP_TRY(launch_layernorm_mx8(X, Bk.ln2.g, Bk.ln2.b, XN8, SM, R, R, width, width, width, 1e-5f, s));
+    // c_fc quantises its GELU output where it is produced (fp32 values -> e4m3fn + block scales): no bf16 round trip, no extra pass
+    unsigned char* SH = SM + ((size_t)R * (width / 32) + 255) / 256 * 256;      // H's scales, behind the LayerNorm output's
+    GemmParams pf = gemm_desc_mx(XN8, SM, R, width, Bk.fc, H8, mlp, (int)R, EPI_BIAS_GELU, false);
+    pf.out_mx8 = 1; pf.mxc = SH; pf.mxc_rows = R;
+    FERN_TRY(run_gemm_b(c, pf, s));
+    GemmParams p2 = gemm_desc_mx(H8, SH, R, mlp, Bk.proj, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
+    p2.R = X;
+    return run_gemm_b(c, p2, s);
+}
+
 // Last ViT block: only the class token is consumed afterwards (ln_post on token 0, modeling_clip.py:876-877), so
 // K/V are projected for every token but Q, the attention output, out_proj and the MLP run for the class rows only.
 // Bit-identical to the full block on the rows that are read.
@@ -1075,8 +1138,17 @@ static int clip_block_cls_only(fern_ctx* c, const ClipBlockW& Bk, const float* X
     const long R = (long)batch * S;
     const int hd = width / heads;
     LinearW kv{Bk.qkv.w + (size_t)width * width, Bk.qkv.b + width, 2 * width, width, Bk.qkv.wb + (size_t)width * width,
-               Bk.qkv.w8 ? Bk.qkv.w8 + (size_t)width * width : nullptr, Bk.qkv.sw ? Bk.qkv.sw + width : nullptr};
-    if (c->precision == FERN_PREC_FP8) {
+               Bk.qkv.w8 ? Bk.qkv.w8 + (size_t)width * width : nullptr, Bk.qkv.sw ? Bk.qkv.sw + width : nullptr,
+               Bk.qkv.wm ? Bk.qkv.wm + (size_t)width * width : nullptr, Bk.qkv.swm ? Bk.qkv.swm + (size_t)width * 4 : nullptr, Bk.qkv.swm_rows};
+    if (c->precision == FERN_PREC_MX8) {
+        // MX mode: block-scaled K/V projection of all tokens (fp32 output); the class-row chain below stays fp32
+        unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
+        unsigned char* SM = reinterpret_cast<unsigned char*>(XN + ((size_t)R * width / 4 + 63) / 64 * 64);
+        HIP_TRY(launch_layernorm_mx8(X, Bk.ln1.g, Bk.ln1.b, XN8, SM, R, R, width, width, width, 1e-5f, s));
+        FERN_TRY(run_gemm_b(c, gemm_desc_mx(XN8, SM, R, width, kv, QKV + width, 3 * width, (int)R, EPI_BIAS, false), s));
+        HIP_TRY(launch_gather_rows(X, width, T1, width, batch, width, 1, S, 0, nullptr, s));
+        HIP_TRY(launch_layernorm(T1, nullptr, Bk.ln1.g, Bk.ln1.b, T0, batch, width, width, width, 1e-5f, s));
+    } else if (c->precision == FERN_PREC_FP8) {
         // fp8 mode: quantised K/V projection of all tokens (fp32 output); the class-row chain below stays fp32
         unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
         float* SA = XN + ((size_t)R * width / 4 + 63) / 64 * 64;       // scales live behind the fp8 rows inside XN
@@ -1135,7 +1207,13 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
     HIP_TRY(launch_vit_cls(W.cls, W.vpos, X, b, S, vw, s));
     HIP_TRY(launch_layernorm(X, nullptr, W.ln_pre.g, W.ln_pre.b, X, R, vw, vw, vw, 1e-5f, s));
     for (int l = 0; l + 1 < cf.v_layers; ++l) {
-        if (c->precision == FERN_PREC_FP8) {    // XN: fp8 rows + scales; ATT / H: bf16 output in the first half, its fp8 copy behind it
+        if (c->precision == FERN_PREC_MX8) {    // same buffer plan as fp8 below; the scale area holds E8M0 bytes
+            unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
+            FERN_TRY(clip_block_mx8(c, W.vblocks[l], X, XN8, reinterpret_cast<unsigned char*>(XN + ((size_t)R * vw / 4 + 63) / 64 * 64),
+                                    reinterpret_cast<unsigned short*>(QKV), reinterpret_cast<unsigned short*>(ATT),
+                                    reinterpret_cast<unsigned char*>(ATT) + (size_t)R * vw * 2, reinterpret_cast<unsigned char*>(H),
+                                    b, S, vw, cf.v_heads, 0, s));
+        } else if (c->precision == FERN_PREC_FP8) {    // XN: fp8 rows + scales; ATT / H: bf16 output in the first half, its fp8 copy behind it
             unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
             FERN_TRY(clip_block_fp8(c, W.vblocks[l], X, XN8, XN + ((size_t)R * vw / 4 + 63) / 64 * 64, reinterpret_cast<unsigned short*>(QKV),
                                     reinterpret_cast<unsigned short*>(ATT), reinterpret_cast<unsigned char*>(ATT) + (size_t)R * vw * 2,
@@ -1269,7 +1347,13 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
     FERN_TRY(ws_get(c, (size_t)B, &eot));
     HIP_TRY(launch_text_embed(tokens, W.tok_emb, W.tpos, X, eot, B, T, tw, cf.vocab_size, c->tok_flag, s));
     for (int l = 0; l < cf.t_layers; ++l) {
-        if (c->precision == FERN_PREC_FP8) {
+        if (c->precision == FERN_PREC_MX8) {
+            unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
+            FERN_TRY(clip_block_mx8(c, W.tblocks[l], X, XN8, reinterpret_cast<unsigned char*>(XN + ((size_t)R * tw / 4 + 63) / 64 * 64),
+                                    reinterpret_cast<unsigned short*>(QKV), reinterpret_cast<unsigned short*>(ATT),
+                                    reinterpret_cast<unsigned char*>(ATT) + (size_t)R * tw * 2, reinterpret_cast<unsigned char*>(H),
+                                    B, T, tw, cf.t_heads, 1, s));
+        } else if (c->precision == FERN_PREC_FP8) {
             unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
             FERN_TRY(clip_block_fp8(c, W.tblocks[l], X, XN8, XN + ((size_t)R * tw / 4 + 63) / 64 * 64, reinterpret_cast<unsigned short*>(QKV),
                                     reinterpret_cast<unsigned short*>(ATT), reinterpret_cast<unsigned char*>(ATT) + (size_t)R * tw * 2,
@@ -1623,6 +1707,24 @@ extern "C" int fern_gemm_mx8(fern_ctx* c, const uint8_t* A, int64_t lda, const u
     return run_gemm_b(c, p, (hipStream_t)stream);
 }
 
+extern "C" int fern_gemm_mx8_quant(fern_ctx* c, const uint8_t* A, int64_t lda, const uint8_t* scales_a, int64_t scale_rows_a, const uint8_t* W,
+                                   int64_t ldw, const uint8_t* scales_w, int64_t scale_rows_w, const float* bias, uint8_t* C8, int64_t ldc,
+                                   uint8_t* scales_c, int64_t scale_rows_c, int M, int N, int K, int epilogue, void* stream) {
+    if (!c || M < 0 || N < 0 || K <= 0) return fail(FERN_ERR_ARG, "fern_gemm_mx8_quant: bad argument");
+    if (M == 0 || N == 0) return FERN_OK;
+    if (!A || !W || !C8 || !scales_a || !scales_w || !scales_c) return fail(FERN_ERR_ARG, "fern_gemm_mx8_quant: NULL argument");
+    if (epilogue != FERN_EPI_BIAS && epilogue != FERN_EPI_BIAS_GELU) return fail(FERN_ERR_ARG, "fern_gemm_mx8_quant: epilogue must be BIAS or BIAS_GELU");
+    if (K % 128 || N % 128 || lda % 16 || ldw % 16 || ldc % 16 || scale_rows_a < M || scale_rows_w < N || scale_rows_c < M)
+        return fail(FERN_ERR_ARG, "fern_gemm_mx8_quant: K % 128, N % 128, lda / ldw / ldc % 16 must be 0, scale_rows >= rows");
+    HIP_TRY(hipSetDevice(c->device));
+    GemmParams p{};
+    p.Ab = reinterpret_cast<const unsigned short*>(A); p.lda = lda; p.Wb = reinterpret_cast<const unsigned short*>(W); p.ldw = ldw;
+    p.bias = bias; p.C = reinterpret_cast<float*>(C8); p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epilogue;
+    p.aload = ALOAD_PLAIN; p.fp8 = 2; p.mxa = scales_a; p.mxa_rows = scale_rows_a; p.mxw = scales_w; p.mxw_rows = scale_rows_w;
+    p.out_mx8 = 1; p.mxc = scales_c; p.mxc_rows = scale_rows_c;
+    return run_gemm_b(c, p, (hipStream_t)stream);
+}
+
 extern "C" int fern_layernorm(fern_ctx* c, const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                               int64_t rows, int d, float eps, void* stream) {
     if (!c || !x || !gamma || !beta || !y || rows < 0) return fail(FERN_ERR_ARG, "fern_layernorm: bad argument");
@@ -1686,7 +1788,8 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
         if (dump) std::fprintf(dump, "%d,%d,%d,%d,%d,%.6f,%.0f\n", r.kind, r.m, r.n, r.k, r.tag, ms, r.work);
         switch (r.kind) {
             case PROF_GEMM:
-                if (r.tag >= 200) { out->gemm_fp8_ms += ms; out->gemm_fp8_flops += r.work; out->gemm_fp8_launches++; }
+                if (r.tag >= 300) { out->gemm_mx8_ms += ms; out->gemm_mx8_flops += r.work; out->gemm_mx8_launches++; }
+                else if (r.tag >= 200) { out->gemm_fp8_ms += ms; out->gemm_fp8_flops += r.work; out->gemm_fp8_launches++; }
                 else if (r.tag >= 100) { out->gemm_bf16_ms += ms; out->gemm_bf16_flops += r.work; out->gemm_bf16_launches++; }
                 else { out->gemm_ms += ms; out->gemm_flops += r.work; out->gemm_launches++;
                        out->gemm_alg_bytes += 4.0 * ((double)r.m * r.k + (double)r.n * r.k + (double)r.m * r.n);

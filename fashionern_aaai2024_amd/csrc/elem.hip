@@ -193,12 +193,6 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const unsigned s
 // ---- MX (block-scaled) e4m3fn quantisers: one E8M0 byte per 32 consecutive k, the operand form of
 // v_mfma_scale_f32_32x32x64_f8f6f4 (gemm_bf16.hip: gemm_mx8_kernel).  e = the smallest power of two that brings the block's
 // maximum to <= 448, read off the maximum's exponent / mantissa bits (448 = 1.75 * 2^8); the scaling x * 2^(127-e) is exact.
-__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
-    const unsigned u = __float_as_uint(amax);
-    const int e = (int)(u >> 23) - 8 + ((u & 0x7FFFFFu) > 0x600000u ? 1 : 0);
-    return (unsigned)min(max(e, 1), 253);
-}
-__device__ __forceinline__ float mx_inv_scale(unsigned e) { return __uint_as_float((254u - e) << 23); }
 
 // LayerNorm fused with the MX quantiser (a lane holds 4 consecutive elements: a 32-block is 8 lanes)
 __global__ __launch_bounds__(256) void layernorm_mx8_kernel(const float* x, const float* gamma, const float* beta, unsigned char* y,

@@ -24,6 +24,7 @@ namespace fern {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef long i64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // FP8: the operands are OCP e4m3fn bytes and the MFMA is v_mfma_f32_32x32x16_fp8_fp8 (same rate as bf16, half the bytes):
 // a BKE-element tile row is then BKE bytes, one ds_read_b128 holds the fragments of TWO consecutive MFMA k-steps (low /
@@ -316,7 +317,57 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
         compute(slot);
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
-    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N, true>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
+    if (!p.out_mx8) {
+        gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N, true>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
+        return;
+    }
+    // Quantising epilogue: bias (+ GELU) in the accumulator layout (lane = column), then each 32x32 tile is turned through a
+    // private LDS patch so that a lane holds 16 consecutive columns of ONE row (2 lanes per row = one 32-column MX block):
+    // block maximum -> E8M0 byte -> 16 e4m3fn bytes, one 16-byte store per lane.
+    __syncthreads();                                         // every wave is done with the operand tiles
+    constexpr int PS = 36;                                   // patch row stride in floats (16-byte aligned rows)
+    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PS);
+    static_assert(NW * 32 * PS * 4 <= STAGES * TILE, "patches must fit the operand ring");
+    const int row_w = bm * BM + wm * WM, col_w = bn * BN + wn * WN;
+    const int rr = lane >> 1, hh = lane & 1;
+    unsigned char* C8 = reinterpret_cast<unsigned char*>(p.C);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row0 = row_w + i * 32, col0 = col_w + j * 32;            // wave-uniform
+            if (row0 >= p.M || col0 >= p.N) continue;
+            const float bia = p.bias ? p.bias[col0 + l31] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] + bia;
+                if (p.epi == EPI_BIAS_GELU) v = gelu_erf(v);
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PS + l31] = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the wave's own LDS writes, then its reads
+            f32x4 v4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const f32x4*>(patch + rr * PS + hh * 16 + q * 4);
+            float am = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(v4[q][e]));
+            am = fmaxf(am, __shfl_xor(am, 1));
+            const unsigned e8 = mx_scale_byte(am);
+            const float inv = mx_inv_scale(e8);
+            uint4 o;
+            o.x = pack4_fp8(v4[0][0] * inv, v4[0][1] * inv, v4[0][2] * inv, v4[0][3] * inv);
+            o.y = pack4_fp8(v4[1][0] * inv, v4[1][1] * inv, v4[1][2] * inv, v4[1][3] * inv);
+            o.z = pack4_fp8(v4[2][0] * inv, v4[2][1] * inv, v4[2][2] * inv, v4[2][3] * inv);
+            o.w = pack4_fp8(v4[3][0] * inv, v4[3][1] * inv, v4[3][2] * inv, v4[3][3] * inv);
+            const int row = row0 + rr;
+            if (row < p.M) {
+                *reinterpret_cast<uint4*>(C8 + (long)row * p.ldc + col0 + hh * 16) = o;
+                if (hh == 0) p.mxc[mx_scale_offset(row, col0 >> 5, p.mxc_rows)] = (unsigned char)e8;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // reads done before the next tile overwrites the patch
+        }
 }
 
 struct TileCfgB { int bm, bn, bk; };
@@ -404,7 +455,7 @@ static int forced_cfg_b() {
 // Per-shape tile selection, as in gemm.hip: every configuration produces bit-identical results, so the choice is purely a
 // speed choice; each new (M, N, K, epilogue) is timed once on scratch outputs (outside stream capture).
 struct ShapeKeyB {
-    int M, N, K, epi, ob;      // ob: bit 0 = bf16 output, bit 1 = fp8 operands, bit 2 = MX fp8 operands
+    int M, N, K, epi, ob;      // ob: bit 0 = bf16 output, bit 1 = fp8 operands, bit 2 = MX fp8 operands, bit 3 = MX fp8 output
     bool operator<(const ShapeKeyB& o) const {
         if (M != o.M) return M < o.M;
         if (N != o.N) return N < o.N;
@@ -470,21 +521,28 @@ static int tune_shape_b(const GemmParams& p, hipStream_t s) {
     (void)hipEventCreate(&e1);
     GemmParams q = p;
     q.C = scratch;            // the residual input is only read: tuning has no side effects on the caller's buffers
+    if (p.out_mx8) { q.mxc = reinterpret_cast<unsigned char*>(scratch) + (size_t)p.M * p.ldc; q.mxc_rows = p.M; }   // bytes [M*ldc, M*ldc + M*N/32)
+    // two rounds, each candidate keeps its faster time (the first launches after an idle spell run on ramping clocks)
+    const int ncand = p.fp8 == 2 ? kNumCfgsMx : f8 ? kNumCfgsF8 : kNumCfgsB;
+    float t[16];
+    for (float& v : t) v = 1e30f;
+    for (int round = 0; round < 2; ++round)
+        for (int c = 0; c < ncand; ++c) {
+            if (!f8 && p.K % kCfgsB[c].bk) continue;
+            if (launch(c, q, s) != hipSuccess) continue;                       // warm
+            (void)hipEventRecord(e0, s);
+            (void)launch(c, q, s);
+            (void)launch(c, q, s);
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) continue;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            t[c] = ms < t[c] ? ms : t[c];
+        }
     int best = fallback;
     float best_ms = 1e30f;
-    const int ncand = p.fp8 == 2 ? kNumCfgsMx : f8 ? kNumCfgsF8 : kNumCfgsB;
-    for (int c = 0; c < ncand; ++c) {
-        if (!f8 && p.K % kCfgsB[c].bk) continue;
-        if (launch(c, q, s) != hipSuccess) continue;                       // warm
-        (void)hipEventRecord(e0, s);
-        (void)launch(c, q, s);
-        (void)launch(c, q, s);
-        (void)hipEventRecord(e1, s);
-        if (hipEventSynchronize(e1) != hipSuccess) continue;
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best_ms) { best_ms = ms; best = c; }
-    }
+    for (int c = 0; c < ncand; ++c)
+        if (t[c] < best_ms) { best_ms = t[c]; best = c; }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(scratch);
@@ -501,12 +559,14 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     if (p.fp8 == 2) {
         if (!p.mxa || !p.mxw || p.scale_a || ((uintptr_t)p.mxa & 3) || ((uintptr_t)p.mxw & 3) || p.mxa_rows < p.M || p.mxw_rows < p.N)
             return hipErrorInvalidValue;
+        if (p.out_mx8 && (!p.mxc || p.mxc_rows < p.M || (p.N & 31) || (p.ldc & 15) || ((uintptr_t)p.C & 15) || (p.epi != EPI_BIAS && p.epi != EPI_BIAS_GELU)))
+            return hipErrorInvalidValue;
         static int forced = [] { const char* e = getenv("FERN_GEMM_MX8_CFG"); return e ? atoi(e) : -1; }();
         int c = forced;
         if (c < 0 || c >= kNumCfgsMx) {
             c = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) >= 256 ? 0 : 6;
             if (2.0 * p.M * (double)p.N * p.K >= 2.5e8) {
-                const ShapeKeyB key{p.M, p.N, p.K, p.epi, p.out_bf16 | 4};
+                const ShapeKeyB key{p.M, p.N, p.K, p.epi, p.out_bf16 | 4 | (p.out_mx8 ? 8 : 0)};
                 std::lock_guard<std::mutex> lock(g_tuned_b_mu);
                 auto it = g_tuned_b.find(key);
                 if (it == g_tuned_b.end()) it = g_tuned_b.emplace(key, tune_shape_b(p, s)).first;

@@ -96,6 +96,12 @@ struct GemmParams {
     const unsigned char* mxa;     // A's scales, mxa_rows >= M rows per 128-k tile
     const unsigned char* mxw;     // W's scales, mxw_rows >= N
     long mxa_rows, mxw_rows;
+    // out_mx8 (fp8 == 2, EPI_BIAS / EPI_BIAS_GELU, N % 32 == 0): the output is quantised where it is produced -- C holds e4m3fn
+    // bytes (ldc in bytes), mxc the E8M0 scales of its 32-column blocks (mx_scale_offset layout, mxc_rows rows): the next
+    // GEMM's A operand, with the same rounding as launch_quantize_mx8 applied to the fp32 values.
+    int out_mx8;
+    unsigned char* mxc;
+    long mxc_rows;
 };
 // MX scale layout of a [rows, K] fp8 matrix: scale byte of (row r, 32-k block b) lives at
 //   ((b / 4) * srows + r) * 4 + (b % 4)      (srows >= rows: the array's row count)
@@ -176,6 +182,14 @@ __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d
     int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
     return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
 }
+// MX quantiser arithmetic (elem.hip quantisers, gemm_bf16.hip quantising epilogue): the E8M0 byte of a block with maximum `amax`,
+// and the exact power-of-two factor that scales the block into e4m3 range
+__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
+    const unsigned u = __float_as_uint(amax);
+    const int e = (int)(u >> 23) - 8 + ((u & 0x7FFFFFu) > 0x600000u ? 1 : 0);
+    return (unsigned)min(max(e, 1), 253);
+}
+__device__ __forceinline__ float mx_inv_scale(unsigned e) { return __uint_as_float((254u - e) << 23); }
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {   // round to nearest even (finite inputs)
     unsigned u = __float_as_uint(f);
     u += 0x7fffu + ((u >> 16) & 1u);

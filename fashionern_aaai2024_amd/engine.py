@@ -21,8 +21,8 @@ COMBINER_TARGET, COMBINER_DVR_GLOBAL, COMBINER_DVR_LOCAL, COMBINER_DVR_FINAL = 0
 SR_TARGET, SR_DVR = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
 PART_DVR, PART_TARGET_SR, PART_TARGET_COMBINER, PART_ALL = 1, 2, 4, 7
-PREC_FP32, PREC_BF16, PREC_FP8 = 0, 1, 2
-_PREC_NAMES = {"fp32": PREC_FP32, "bf16": PREC_BF16, "fp8": PREC_FP8}
+PREC_FP32, PREC_BF16, PREC_FP8, PREC_MX8 = 0, 1, 2, 3
+_PREC_NAMES = {"fp32": PREC_FP32, "bf16": PREC_BF16, "fp8": PREC_FP8, "mx8": PREC_MX8}
 PATCH_NUM = 13
 
 
@@ -65,8 +65,8 @@ class FernEngine:
         return child
 
     def set_precision(self, precision) -> None:
-        """Operand precision of the CLIP towers' token-level GEMMs: "fp32" (parity mode, default) or "bf16" (perf mode:
-        bf16 operands, fp32 accumulation -- include/fern.h:fern_precision)."""
+        """Operand precision of the CLIP towers' token-level GEMMs: "fp32" (parity mode, default), "bf16", "fp8" (per-row
+        scales) or "mx8" (block-scaled fp8 on the scaled MFMA) -- include/fern.h:fern_precision."""
         prec = _PREC_NAMES[precision] if isinstance(precision, str) else int(precision)
         _lib.check(self.lib.fern_set_precision(self._h, prec), "fern_set_precision")
 
@@ -381,6 +381,17 @@ class FernEngine:
         _lib.check(self.lib.fern_gemm_mx8(self._h, _ptr(a8), k, _ptr(sa), sa.shape[1], _ptr(w8), k, _ptr(sw), sw.shape[1], _ptr(bias),
                                           _ptr(residual), _ptr(out), n, m, n, k, int(epilogue), int(bool(out_bf16)), _stream()), "fern_gemm_mx8")
         return out
+
+    def gemm_mx8_quant(self, a8, sa, w8, sw, bias=None, epilogue=EPI_BIAS):
+        """gemm_mx8 with the output quantised in the epilogue: returns (e4m3fn bytes [M,N], block scales [N/128, M, 4])."""
+        m, k = a8.shape
+        n = w8.shape[0]
+        bias = None if bias is None else self._f32(bias, (n,))
+        out = torch.empty(m, n, dtype=torch.uint8, device=self.device)
+        sc = torch.empty(n // 128, m, 4, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.fern_gemm_mx8_quant(self._h, _ptr(a8), k, _ptr(sa), sa.shape[1], _ptr(w8), k, _ptr(sw), sw.shape[1], _ptr(bias),
+                                                _ptr(out), n, _ptr(sc), m, m, n, k, int(epilogue), _stream()), "fern_gemm_mx8_quant")
+        return out, sc
 
     def layernorm(self, x, gamma, beta, eps: float, residual=None) -> torch.Tensor:
         x = self._f32(x)

@@ -119,8 +119,8 @@ def main(kind: str) -> None:
     p.add_argument("--seed", default=42, type=int)
     p.add_argument("--data-root", type=str, default=None,
                    help="directory holding fashion-iq/ (fiq, val), cirr_dataset/ (cirr), the shoes files (shoes) or the Fashion200k root (200k); default: synthetic data")
-    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp8"],
-                   help="encoder operand precision: fp32 = the reference's arithmetic; bf16 / fp8 = perf modes (ViT / text towers)")
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp8", "mx8"],
+                   help="encoder operand precision: fp32 = the reference's arithmetic; bf16 / fp8 / mx8 = perf modes (ViT / text towers)")
     args = p.parse_args()
     setup_seed(args.seed)
     device = torch.device("cuda")

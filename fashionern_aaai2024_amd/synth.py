@@ -167,6 +167,7 @@ CLIP_CONFIGS = {
     # small shapes for tests / fixtures (same arithmetic, seconds on CPU)
     "tiny": ClipConfig("tiny", 128, 64, 16, 128, 2, 4, 512, 77, 1000, 128, 4, 2, 512),
     "tiny-hd64": ClipConfig("tiny-hd64", 64, 48, 16, 192, 2, 3, 384, 77, 600, 128, 2, 2, 256),
+    "tiny-w256": ClipConfig("tiny-w256", 64, 48, 16, 256, 3, 4, 512, 77, 600, 128, 2, 2, 256),     # widths % 128 == 0 (block-scaled fp8 mode)
 }
 
 

@@ -86,7 +86,12 @@ typedef enum {
      * (max|row| / 448, computed where the row is produced) and one static scale per output channel of the weight, both
      * folded back in the fp32 epilogue; attention, and the fusion stage's BERT blocks, stay in the bf16 operand form (fp8 is
      * for the encoder GEMMs only).  Needs tower / MLP widths % 64 == 0. */
-    FERN_PREC_FP8 = 2
+    FERN_PREC_FP8 = 2,
+    /* The same block structure with BLOCK-SCALED (MX) fp8 operands on v_mfma_scale_f32_32x32x64_f8f6f4, gfx950's scaled MFMA at
+     * twice the bf16 / plain-fp8 matrix rate: one E8M0 (power-of-two) scale per (token, 32 consecutive channels) of the
+     * activations and per (output channel, 32 consecutive inputs) of the weights (fern_quantize_mx8), applied inside the MFMA --
+     * an outlier channel costs the precision of its own 32-block, not of the whole token row.  Needs tower / MLP widths % 128 == 0. */
+    FERN_PREC_MX8 = 3
 } fern_precision;
 
 typedef enum {
@@ -134,6 +139,9 @@ typedef struct {
     int64_t gemm_bf16_launches;
     double gemm_alg_bytes; /* algorithmic bytes of the fp32 GEMM launches counted in gemm_*: 4 (M K + N K + M N) each */
     int64_t gemm_dispatches; /* kernel dispatches behind gemm_launches (a bulk + remainder plan is two dispatches per launch) */
+    double gemm_mx8_ms;    /* block-scaled fp8 GEMM launches (FERN_PREC_MX8, fern_gemm_mx8): not included in any of the above */
+    double gemm_mx8_flops;
+    int64_t gemm_mx8_launches;
 } fern_prof_stats;
 
 FERN_API int fern_abi_version(void);
@@ -281,6 +289,12 @@ FERN_API int fern_quantize_mx8(fern_ctx* ctx, const void* x, int x_is_bf16, int6
 FERN_API int fern_gemm_mx8(fern_ctx* ctx, const uint8_t* A, int64_t lda, const uint8_t* scales_a, int64_t scale_rows_a, const uint8_t* W,
                   int64_t ldw, const uint8_t* scales_w, int64_t scale_rows_w, const float* bias, const float* residual, void* C,
                   int64_t ldc, int M, int N, int K, int epilogue, int out_bf16, void* stream);
+/* fern_gemm_mx8 whose output is quantised where it is produced: C8 [M, ldc] e4m3fn bytes + scales_c (the layout above, scale_rows_c
+ * rows) = fern_quantize_mx8 applied to the fp32 values bias + sum (+ GELU), bit for bit -- the A operand of the next
+ * fern_gemm_mx8.  N % 128 == 0, ldc % 16 == 0; epilogue BIAS or BIAS_GELU. */
+FERN_API int fern_gemm_mx8_quant(fern_ctx* ctx, const uint8_t* A, int64_t lda, const uint8_t* scales_a, int64_t scale_rows_a, const uint8_t* W,
+                        int64_t ldw, const uint8_t* scales_w, int64_t scale_rows_w, const float* bias, uint8_t* C8, int64_t ldc,
+                        uint8_t* scales_c, int64_t scale_rows_c, int M, int N, int K, int epilogue, void* stream);
 /* y = LayerNorm(x (+ residual)) * gamma + beta, rows of width d */
 FERN_API int fern_layernorm(fern_ctx* ctx, const float* x, const float* residual, const float* gamma,
                    const float* beta, float* y, int64_t rows, int d, float eps, void* stream);

@@ -88,7 +88,7 @@ def _attention(sd, prefix, x, heads, causal, prec=None, q_rows=None):
     still come from every token (reduced-precision operands, fp32 result)."""
     b, s, w = x.shape
     hd = w // heads
-    reduced = prec in ("bf16", "fp8")
+    reduced = prec in ("bf16", "fp8", "mx8")
     wi, bi = sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"]
     if q_rows is None:
         qkv = _r(_linear(x, wi, bi, prec), reduced)       # reduced precision: the packed projection is STORED as bf16
@@ -130,10 +130,11 @@ def _attention(sd, prefix, x, heads, causal, prec=None, q_rows=None):
 
 def _block(sd, prefix, x, heads, causal, prec=None):
     """Pre-LN residual block, modeling_clip.py:354-401; MLP :339-351 with exact GELU."""
-    reduced = prec in ("bf16", "fp8")
+    reduced = prec in ("bf16", "fp8", "mx8")
     x = x + _attention(sd, prefix + ".attn", _ln(sd, prefix + ".ln_1", x), heads, causal, prec)
     h = F.gelu(_linear(_ln(sd, prefix + ".ln_2", x), sd[prefix + ".mlp.c_fc.weight"], sd[prefix + ".mlp.c_fc.bias"], prec))
-    return x + _linear(_r(h, reduced), sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"], prec)   # h is stored as bf16
+    # h is stored as bf16 -- except in the block-scaled mode, whose c_fc GEMM quantises its fp32 GELU output in the epilogue
+    return x + _linear(_r(h, reduced and prec != "mx8"), sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"], prec)
 
 
 def _block_cls(sd, prefix, x, heads, prec):
@@ -191,10 +192,10 @@ def encode_image_resnet(sd, cfg, images):
 def encode_image(sd, cfg, images, precision="fp32"):
     """[b,3,H,W] f32 -> [b,embed_dim] un-normalised (call site utils/utils.py:64).
 
-    ``precision="bf16"`` / ``"fp8"`` restate the product's reduced-precision modes (no reference counterpart;
+    ``precision="bf16"`` / ``"fp8"`` / ``"mx8"`` restate the product's reduced-precision modes (no reference counterpart;
     include/fern.h:fern_precision): the same arithmetic with the operands of the token-level block GEMMs rounded to
-    bfloat16, or quantised to e4m3fn with per-token / per-channel scales."""
-    if precision not in ("fp32", "bf16", "fp8"):
+    bfloat16, quantised to e4m3fn with per-token / per-channel scales, or to e4m3fn with one E8M0 scale per 32-element block."""
+    if precision not in ("fp32", "bf16", "fp8", "mx8"):
         raise ValueError(precision)
     bf16 = precision != "fp32"
     prec = None if precision == "fp32" else precision

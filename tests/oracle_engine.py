@@ -21,7 +21,7 @@ class OracleEngine:
         self.precision = "fp32"
 
     def set_precision(self, precision):
-        if precision not in ("fp32", "bf16", "fp8"):
+        if precision not in ("fp32", "bf16", "fp8", "mx8"):
             raise ValueError(precision)
         self.precision = precision
 

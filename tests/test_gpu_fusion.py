@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from fashionern_aaai2024_amd import synth
+from fashionern_aaai2024_amd._lib import FernError
 from fashionern_aaai2024_amd.engine import (COMBINER_DVR_FINAL, COMBINER_DVR_GLOBAL, COMBINER_DVR_LOCAL, COMBINER_TARGET,
                                              SR_DVR, SR_TARGET, FernEngine)
 from oracle import clip as oclip
@@ -289,6 +290,61 @@ def test_clip_towers_fp8_precision(name, n):
     eng.close()
 
 
+@pytest.mark.parametrize("name,n", [("tiny-w256", 4), ("ViT-B-16", 3)])
+def test_clip_towers_mx8_precision(name, n):
+    """BASELINE config 5 on the block-scaled MFMA (fern_set_precision(MX8)): e4m3fn operands with one E8M0 scale per 32-element
+    block.  Kernels pinned in test_gpu_kernels.py (bit-exact quantiser, GEMM against exact arithmetic on the same bytes and
+    scales).  End to end: (1) against the oracle restating the same quantisation points (e4m3 rounding flips compound over the
+    layers, as in the per-row fp8 mode, so the agreement is loose but closer than to fp32); (2) against the fp32 oracle, the cost of
+    the mode; (3) batch invariance and a clean return to fp32."""
+    cfg = synth.CLIP_CONFIGS[name]
+    sd_np = synth.clip_state_dict(cfg, seed=11)
+    sd = ofusion.as_torch(sd_np)
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(sd_np)
+    eng.finalize_clip(cfg)
+    imgs = _t(synth.images(n, cfg))
+    toks = _t(synth.captions(n, cfg))
+    fp32_img = eng.encode_image(imgs)
+    eng.set_precision("mx8")
+    assert eng.precision == "mx8"
+    got = eng.encode_image(imgs)
+    g, s = eng.encode_text(toks)
+    assert torch.equal(eng.encode_image(imgs[1:2]), got[1:2])          # block scales are per token: still batch-invariant
+    assert torch.equal(eng.encode_text(toks[2:3])[0], g[2:3])
+    eng.set_precision("fp8")
+    got8 = eng.encode_image(imgs)
+    eng.set_precision("fp32")
+    assert torch.equal(eng.encode_image(imgs), fp32_img)
+
+    ref_q = oclip.encode_image(sd, cfg, imgs, precision="mx8")
+    ref_f = oclip.encode_image(sd, cfg, imgs)
+    rg_q, _ = oclip.encode_text(sd, cfg, toks, precision="mx8")
+    rg_f, _ = oclip.encode_text(sd, cfg, toks)
+
+    def cos_err(a, b):
+        return (1 - F.cosine_similarity(a.cpu().double(), b.double(), dim=-1)).abs().max().item()
+
+    print(f"mx8 {name}: vs restatement {cos_err(got, ref_q):.2e} / {cos_err(g, rg_q):.2e}, vs fp32 {cos_err(got, ref_f):.2e} / {cos_err(g, rg_f):.2e}, "
+          f"per-row fp8 vs fp32 {cos_err(got8, ref_f):.2e}")
+    assert cos_err(got, ref_q) < 2e-3 and cos_err(g, rg_q) < 2e-3      # same quantisation points
+    assert cos_err(got, ref_q) < cos_err(got, ref_f) and cos_err(g, rg_q) < cos_err(g, rg_f)
+    assert cos_err(got, ref_f) < 1e-2 and cos_err(g, rg_f) < 1e-2
+    assert cos_err(got, ref_f) > 1e-5
+    eng.close()
+
+
+def test_mx8_precision_needs_widths_that_are_multiples_of_128():
+    cfg = synth.CLIP_CONFIGS["tiny-hd64"]                              # ViT width 192
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(synth.clip_state_dict(cfg, seed=1))
+    eng.finalize_clip(cfg)
+    with pytest.raises(FernError, match="multiples of 128"):
+        eng.set_precision("mx8")
+    assert eng.precision == "fp32"
+    eng.close()
+
+
 def test_fp8_precision_needs_widths_that_are_multiples_of_64():
     cfg = synth.CLIP_CONFIGS["tiny"]
     eng = FernEngine("cuda:0")
@@ -313,7 +369,7 @@ def test_dvr_fuse_reduced_precision(d, b, t):
     ref_b = ofusion.dvr_fuse(sd, rl, ts, rg, tg, precision="bf16")
     ref_f = ofusion.dvr_fuse(sd, rl, ts, rg, tg)
     try:
-        for prec in ("bf16", "fp8"):
+        for prec in ("bf16", "fp8", "mx8"):
             eng.set_precision(prec)
             got = eng.dvr_fuse(rg, rl, tg, ts)
             assert torch.equal(eng.dvr_fuse(rg[1:2], rl[1:2], tg[1:2], ts[1:2]), got[1:2])      # batch-invariant
@@ -325,11 +381,11 @@ def test_dvr_fuse_reduced_precision(d, b, t):
     assert torch.equal(eng.dvr_fuse(rg, rl, tg, ts), fp32)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp8"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp8", "mx8"])
 def test_encoders_chunk_large_batches_without_changing_rows(precision):
     """Batches larger than the internal chunk (64 images, 256 captions, 256 fusion rows) are processed in pieces: every row
     must equal the row computed alone, in every precision mode (workspace reuse across chunks, scale buffers, bf16 copies)."""
-    cfg = synth.CLIP_CONFIGS["tiny-hd64"]
+    cfg = synth.CLIP_CONFIGS["tiny-w256" if precision == "mx8" else "tiny-hd64"]
     d = cfg.embed_dim
     eng = FernEngine("cuda:0")
     eng.load_tensors(synth.clip_state_dict(cfg, seed=8))

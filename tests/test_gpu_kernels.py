@@ -348,6 +348,23 @@ def test_gemm_fp8(engine, m, n, k, epi, out_bf16):
         assert torch.equal(gi.cpu(), ai @ wi.T)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(64, 128, 128), (197, 384, 256), (1000, 512, 640), (4097, 3072, 768)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_gemm_mx8_quantising_epilogue_is_the_quantiser_applied_to_the_fp32_output(engine, m, n, k, epi):
+    """fern_gemm_mx8_quant == fern_quantize_mx8(fern_gemm_mx8(... fp32 output)), bytes and scales, bit for bit."""
+    g = torch.Generator().manual_seed(m + n + k + epi)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * k ** -0.5
+    b = torch.randn(n, generator=g)
+    a8, sa = engine.quantize_mx8(a)
+    w8, sw = engine.quantize_mx8(w)
+    q_ref, s_ref = engine.quantize_mx8(engine.gemm_mx8(a8, sa, w8, sw, b, epilogue=epi))
+    q, sc = engine.gemm_mx8_quant(a8, sa, w8, sw, b, epilogue=epi)
+    assert torch.equal(sc, s_ref)
+    assert torch.equal(q, q_ref)
+
+
 def _mx_scales_by_block(sc):
     """engine.quantize_mx8's [D/128, R, 4] scale array -> [R, D/32] (block b = k // 32)."""
     return sc.permute(1, 0, 2).reshape(sc.shape[1], -1)

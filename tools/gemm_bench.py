@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--shapes", default="all")
     ap.add_argument("--bf16", action="store_true", help="bf16-operand kernel (FERN_GEMM_BF16_CFG picks the tile)")
+    ap.add_argument("--fp8", action="store_true", help="per-row-scaled fp8 kernel (FERN_GEMM_FP8_CFG)")
+    ap.add_argument("--mx8", action="store_true", help="block-scaled fp8 kernel (FERN_GEMM_MX8_CFG)")
     args = ap.parse_args()
     eng = FernEngine("cuda:0")
     groups = SHAPES if args.shapes == "all" else {args.shapes: SHAPES[args.shapes]}
@@ -37,7 +39,14 @@ def main():
             w = torch.randn(n, k, device="cuda") * k ** -0.5
             b = torch.randn(n, device="cuda")
             r = torch.randn(m, n, device="cuda") if epi == 3 else None
-            if args.bf16:
+            if args.fp8 or args.mx8:
+                if epi == 2 or k % 128:
+                    continue
+                quant, gemm = (eng.quantize_mx8, eng.gemm_mx8) if args.mx8 else (eng.quantize_rows_fp8, eng.gemm_fp8)
+                (a8, sa), (w8, sw) = quant(a), quant(w)
+                out_b = epi in (0, 1)
+                run = lambda: gemm(a8, sa, w8, sw, b, residual=r, epilogue=epi, out_bf16=out_b)  # noqa: E731
+            elif args.bf16:
                 ab, wb = eng.to_bf16(a), eng.to_bf16(w)
                 out_b = epi in (0, 1)
                 run = lambda: eng.gemm_bf16(ab, wb, b, residual=r, epilogue=epi, out_bf16=out_b)  # noqa: E731
