@@ -1113,8 +1113,13 @@ static int clip_block_mx8(fern_ctx* c, const ClipBlockW& Bk, float* X, unsigned 
     FERN_TRY(run_gemm_b(c, gemm_desc_mx(XN8, SM, R, width, Bk.qkv, QKVb, 3 * width, (int)R, EPI_BIAS, true), s));
     AttnParams a{nullptr, nullptr, nullptr, nullptr, 3L * width, 3L * width, 3L * width, (long)width,
                  batch, heads, hd, S, S, causal, 1.0f / std::sqrt((float)hd), ATTb, QKVb, QKVb + width, QKVb + 2 * width};
-    FERN_TRY(run_attention(c, a, s));
-    HIP_TRY(launch_quantize_mx8(ATTb, nullptr, width, ATT8, width, SM, R, R, width, s));
+    if (hd % 32 == 0) {      // the attention kernel quantises its fp32 output itself (the QKV GEMM is done with SM by now)
+        a.out_b = nullptr; a.out_q8 = ATT8; a.out_scales = SM; a.out_srows = R;
+        FERN_TRY(run_attention(c, a, s));
+    } else {
+        FERN_TRY(run_attention(c, a, s));
+        HIP_TRY(launch_quantize_mx8(ATTb, nullptr, width, ATT8, width, SM, R, R, width, s));
+    }
     GemmParams po = gemm_desc_mx(ATT8, SM, R, width, Bk.out, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
     po.R = X;
     FERN_TRY(run_gemm_b(c, po, s));

@@ -268,7 +268,28 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(AttnParams p) {
         }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
-        if (qi < p.s_q) {
+        if (p.out_q8) {
+            // block-scaled fp8 output (the out-projection's MX operand): the two lanes of a query (halves 0 / 1) hold the 32 values
+            // of a d block between them -- block maximum, E8M0 byte, 16 e4m3fn bytes per lane (hd % 32 == 0 on this path)
+            const long orow = (long)b * p.s_q + qi;
+#pragma unroll
+            for (int db = 0; db < HDP / 32; ++db) {
+                float am = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(o[db][r] * inv));
+                am = fmaxf(am, __shfl_xor(am, 32));
+                const unsigned e8 = mx_scale_byte(am);
+                const float qs = mx_inv_scale(e8);
+                if (qi < p.s_q && db * 32 < hd) {
+                    unsigned char* o8 = p.out_q8 + orow * p.ldo + (long)h * hd + db * 32 + 4 * lh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<unsigned*>(o8 + 8 * g) = pack4_fp8(o[db][4 * g] * inv * qs, o[db][4 * g + 1] * inv * qs,
+                                                                             o[db][4 * g + 2] * inv * qs, o[db][4 * g + 3] * inv * qs);
+                    if (lh == 0) p.out_scales[mx_scale_offset(orow, (h * hd + db * 32) >> 5, p.out_srows)] = (unsigned char)e8;
+                }
+            }
+        } else if (qi < p.s_q) {
             unsigned short* ob = p.out_b + ((long)b * p.s_q + qi) * p.ldo + (long)h * hd;
 #pragma unroll
             for (int db = 0; db < HDP / 32; ++db)
@@ -348,7 +369,7 @@ static hipError_t launch_hd(const AttnParams& p, hipStream_t s) {
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.batch <= 0 || p.heads <= 0 || p.s_q <= 0 || p.s_k <= 0) return hipErrorInvalidValue;
     if (p.qb || p.kb || p.vb) {
-        if (!p.qb || !p.kb || !p.vb || !p.out_b || (p.hd & 7) || (p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3)) return hipErrorInvalidValue;
+        if (!p.qb || !p.kb || !p.vb || (!p.out_b && !p.out_q8) || (p.out_q8 && (!p.out_scales || (p.hd & 31))) || (p.hd & 7) || (p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3)) return hipErrorInvalidValue;
         if (p.causal && p.s_q != p.s_k) return hipErrorInvalidValue;
         if (p.hd <= 32) return launch_hd_b<32>(p, s);
         if (p.hd <= 64) return launch_hd_b<64>(p, s);

@@ -209,6 +209,11 @@ struct AttnParams {
     const unsigned short* qb;
     const unsigned short* kb;
     const unsigned short* vb;
+    // bf16 operand form with a block-scaled fp8 output instead of out_b (MX operand of the out-projection; hd % 32 == 0): e4m3fn
+    // bytes (ldo in bytes) + E8M0 scales in the mx_scale_offset layout, quantised from the fp32 output values
+    unsigned char* out_q8;
+    unsigned char* out_scales;
+    long out_srows;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);   // hipErrorInvalidValue for unsupported shapes
 

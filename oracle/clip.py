@@ -106,7 +106,8 @@ def _attention(sd, prefix, x, heads, causal, prec=None, q_rows=None):
                 att = att + torch.full((s, s), float("-inf")).triu(1)
             e = torch.exp(att - att.max(dim=-1, keepdim=True).values)
             o = (_r(e, True) @ v) / e.sum(dim=-1, keepdim=True)
-            o = _r(o.transpose(1, 2).reshape(b, s, w), True)
+            # stored as bf16 -- in the block-scaled mode the kernel quantises the fp32 values itself (head_dim % 32 == 0)
+            o = _r(o.transpose(1, 2).reshape(b, s, w), not (prec == "mx8" and hd % 32 == 0))
             return _linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"], prec)
     else:
         k, v = _linear(x, wi[w:], bi[w:], prec).split(w, dim=-1)
