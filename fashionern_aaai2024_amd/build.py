@@ -103,10 +103,12 @@ def ensure_built() -> str:
     """Return the library path, building it if hipcc is available and it is missing/stale."""
     if _stale():
         try:
-            build_lib()
+            _hipcc()
         except RuntimeError:
-            if not os.path.exists(LIB):
-                raise
+            if os.path.exists(LIB):
+                return LIB      # no toolchain on this machine: use the library that travelled with the tree
+            raise
+        build_lib()             # a failing compile (or a kernel that spills) is an error, never a silent fall-back to the old library
     return LIB
 
 

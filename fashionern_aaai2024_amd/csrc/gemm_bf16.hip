@@ -176,15 +176,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MINW>
+template <int BM, int BN, int WM, int WN, int STAGES, int MINW, int RB = 128>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_kernel(GemmParams p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int ROWS = BM + BN;
-    constexpr int RB = 128;                              // bytes (= k) per tile row
-    constexpr int RPP = 8;                               // tile rows per 1 KiB piece
+    static_assert(RB == 128 || RB == 64, "tile rows are one or two 64-k MFMA steps");   // RB: bytes (= k) per tile row
+    constexpr int C4 = RB / 16;                          // 16-byte chunks per tile row
+    constexpr int RPP = 64 / C4;                         // tile rows per 1 KiB piece
+    constexpr int FSH = RB == 64 ? 2 : 1;                // chunk c of row r lives at position c ^ ((r >> FSH) & FMASK)
+    constexpr int FMASK = C4 - 1;
     constexpr int PIECES = ROWS / RPP;
     static_assert(PIECES % NW == 0, "pieces must divide over the waves");
     constexpr int PPW = PIECES / NW;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
     constexpr int SPW = (SP + NW - 1) / NW;              // per wave (the surplus re-stages a piece: same bytes, same place)
     constexpr int DATA = ROWS * RB;
     constexpr int TILE = (DATA + ROWS * 4 + 1023) / 1024 * 1024;   // bytes per stage: rows, then one scale dword per row
-    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
 
     __shared__ __attribute__((aligned(1024))) char smem[STAGES * TILE];
 
@@ -213,8 +216,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int piece = wave + NW * j;
-        const int trow = piece * RPP + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((trow >> 1) & 7);
+        const int trow = piece * RPP + lane / C4;
+        const int chunk = (lane & FMASK) ^ ((trow >> FSH) & FMASK);
         if (trow < BM) {
             int row = bm * BM + trow;
             row = row < p.M ? row : p.M - 1;
@@ -253,7 +256,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
 #pragma unroll
         for (int j = 0; j < SPW; ++j) {
             const int sp = (wave + NW * j) % SP;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc[j] + kt * sstep[j]),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc[j] + (RB == 64 ? kt >> 1 : kt) * sstep[j]),
                                              (__attribute__((address_space(3))) void*)(smem + buf * TILE + DATA + sp * 256), 4, 0, 0);
         }
     };
@@ -266,18 +269,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int sw = (l31 >> 1) & 7;
-    auto compute = [&](int buf) {
+    const int sw = (l31 >> FSH) & FMASK;
+    auto compute = [&](int buf, int kt) {
         const char* As = smem + buf * TILE;
         const char* Ws = As + BM * RB;
         const unsigned* Ss = reinterpret_cast<const unsigned*>(As + DATA);
         int sa[TM], sb[TN];
+        const int sh = RB == 64 ? 16 * (kt & 1) + 8 * lh : 8 * lh;       // 64-byte rows: a tile is ONE step, the dword covers two tiles
 #pragma unroll
-        for (int i = 0; i < TM; ++i) sa[i] = (int)(Ss[wm * WM + i * 32 + l31] >> (8 * lh));
+        for (int i = 0; i < TM; ++i) sa[i] = (int)(Ss[wm * WM + i * 32 + l31] >> sh);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) sb[j] = (int)(Ss[BM + wn * WN + j * 32 + l31] >> (8 * lh));
+        for (int j = 0; j < TN; ++j) sb[j] = (int)(Ss[BM + wn * WN + j * 32 + l31] >> sh);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {                           // the two 64-k MFMA steps of a 128-k tile
+        for (int e = 0; e < RB / 64; ++e) {                     // the 64-k MFMA steps of a tile
             const int pc0 = ((4 * e + lh) ^ sw) * 16, pc1 = ((4 * e + 2 + lh) ^ sw) * 16;     // k = 16h .. +15 and 32 + 16h .. +15
             i32x8 af[TM], bf[TN];
 #pragma unroll
@@ -306,7 +310,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
         if (t < nk) stage(t, t);
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (STAGES == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + SPW) : "memory");
+        // tiles kt+1 .. kt+STAGES-2 may stay in flight; near the end fewer have been issued
+        const int younger = nk - 1 - kt < STAGES - 2 ? nk - 1 - kt : STAGES - 2;
+        if (STAGES >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PPW + SPW)) : "memory");
+        else if (STAGES >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + SPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kt + STAGES - 1 < nk) {
@@ -314,7 +321,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
             fill = fill >= STAGES ? fill - STAGES : fill;
             stage(fill, kt + STAGES - 1);
         }
-        compute(slot);
+        compute(slot, kt);
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
     if (!p.out_mx8) {
@@ -426,8 +433,11 @@ static const TileCfgB kCfgsMx[] = {
     {128, 64, 128},    // 5: 4 waves of 64x32
     {64, 64, 128},     // 6: 4 waves of 32x32
     {256, 256, 128},   // 7: 16 waves of 64x64, 2 stages (132 KiB)
+    {128, 128, 64},    // 8: as 0 with 64-byte rows (one MFMA step per barrier), 3 stages: 50 KiB, 3 workgroups per CU
+    {256, 128, 64},    // 9: as 1 with 64-byte rows, 3 stages: 75 KiB, 2 workgroups per CU (needs <= 128 VGPRs)
+    {256, 256, 64},    // 10: 8 waves of 128x64, 64-byte rows, 4 stages (136 KiB): fewest staged bytes per FLOP, deep prefetch instead of occupancy
 };
-constexpr int kNumCfgsMx = 8;
+constexpr int kNumCfgsMx = 11;
 static hipError_t launch_cfg_mx(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsMx[c].bm - 1) / kCfgsMx[c].bm) * ((p.N + kCfgsMx[c].bn - 1) / kCfgsMx[c].bn);
     switch (c) {
@@ -439,6 +449,9 @@ static hipError_t launch_cfg_mx(int c, const GemmParams& p, hipStream_t s) {
         case 5: hipLaunchKernelGGL((gemm_mx8_kernel<128, 64, 64, 32, 2, 3>), dim3(nb), dim3(256), 0, s, p); break;
         case 6: hipLaunchKernelGGL((gemm_mx8_kernel<64, 64, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
         case 7: hipLaunchKernelGGL((gemm_mx8_kernel<256, 256, 64, 64, 2, 1>), dim3(nb), dim3(1024), 0, s, p); break;
+        case 8: hipLaunchKernelGGL((gemm_mx8_kernel<128, 128, 64, 64, 3, 3, 64>), dim3(nb), dim3(256), 0, s, p); break;
+        case 9: hipLaunchKernelGGL((gemm_mx8_kernel<256, 128, 64, 64, 3, 4, 64>), dim3(nb), dim3(512), 0, s, p); break;
+        case 10: hipLaunchKernelGGL((gemm_mx8_kernel<256, 256, 128, 64, 4, 2, 64>), dim3(nb), dim3(512), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

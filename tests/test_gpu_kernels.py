@@ -436,7 +436,7 @@ def test_gemm_mx8(engine, m, n, k, epi, out_bf16):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("var,cfg", [("FERN_GEMM_BF16_CFG", c) for c in range(7)] + [("FERN_GEMM_FP8_CFG", c) for c in range(6)] +
-                         [("FERN_GEMM_MX8_CFG", c) for c in range(8)])
+                         [("FERN_GEMM_MX8_CFG", c) for c in range(11)])
 def test_every_reduced_precision_gemm_tile_variant(var, cfg):
     """The bf16 / fp8 launchers pick (or tune) a tile per shape; each variant is also forced over its shape suite."""
     import os
