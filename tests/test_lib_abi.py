@@ -33,6 +33,11 @@ def test_ctypes_loader_and_error_reporting_without_gpu():
     assert lib.fern_finalize_fusion(None, 512, 7) == -1
     assert b"ctx is NULL" in lib.fern_last_error()
     assert lib.fern_load_tensor(None, b"x", None, 0, 0, None) == -1
+    # the block-scaled fp8 entry points validate before touching the device too
+    assert lib.fern_quantize_mx8(None, None, 0, 0, None, 0, None, 0, 0, 128, None) == -1
+    assert lib.fern_gemm_mx8(None, None, 0, None, 0, None, 0, None, 0, None, None, None, 0, 1, 1, 128, 0, 0, None) == -1
+    assert lib.fern_gemm_mx8_quant(None, None, 0, None, 0, None, 0, None, 0, None, None, 0, None, 0, 1, 128, 128, 0, None) == -1
+    assert b"fern_gemm_mx8_quant" in lib.fern_last_error()
 
 
 def test_code_object_targets_gfx950_only():

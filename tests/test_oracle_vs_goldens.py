@@ -184,3 +184,38 @@ def test_chain_oracle_is_an_exact_fma_chain_in_the_kernels_k_order():
     for b in range(3):
         for a, c in zip(i[b][:-1], i[b][1:]):
             assert s[b][list(i[b]).index(a)] > s[b][list(i[b]).index(c)] or a < c
+
+
+def test_mx8_quantiser_restatement_known_answers_and_exactness():
+    """oracle/clip.py: mx8_quantize / mx8_dequantize (the product's block-scaled fp8 mode has no reference counterpart; this pins
+    the restatement the GPU tests compare with bit for bit): hand-computed scale bytes and element bytes, power-of-two exactness,
+    the no-clipping bound, and dequantised error within half an e4m3 step of the block maximum."""
+    from oracle.clip import mx8_dequantize, mx8_quantize
+    x = torch.zeros(4, 64)
+    x[0, 0] = 448.0                    # block max 448 = 1.75 * 2^8: scale 2^0 (byte 127), element 0x7E (largest finite e4m3fn)
+    x[0, 1] = 1.0                      # -> 1.0 = 0x38
+    x[0, 32] = 449.0                   # next block: max just above 448 -> scale 2^1 (byte 128), 224.5 rounds to 224 = 0x76
+    x[1, 0] = 1.0                      # max 1.0 -> scale 2^-8 (byte 119): element 256 = 0x78
+    x[1, 32] = 0.4375                  # 0.4375 = 1.75 * 2^-2 -> scale byte 117, element 448 = 0x7E
+    x[2, :32] = torch.arange(32) - 16.0                     # integers up to 16 in magnitude: scale 2^-4 (byte 123), exact
+    x[3, 5] = -3.0e-5
+    q, e = mx8_quantize(x)
+    qb = q.view(torch.uint8)
+    assert e[0].tolist() == [127, 128] and qb[0, 0] == 0x7E and qb[0, 1] == 0x38 and qb[0, 32] == 0x76
+    assert e[1].tolist() == [119, 117] and qb[1, 0] == 0x78 and qb[1, 32] == 0x7E
+    assert e[2, 0] == 123 and e[2, 1] == 1 and int(qb[2, 32:].max()) == 0        # an all-zero block: byte 1, zeros
+    dq = mx8_dequantize(q, e)
+    assert torch.equal(dq[2], x[2]) and torch.equal(dq[1], x[1])                 # representable values survive exactly
+    assert dq[0, 32] == 448.0 and dq[0, 0] == 448.0
+    assert (dq[3, 5] - x[3, 5]).abs() <= abs(x[3, 5].item()) * 2.0 ** -4
+    # random data over 12 orders of magnitude: nothing clipped (|q| <= 448, top binade used), error <= 2^-4 of the block maximum
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn(64, 256, generator=g) * torch.logspace(-6, 6, 64).unsqueeze(1)
+    q, e = mx8_quantize(y)
+    qa = q.float().abs().reshape(64, 8, 32).amax(-1)
+    assert (qa <= 448).all() and (qa >= 224).all()                                # (224, 448] before the cast rounds
+    blk = y.reshape(64, 8, 32)
+    assert ((mx8_dequantize(q, e).reshape(64, 8, 32) - blk).abs() <= blk.abs().amax(-1, keepdim=True) * 2.0 ** -4).all()
+    # scaling a block by a power of two moves the scale byte and nothing else
+    q2, e2 = mx8_quantize(y * 8.0)
+    assert torch.equal(q2.view(torch.uint8), q.view(torch.uint8)) and torch.equal(e2.int(), e.int() + 3)
