@@ -346,10 +346,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
             if (row0 >= p.M || col0 >= p.N) continue;
             const float bia = p.bias ? p.bias[col0 + l31] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r] + bia;
-                if (p.epi == EPI_BIAS_GELU) v = gelu_erf(v);
-                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PS + l31] = v;
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 v2 = {acc[i][j][r] + bia, acc[i][j][r + 1] + bia};
+                if (p.epi == EPI_BIAS_GELU) v2 = gelu_fast2(v2);
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PS + l31] = v2[0];
+                patch[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh) * PS + l31] = v2[1];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the wave's own LDS writes, then its reads
             f32x4 v4[4];

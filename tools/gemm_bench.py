@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="bf16-operand kernel (FERN_GEMM_BF16_CFG picks the tile)")
     ap.add_argument("--fp8", action="store_true", help="per-row-scaled fp8 kernel (FERN_GEMM_FP8_CFG)")
     ap.add_argument("--mx8", action="store_true", help="block-scaled fp8 kernel (FERN_GEMM_MX8_CFG)")
+    ap.add_argument("--mx8q", action="store_true", help="with --mx8: quantising epilogue (fp8 + block scales out) on the BIAS / GELU shapes")
     args = ap.parse_args()
     eng = FernEngine("cuda:0")
     groups = SHAPES if args.shapes == "all" else {args.shapes: SHAPES[args.shapes]}
@@ -46,6 +47,8 @@ def main():
                 (a8, sa), (w8, sw) = quant(a), quant(w)
                 out_b = epi in (0, 1)
                 run = lambda: gemm(a8, sa, w8, sw, b, residual=r, epilogue=epi, out_bf16=out_b)  # noqa: E731
+                if args.mx8 and args.mx8q and epi in (0, 1):
+                    run = lambda: eng.gemm_mx8_quant(a8, sa, w8, sw, b, epilogue=epi)  # noqa: E731
             elif args.bf16:
                 ab, wb = eng.to_bf16(a), eng.to_bf16(w)
                 out_b = epi in (0, 1)
