@@ -12,17 +12,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int ROWS_PER_BLOCK = 4;   // 4 waves per workgroup, one row each
 constexpr int MAXV = 5;             // row width <= 64 lanes * 4 floats * MAXV = 1280 (2 x 640 for the CLIP4Cir Combiner)
 
+// Wave-wide reductions on the DPP network (quad swaps, half-row and row mirrors: every lane then holds its 16-lane row's value) plus
+// four readlanes added in a fixed order -- ~10 issue slots, against six dependent ds_bpermute round trips (~100 cycles each) for the
+// __shfl_xor butterfly.  The row kernels are one wave per row with two or three reductions each: that latency, not the bytes, was
+// most of a LayerNorm launch.  Results are the same for every lane and depend only on the row (batch-invariant).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }   // (readlane is an int builtin)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_move<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);      // row_half_mirror
+    v += dpp_move<0x140>(v);      // row_mirror
+    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
 }
-
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    v = fmaxf(v, dpp_move<0x140>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
+// maximum over the aligned group of 4 / 8 consecutive lanes (the lanes that share a 32-element MX block)
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    return fmaxf(v, dpp_move<0x4E>(v));
+}
+__device__ __forceinline__ float oct_max(float v) { v = quad_max(v); return fmaxf(v, dpp_move<0x141>(v)); }
 
 // A row of width d (d % 4 == 0, d <= 1024) held as up to MAXV float4 per lane: element c = (i*64 + lane)*4.
 struct RowRegs {
@@ -208,8 +226,7 @@ __global__ __launch_bounds__(256) void layernorm_mx8_kernel(const float* x, cons
     for (int i = 0; i < MAXV; ++i) {
         const int c = (i * 64 + lane) * 4;
         float am = fmaxf(fmaxf(fabsf(r.v[i][0]), fabsf(r.v[i][1])), fmaxf(fabsf(r.v[i][2]), fabsf(r.v[i][3])));
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
+        am = oct_max(am);
         if (c < d) {
             const unsigned e = mx_scale_byte(am);
             const float inv = mx_inv_scale(e);
@@ -246,8 +263,7 @@ __global__ __launch_bounds__(256) void quantize_mx8_kernel(const unsigned short*
         float am = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(v[e]));
-        am = fmaxf(am, __shfl_xor(am, 1));
-        am = fmaxf(am, __shfl_xor(am, 2));
+        am = quad_max(am);
         if (c < d) {
             const unsigned e8 = mx_scale_byte(am);
             const float inv = mx_inv_scale(e8);
