@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmParams p) {
             if (row0 + r >= p.M) continue;
             float v = acc[t][r] + bia;
             switch (p.epi) {
-                case EPI_BIAS_GELU: v = gelu_erf(v); break;
+                case EPI_BIAS_GELU: v = gelu_erf2(f32x2{v, v})[0]; break;      // the 32x32 kernels' arithmetic, bit for bit
                 case EPI_BIAS_RELU: v = fmaxf(v, 0.0f); break;
                 case EPI_BIAS_RESIDUAL: v += add[r]; break;
                 case EPI_BIAS_RESIDUAL_RELU: v = fmaxf(v + add[r], 0.0f); break;

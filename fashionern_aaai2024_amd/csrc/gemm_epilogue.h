@@ -12,17 +12,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // fp32 rounding level) evaluated branch-free: 1 + erf(z) = 2 - P(t) e^{-z^2} for z >= 0 and P(t) e^{-z^2} for z < 0
 // (t = 1 / (1 + p |z|)), which also avoids the cancellation of 1 + erf(z) in the negative tail.  ~15 VALU ops per
 // element instead of the ~45 of libm's erff: the GELU epilogue of the 3072-wide MLP GEMMs was VALU-bound.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = x * 0.70710678118654752440f;
-    const float az = fabsf(z);
-    const float t = __frcp_rn(fmaf(0.3275911f, az, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float pe = poly * t * __expf(-az * az);
-    const float cdf2 = z >= 0.0f ? 2.0f - pe : pe;
-    return 0.5f * x * cdf2;
+// Evaluated on two elements at a time: the polynomial and the products compile to packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32), the
+// reciprocal is the hardware's 1-ulp v_rcp_f32 rather than a correctly rounded division (a 6e-8 relative change of t, below the
+// formula's own 1.5e-7) and the exponential is v_exp_f32 on a pre-scaled argument: ~17 issue slots per element (the scalar form with
+// a correctly rounded division took ~30, libm's erff ~45).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 z = x * 0.70710678118654752440f;
+    const f32x2 az = __builtin_elementwise_abs(z);
+    const f32x2 d = az * 0.3275911f + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 poly = t * 1.061405429f + -1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + -0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const f32x2 m = az * az * -1.4426950408889634f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(m[0]), __builtin_amdgcn_exp2f(m[1])};
+    const f32x2 pe = poly * t * e;
+    const f32x2 cdf2 = {z[0] >= 0.0f ? 2.0f - pe[0] : pe[0], z[1] >= 0.0f ? 2.0f - pe[1] : pe[1]};
+    return x * 0.5f * cdf2;
 }
 
 // GELU of the reduced-precision GEMM family (bf16 / fp8 / block-scaled fp8 operands: outputs are rounded to bf16 or fp8, or feed a
@@ -32,7 +40,6 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // float2 so that the polynomial and the four squarings compile to packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32): ~11 issue slots
 // per element against ~30 for gelu_erf (two quarter-rate transcendentals and a correctly rounded division) -- the GELU epilogue,
 // not the MFMA loop, was the longest phase of the block-scaled c_fc GEMM.  |gelu_fast - exact| <= 8.2e-7 over [-12, 12] (fp32).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
     const f32x2 z = x * 0.70710678118654752440f;
     const f32x2 az = __builtin_elementwise_abs(z);
@@ -101,21 +108,17 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16&
             else Ct[(long)ru * p.ldc + loff] = v;
         }
     };
-    if (EPI == EPI_BIAS_GELU && FAST) {                      // two elements per packed instruction, stored as they are produced
+    if (EPI == EPI_BIAS_GELU) {                              // two elements per packed instruction, stored as they are produced
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const f32x2 v2 = {SCALED ? acc[r] * qs[r] + bia : acc[r] + bia, SCALED ? acc[r + 1] * qs[r + 1] + bia : acc[r + 1] + bia};
-            const f32x2 g2 = gelu_fast2(v2);
+            const f32x2 g2 = FAST ? gelu_fast2(v2) : gelu_erf2(v2);
             emit(r, g2[0]);
             emit(r + 1, g2[1]);
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = SCALED ? acc[r] * qs[r] + bia : acc[r] + bia;
-            if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
-            emit(r, v);
-        }
+        for (int r = 0; r < 16; ++r) emit(r, SCALED ? acc[r] * qs[r] + bia : acc[r] + bia);
     }
 }
 
