@@ -248,8 +248,7 @@ def main():
             return block[:n_gal]
         if gloo:
             full = torch.empty((world * per, D), dtype=block.dtype)
-            dist.all_gather_into_tensor(full.view(torch.int16) if block.dtype == torch.bfloat16 else full,
-                                        block.cpu().view(torch.int16) if block.dtype == torch.bfloat16 else block.cpu())
+            dist.all_gather_into_tensor(full.view(torch.uint8), block.cpu().view(torch.uint8))      # bytes: gloo has no bf16 / int16
             return full.to(device)[:n_gal]
         return fd.all_gather_shards(block, n_gal)
 

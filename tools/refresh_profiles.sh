@@ -39,5 +39,7 @@ for c in c2 c3 c4 c5; do
     timeout 900 python3 bench.py --config $c $( [ $c = c2 ] || echo --no-cpu-baseline ) > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err
 done
 FERN_DIST_BACKEND=gloo FERN_BENCH_SHARE_GPU=1 timeout 900 python3 bench.py --gpus 2 --headline-only > $O/${TAG}_bench_2ranks_one_gpu_gloo.json 2> $O/${TAG}_bench_2ranks_one_gpu_gloo.err
+FERN_DIST_BACKEND=gloo FERN_BENCH_SHARE_GPU=1 timeout 900 python3 bench.py --gpus 2 --config c5 --headline-only > $O/${TAG}_bench_c5_2ranks_one_gpu_gloo.json 2> $O/${TAG}_bench_c5_2ranks_one_gpu_gloo.err
+timeout 600 bash tools/mx_cfg_sweep.sh > $O/${TAG}_mx_cfg_sweep.txt 2>&1
 tail -c 400 $O/${TAG}_bench_c2.json
 ls -la $O
