@@ -95,6 +95,7 @@ struct ClipW {
     ResNetW res;
     fern_clip_config cfg{};
     const float *conv_w = nullptr, *cls = nullptr, *vpos = nullptr, *vproj_t = nullptr;
+    LinearW conv_mx;                 // conv1 as a [width, 3 * patch * patch] linear layer: the block-scaled copy (FERN_PREC_MX8 patch embedding)
     LNW ln_pre, ln_post, ln_final;
     std::vector<ClipBlockW> vblocks, tblocks;
     const float *tok_emb = nullptr, *tpos = nullptr, *tproj_t = nullptr;
@@ -676,6 +677,8 @@ extern "C" int fern_finalize_clip(fern_ctx* c, const fern_clip_config* cfg) {
             return fail(FERN_ERR_ARG, "clip: unsupported image tower shape");
         const int vw = cfg->v_width, P = cfg->patch_size, tokens = g * g + 1;
         FERN_TRY(up_key(c, "visual.conv1.weight", {vw, 3, P, P}, &W.conv_w));
+        W.conv_mx = LinearW{W.conv_w, nullptr, vw, 3 * P * P};
+        FERN_TRY(make_mx8(c, &W.conv_mx));
         FERN_TRY(up_key(c, "visual.class_embedding", {vw}, &W.cls));
         FERN_TRY(up_key(c, "visual.positional_embedding", {tokens, vw}, &W.vpos));
         FERN_TRY(up_ln(c, "visual.ln_pre", vw, &W.ln_pre));
@@ -1202,6 +1205,18 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
     FERN_TRY(ws_get(c, (size_t)R * vw, &ATT));
     FERN_TRY(ws_get(c, (size_t)R * cf.v_mlp, &H));
     FERN_TRY(ws_get(c, (size_t)b * vw, &CLS));
+    if (c->precision == FERN_PREC_MX8 && W.conv_mx.wm && (3 * cf.patch_size * cf.patch_size) <= 1280) {
+        // block-scaled mode: patch rows are quantised once (H is free until the first block) and conv1 runs on the scaled MFMA;
+        // same epilogue (positional embedding added, class slot skipped)
+        const int kd = 3 * cf.patch_size * cf.patch_size;
+        const long rows = (long)b * g2;
+        unsigned char* A8 = reinterpret_cast<unsigned char*>(H);
+        unsigned char* SA = A8 + ((size_t)rows * kd + 255) / 256 * 256;
+        HIP_TRY(launch_im2col_mx8(images, A8, SA, rows, b, cf.image_size, cf.patch_size, g, s));
+        GemmParams pm = gemm_desc_mx(A8, SA, rows, kd, W.conv_mx, X, vw, (int)rows, EPI_PATCH_EMBED, false);
+        pm.aux0 = W.vpos; pm.grid = g;
+        FERN_TRY(run_gemm_b(c, pm, s));
+    } else {
     // conv1 as an im2col-free GEMM; epilogue adds the positional embedding and skips the class slot
     GemmParams pe{};
     pe.A = images; pe.W = W.conv_w; pe.ldw = 3L * cf.patch_size * cf.patch_size; pe.C = X; pe.ldc = vw;
@@ -1209,6 +1224,7 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
     pe.epi = EPI_PATCH_EMBED; pe.aload = ALOAD_IM2COL; pe.aux0 = W.vpos;
     pe.img = cf.image_size; pe.patch = cf.patch_size; pe.grid = g;
     FERN_TRY(run_gemm(c, pe, s));
+    }
     HIP_TRY(launch_vit_cls(W.cls, W.vpos, X, b, S, vw, s));
     HIP_TRY(launch_layernorm(X, nullptr, W.ln_pre.g, W.ln_pre.b, X, R, vw, vw, vw, 1e-5f, s));
     for (int l = 0; l + 1 < cf.v_layers; ++l) {

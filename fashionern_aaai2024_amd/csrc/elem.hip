@@ -236,6 +236,37 @@ __global__ __launch_bounds__(256) void layernorm_mx8_kernel(const float* x, cons
     }
 }
 
+// Patch rows of a [b, 3, img, img] image batch, block-scale quantised: row (image, gy, gx) = the 3 x patch x patch pixels of one
+// patch in (channel, y, x) order -- the k order of conv1's [width, 3 * patch * patch] weight -- so that the patch embedding of the
+// block-scaled mode is a plain MX GEMM.  One wave per patch; a lane holds 4 consecutive x of one (channel, y) per step.
+__global__ __launch_bounds__(256) void im2col_mx8_kernel(const float* images, unsigned char* y, unsigned char* scales, long srows, long rows,
+                                                         int img, int patch, int grid) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int pp = patch * patch, d = 3 * pp, g2 = grid * grid;
+    const long b = row / g2;
+    const int gy = (int)(row % g2) / grid, gx = (int)(row % g2) % grid;
+    const float* src = images + b * 3L * img * img + (long)(gy * patch) * img + gx * patch;
+    unsigned char* yr = y + row * d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int k = (i * 64 + lane) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < d) {
+            const int ch = k / pp, rem = k % pp;
+            v = *reinterpret_cast<const f32x4*>(src + ((long)ch * img + rem / patch) * img + rem % patch);
+        }
+        const float am = oct_max(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        if (k < d) {
+            const unsigned e = mx_scale_byte(am);
+            const float inv = mx_inv_scale(e);
+            *reinterpret_cast<unsigned*>(yr + k) = pack4_fp8(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+            if ((lane & 7) == 0) scales[mx_scale_offset(row, k >> 5, srows)] = (unsigned char)e;
+        }
+    }
+}
+
 // bf16 or fp32 rows up to 4096 wide (a lane holds 8 consecutive elements: a 32-block is 4 lanes)
 __global__ __launch_bounds__(256) void quantize_mx8_kernel(const unsigned short* xb, const float* xf, long ldx, unsigned char* y, long ldy,
                                                            unsigned char* scales, long srows, long rows, int d) {
@@ -601,6 +632,15 @@ hipError_t launch_layernorm_mx8(const float* x, const float* gamma, const float*
     if (rows <= 0) return hipSuccess;
     if (d <= 0 || d % 128 || d > 256 * MAXV || (ldx & 3) || (ldy & 3) || srows < rows) return hipErrorInvalidValue;
     hipLaunchKernelGGL(layernorm_mx8_kernel, row_grid(rows), dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps);
+    return hipGetLastError();
+}
+hipError_t launch_im2col_mx8(const float* images, unsigned char* y, unsigned char* scales, long srows, int b, int img, int patch, int grid,
+                             hipStream_t s) {
+    const long rows = (long)b * grid * grid;
+    if (rows <= 0) return hipSuccess;
+    const int d = 3 * patch * patch;
+    if (d % 128 || d > 256 * MAXV || (patch & 3) || (img & 3) || grid * patch != img || srows < rows) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(im2col_mx8_kernel, row_grid(rows), dim3(256), 0, s, images, y, scales, srows, rows, img, patch, grid);
     return hipGetLastError();
 }
 hipError_t launch_quantize_mx8(const unsigned short* x_bf16, const float* x_f32, long ldx, unsigned char* y, long ldy, unsigned char* scales,

@@ -236,6 +236,9 @@ hipError_t launch_layernorm_mx8(const float* x, const float* gamma, const float*
                                 long rows, int d, long ldx, long ldy, float eps, hipStream_t s);
 hipError_t launch_quantize_mx8(const unsigned short* x_bf16, const float* x_f32, long ldx, unsigned char* y, long ldy, unsigned char* scales,
                                long srows, long rows, int d, hipStream_t s);
+// patch rows [b * grid * grid, 3 * patch * patch] of an image batch ((channel, y, x) order = conv1's weight layout), MX-quantised
+hipError_t launch_im2col_mx8(const float* images, unsigned char* y, unsigned char* scales, long srows, int b, int img, int patch, int grid,
+                             hipStream_t s);
 // mode 0: x / max(||x||, eps) (F.normalize); mode 1: x / (||x|| + eps) (VisualSR.l2norm)
 hipError_t launch_l2norm(const float* x, long ldx, float* y, long ldy, long rows, int d, float eps, int mode, hipStream_t s,
                          const float* x2 = nullptr);   // x2: optional addend (normalize(x + x2))

@@ -90,7 +90,8 @@ typedef enum {
     /* The same block structure with BLOCK-SCALED (MX) fp8 operands on v_mfma_scale_f32_32x32x64_f8f6f4, gfx950's scaled MFMA at
      * twice the bf16 / plain-fp8 matrix rate: one E8M0 (power-of-two) scale per (token, 32 consecutive channels) of the
      * activations and per (output channel, 32 consecutive inputs) of the weights (fern_quantize_mx8), applied inside the MFMA --
-     * an outlier channel costs the precision of its own 32-block, not of the whole token row.  Needs tower / MLP widths % 128 == 0. */
+     * an outlier channel costs the precision of its own 32-block, not of the whole token row.  The ViT patch embedding runs the same way
+     * (patch rows quantised once, conv1 as a block-scaled GEMM) when 3 * patch^2 is a multiple of 128.  Needs tower / MLP widths % 128 == 0. */
     FERN_PREC_MX8 = 3
 } fern_precision;
 

@@ -205,8 +205,13 @@ def encode_image(sd, cfg, images, precision="fp32"):
             raise ValueError("reduced precisions are defined for the transformer towers only")
         return encode_image_resnet(sd, cfg, images)
     w = sd["visual.conv1.weight"]
-    x = F.conv2d(images, w, stride=cfg.patch_size)                      # modeling_clip.py:180-196
-    x = x.flatten(2).transpose(1, 2)                                    # [b, g*g, width]
+    if precision == "mx8" and w[0].numel() % 128 == 0 and w[0].numel() <= 1280:
+        # the block-scaled mode runs conv1 as a linear layer over patch rows ((channel, y, x) order) with block-scaled operands
+        patches = F.unfold(images, kernel_size=cfg.patch_size, stride=cfg.patch_size).transpose(1, 2)    # [b, g*g, 3*P*P]
+        x = _linear(patches, w.flatten(1), None, "mx8")
+    else:
+        x = F.conv2d(images, w, stride=cfg.patch_size)                  # modeling_clip.py:180-196
+        x = x.flatten(2).transpose(1, 2)                                # [b, g*g, width]
     cls = sd["visual.class_embedding"].expand(x.shape[0], 1, -1)
     x = torch.cat((cls, x), dim=1) + sd["visual.positional_embedding"]  # :197-200
     x = _ln(sd, "visual.ln_pre", x)                                     # :839,866
