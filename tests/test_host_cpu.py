@@ -252,3 +252,36 @@ def test_builtin_clip_bpe_tokenizer_on_a_synthetic_merge_table(tmp_path, monkeyp
     got = tk.get_tokenizer("some-unregistered-model")
     assert isinstance(got, ClipBpeTokenizer) and got("red").shape == (1, 77)
     tk._REGISTRY.pop("some-unregistered-model", None)
+
+
+def test_gelu_approximations_meet_their_documented_bounds():
+    """csrc/gemm_epilogue.h evaluates GELU's erf by Abramowitz & Stegun 7.1.26 (fp32 parity mode: gelu_erf2) and 7.1.28 (reduced-precision
+    GEMM family: gelu_fast2).  Both formulas restated in numpy float32, operation for operation, against exact erf: the header's
+    bounds (|error| of GELU <= 5e-7 resp. 8.2e-7 on [-12, 12]) hold, tails included (no cancellation for x << 0)."""
+    from scipy.special import erf
+    f = np.float32
+    x = np.linspace(-12, 12, 400001).astype(f)
+    ref = x.astype(np.float64) * 0.5 * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
+    z = x * f(0.70710678118654752440)
+    az = np.abs(z)
+    # 7.1.26: 1 + erf(z) = 2 - P(t) e^{-z^2} (z >= 0) | P(t) e^{-z^2} (z < 0), t = 1 / (1 + p |z|)
+    t = f(1) / (az * f(0.3275911) + f(1))
+    poly = t * f(1.061405429) + f(-1.453152027)
+    for c in (1.421413741, -0.284496736, 0.254829592):
+        poly = poly * t + f(c)
+    pe = poly * t * np.exp2(az * az * f(-1.4426950408889634))
+    g26 = x * f(0.5) * np.where(z >= 0, f(2) - pe, pe)
+    assert np.abs(g26 - ref).max() < 5e-7
+    # 7.1.28: 1 - erf(z) = (1 + a1 z + ... + a6 z^6)^-16
+    p = az * f(0.0000430638) + f(0.0002765672)
+    for c in (0.0001520143, 0.0092705272, 0.0422820123, 0.0705230784, 1.0):
+        p = p * az + f(c)
+    with np.errstate(over="ignore"):
+        for _ in range(4):
+            p = p * p
+    r = f(1) / p
+    g28 = x * f(0.5) * np.where(z >= 0, f(2) - r, r)
+    assert np.abs(g28 - ref).max() < 8.2e-7
+    tail = x < -3                                   # the negative tail keeps relative accuracy where GELU is still above 1e-5
+    big = tail & (np.abs(ref) > 1e-5)
+    assert (np.abs(g26 - ref)[big] / np.abs(ref)[big]).max() < 1e-2 and (np.abs(g28 - ref)[big] / np.abs(ref)[big]).max() < 6e-2
