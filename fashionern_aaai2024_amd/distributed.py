@@ -82,8 +82,10 @@ def all_gather_shards(block: torch.Tensor, n_total: int) -> torch.Tensor:
     rank, world = world_info()
     if world == 1:
         return block[:n_total]
+    block = block.contiguous()
     full = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
-    dist.all_gather_into_tensor(full, block.contiguous())
+    # gathered as bytes: a bf16 gallery (config 5) then needs no bf16 support from the backend (gloo has none)
+    dist.all_gather_into_tensor(full.view(torch.uint8), block.view(torch.uint8))
     return full[:n_total]
 
 

@@ -45,6 +45,11 @@ def _worker(rank, world, port, n, out_dir):
     # the sharded build proper: this rank holds ONLY its rows of the raw index (what bench.py does at C3 / C5 sizes)
     from_shard = fd.build_gallery_from_shard(eng, raw[start:stop], loc[start:stop], n)
     assert torch.equal(from_shard, gallery)
+    # a bf16 gallery block (config 5) gathers the same way: bytes on the wire, no bf16 support needed from the backend
+    _, _, per = fd.shard_rows(n, rank, world)
+    blk = torch.zeros((per, d), dtype=torch.bfloat16)
+    blk[: stop - start] = gallery[start:stop].bfloat16()
+    assert torch.equal(fd.all_gather_shards(blk, n), gallery.bfloat16())
     wrong = 0 if stop > start else 1                                             # any row count but the shard's own is refused
     with pytest.raises(ValueError):
         fd.build_gallery_from_shard(eng, raw[:wrong], loc[:wrong], n)
