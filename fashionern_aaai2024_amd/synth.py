@@ -168,6 +168,7 @@ CLIP_CONFIGS = {
     "tiny": ClipConfig("tiny", 128, 64, 16, 128, 2, 4, 512, 77, 1000, 128, 4, 2, 512),
     "tiny-hd64": ClipConfig("tiny-hd64", 64, 48, 16, 192, 2, 3, 384, 77, 600, 128, 2, 2, 256),
     "tiny-w256": ClipConfig("tiny-w256", 64, 48, 16, 256, 3, 4, 512, 77, 600, 128, 2, 2, 256),     # widths % 128 == 0 (block-scaled fp8 mode)
+    "tiny-hd48": ClipConfig("tiny-hd48", 64, 48, 16, 384, 2, 8, 768, 77, 600, 128, 2, 2, 256),     # head_dim 48: not a multiple of an MX block
 }
 
 

@@ -290,7 +290,7 @@ def test_clip_towers_fp8_precision(name, n):
     eng.close()
 
 
-@pytest.mark.parametrize("name,n", [("tiny-w256", 4), ("ViT-B-16", 3)])
+@pytest.mark.parametrize("name,n", [("tiny-w256", 4), ("tiny-hd48", 4), ("ViT-B-16", 3)])
 def test_clip_towers_mx8_precision(name, n):
     """BASELINE config 5 on the block-scaled MFMA (fern_set_precision(MX8)): e4m3fn operands with one E8M0 scale per 32-element
     block.  Kernels pinned in test_gpu_kernels.py (bit-exact quantiser, GEMM against exact arithmetic on the same bytes and
