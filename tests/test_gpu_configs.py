@@ -309,11 +309,11 @@ def test_c5_fp8_encoder_with_bf16_similarity_end_to_end():
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+@pytest.mark.parametrize("precision", ["bf16", "fp8", "mx8"])
 def test_full_step_is_hipgraph_capturable_in_reduced_precision(precision):
-    """encode -> fuse -> rank of the tiny-hd64 towers in a reduced-precision mode: after a warm-up call (workspaces, bf16 / fp8
+    """encode -> fuse -> rank of the tiny towers in a reduced-precision mode: after a warm-up call (workspaces, bf16 / fp8 / mx8
     tile tuning) the whole step only enqueues kernels and replays from a hipGraph with identical results."""
-    cfg = synth.CLIP_CONFIGS["tiny-hd64"]
+    cfg = synth.CLIP_CONFIGS["tiny-w256" if precision == "mx8" else "tiny-hd64"]
     d = cfg.embed_dim
     eng = FernEngine("cuda:0")
     eng.load_tensors(synth.clip_state_dict(cfg, seed=2))
