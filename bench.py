@@ -68,6 +68,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--gallery", type=int, default=None, help="override the workload's gallery rows")
     ap.add_argument("--lanes", type=int, default=3, help="query batches kept in flight on separate HIP streams")
+    ap.add_argument("--graphs", action="store_true", help="replay each lane's step from a hipGraph (captured after two eager calls)")
     ap.add_argument("--precision", choices=["fp32", "bf16", "fp8", "mx8"], default=None,
                     help="override the encoder operand precision of the TIMED path (fp32 = parity mode, the c2 headline)")
     ap.add_argument("--headline-only", action="store_true",
@@ -283,7 +284,7 @@ def main():
         members = torch.randint(0, n_gal, (B, 6), generator=g, dtype=torch.int32).to(device)
         members[:, 0] = ex_idx
 
-    pipe = ComposedQueryPipeline(eng, lanes=args.lanes, timing=True)
+    pipe = ComposedQueryPipeline(eng, lanes=args.lanes, timing=True, graphs=args.graphs)
     pipe.set_precision(precision)
     step_no = [0]
 

@@ -230,6 +230,17 @@ def test_pipeline_lanes_are_bit_identical_to_serial():
             torch.cuda.current_stream().synchronize()
             assert torch.equal(i, ri) and torch.equal(s, rs)
     pipe.close()
+    # the same stream of batches with every lane's step replayed from a hipGraph (captured at a lane's third call): identical
+    # results for inputs the graph was not captured with, results of earlier replays not overwritten by later ones
+    pipe = ComposedQueryPipeline(eng, lanes=3, graphs=True)
+    for _ in range(3):
+        futures = [pipe.submit(im, tk, lc, gal, 20) for im, tk, lc in batches]
+        for (rs, ri), fut in zip(serial, futures):
+            s, i = fut.wait()
+            torch.cuda.current_stream().synchronize()
+            assert torch.equal(i, ri) and torch.equal(s, rs)
+    assert all(lg.graph is not None for d_ in pipe._lane_graphs for lg in d_.values())
+    pipe.close()
     clip.engine.close()
 
 
