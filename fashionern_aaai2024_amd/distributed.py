@@ -50,6 +50,19 @@ def world_info() -> Tuple[int, int]:
     return 0, 1
 
 
+def _all_gather_into(out: torch.Tensor, inp: torch.Tensor) -> None:
+    """`dist.all_gather_into_tensor(out, inp)` as BYTES (a bf16 / int32 block needs no dtype support from the backend), and
+    through the host when the backend is gloo but the tensors live on a GPU (the debug layout: several ranks sharing the one GPU
+    of a dev box, FERN_DIST_BACKEND=gloo) -- RCCL takes the device tensors as they are."""
+    inp = inp.contiguous()
+    if dist.get_backend() == "gloo" and inp.is_cuda:
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host.view(torch.uint8).view(-1), inp.cpu().view(torch.uint8).view(-1))
+        out.copy_(host)
+        return
+    dist.all_gather_into_tensor(out.view(torch.uint8).view(-1), inp.view(torch.uint8).view(-1))
+
+
 def shard_rows(n: int, rank: int, world: int) -> Tuple[int, int, int]:
     """Contiguous equal shards of ceil(n / world) rows (the last ones may be short or empty): (start, stop, per)."""
     per = (n + world - 1) // world
@@ -71,7 +84,7 @@ def build_gallery(engine, index_features: torch.Tensor, index_local: torch.Tenso
         block[: stop - start] = engine.index_fuse(index_features[start:stop], index_local[start:stop],
                                                   normalize_input=normalize_input)
     full = torch.empty((world * per, d), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(full, block)
+    _all_gather_into(full, block)
     return full[:n]
 
 
@@ -84,8 +97,7 @@ def all_gather_shards(block: torch.Tensor, n_total: int) -> torch.Tensor:
         return block[:n_total]
     block = block.contiguous()
     full = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
-    # gathered as bytes: a bf16 gallery (config 5) then needs no bf16 support from the backend (gloo has none)
-    dist.all_gather_into_tensor(full.view(torch.uint8), block.view(torch.uint8))
+    _all_gather_into(full, block)      # as bytes: a bf16 gallery (config 5) needs no bf16 support from the backend (gloo has none)
     return full[:n_total]
 
 
@@ -119,8 +131,8 @@ def rank_sharded(engine, queries: torch.Tensor, gallery_shard: torch.Tensor, sha
     b, kk = s.shape
     all_s = torch.empty((world * b, kk), dtype=s.dtype, device=s.device)      # concatenated along dim 0 == [world, B, K]
     all_i = torch.empty((world * b, kk), dtype=i.dtype, device=i.device)
-    dist.all_gather_into_tensor(all_s, s.contiguous())
-    dist.all_gather_into_tensor(all_i, i.contiguous())
+    _all_gather_into(all_s, s)
+    _all_gather_into(all_i, i)
     return engine.topk_merge(all_s.view(world, b, kk), all_i.view(world, b, kk))
 
 
@@ -130,8 +142,30 @@ def gather_rows(x: torch.Tensor) -> torch.Tensor:
     if world == 1:
         return x
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x.contiguous())
+    _all_gather_into(out, x)
     return out
+
+
+def gather_ragged(x: torch.Tensor, objs: Optional[list] = None):
+    """Per-rank results with DIFFERENT row counts (a query shard whose loader dropped unreadable items, the short last shard)
+    -> their concatenation in rank order on every rank.  `objs` (one Python object per row: names, member lists) travel with
+    them.  Returns `x_all` or `(x_all, objs_all)`."""
+    rank, world = world_info()
+    if world == 1:
+        return x if objs is None else (x, list(objs))
+    meta = [None] * world
+    dist.all_gather_object(meta, (int(x.shape[0]), None if objs is None else list(objs)))
+    counts = [m[0] for m in meta]
+    per = max(counts)
+    block = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    block[: x.shape[0]] = x
+    full = torch.empty((world * per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if per:
+        _all_gather_into(full, block)
+    out = torch.cat([full[r * per: r * per + c] for r, c in enumerate(counts)], dim=0)
+    if objs is None:
+        return out
+    return out, [o for m in meta for o in m[1]]
 
 
 def extract_index_features_sharded(dataset, clip_model, patch_num, device, feature_dim, batch_size: int = 32, num_workers: int = 0):
@@ -158,8 +192,8 @@ def extract_index_features_sharded(dataset, clip_model, patch_num, device, featu
         local[: l.shape[0]] = l
     all_f = torch.empty((world * per, feature_dim), dtype=torch.float32, device=device)
     all_l = torch.empty((world * per, patch_num, feature_dim), dtype=torch.float32, device=device)
-    dist.all_gather_into_tensor(all_f, feats)
-    dist.all_gather_into_tensor(all_l, local)
+    _all_gather_into(all_f, feats)
+    _all_gather_into(all_l, local)
     gathered = [None] * world
     dist.all_gather_object(gathered, list(names))
     counts = [len(g) for g in gathered]

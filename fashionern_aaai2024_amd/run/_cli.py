@@ -4,9 +4,14 @@ The datasets themselves are not available offline, so by default the driver eval
 tuple format (``--synthetic-gallery N --synthetic-queries Q``) with random-init or user-supplied (``--clip-path`` /
 ``--fusion-model-path``) weights, and prints the reference's summary lines.  With ``--data-root DIR`` it reads the real
 layouts instead through ``fashionern_aaai2024_amd.dataloader`` (fashion-iq/..., cirr_dataset/..., shoes: SURVEY.md 8f rank 3),
-preprocessing images on the GPU (``preprocess.gpu_preprocess``) and tokenising with ``tokenizer.get_tokenizer``."""
+preprocessing images on the GPU (``preprocess.gpu_preprocess``) and tokenising with ``tokenizer.get_tokenizer``.
+
+Multi-GPU: start it under torchrun (``python -m torch.distributed.run --nproc-per-node N -m fashionern_aaai2024_amd.run.test_fiq ...``);
+every rank takes ``cuda:LOCAL_RANK``, the gallery encode (`distributed.extract_index_features_sharded`), the gallery fusion and the
+query loop are sharded over the ranks (run/_common.py) and rank 0 prints the reference's summary lines -- the same numbers as one process."""
 from __future__ import annotations
 
+import os
 import zlib
 from argparse import ArgumentParser
 from statistics import mean
@@ -15,11 +20,12 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
+from .. import distributed as fd
 from .. import synth
 from ..clip_model import create_model
 from ..model import ERN
 from ..tokenizer import register_tokenizer
-from ..utils import extract_index_features, setup_seed
+from ..utils import setup_seed
 
 _WORDS = ("red", "blue", "longer", "shorter", "sleeves", "striped", "floral", "darker", "brighter", "collar", "more", "less")
 
@@ -123,7 +129,13 @@ def main(kind: str) -> None:
                    help="encoder operand precision: fp32 = the reference's arithmetic; bf16 / fp8 / mx8 = perf modes (ViT / text towers)")
     args = p.parse_args()
     setup_seed(args.seed)
-    device = torch.device("cuda")
+    rank, world, local = fd.init_from_env()                 # torchrun: one process per GPU; a lone process is (0, 1, 0)
+    if world > 1 and os.environ.get("FERN_BENCH_SHARE_GPU"):  # debug only: several ranks on the one GPU of a dev box (gloo)
+        local = local % torch.cuda.device_count()
+    device = torch.device("cuda", local) if world > 1 else torch.device("cuda")
+    if world > 1:
+        torch.cuda.set_device(device)
+    say = print if rank == 0 else (lambda *a, **k: None)
     clip_model = create_model(args.clip_model_name, device=device, seed=None if args.clip_path else args.seed, precision=args.precision)
     if args.clip_path:
         clip_model.load_state_dict(torch.load(args.clip_path, map_location="cpu")["CLIP"])
@@ -148,18 +160,22 @@ def main(kind: str) -> None:
                    for i, split in enumerate(splits)]
     results = []
     for split, classic, relative in triples:
-        feats, names, local = extract_index_features(classic, clip_model, args.patch_num, device, args.feature_dim,
-                                                     num_workers=0 if args.data_root else args.num_workers)
+        feats, names, local = fd.extract_index_features_sharded(classic, clip_model, args.patch_num, device, args.feature_dim,
+                                                                num_workers=0 if args.data_root else args.num_workers)
         res = fn(relative, clip_model, feats, local, names, model, device, args.feature_dim, args.batch_size, args.num_workers,
                  args.clip_model_name)
-        print(split, "recalls:", res)
+        say(split, "recalls:", res)
         results.append(res)
     avg = [mean(r[j] for r in results) for j in range(len(results[0]))]
     if kind == "cirr":
-        print("Average: ", (avg[4] + avg[0]) / 2)        # (R@5 + R_subset@1) / 2, test_cirr.py:198
+        say("Average: ", (avg[4] + avg[0]) / 2)        # (R@5 + R_subset@1) / 2, test_cirr.py:198
     elif kind == "val":
-        print("Average recalls: ", avg)
+        say("Average recalls: ", avg)
     else:
-        print("R@10: ", avg[0])
-        print("R@50: ", avg[1])
-        print("Average: ", (avg[0] + avg[1]) / 2)
+        say("R@10: ", avg[0])
+        say("R@50: ", avg[1])
+        say("Average: ", (avg[0] + avg[1]) / 2)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()

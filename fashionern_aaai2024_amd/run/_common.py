@@ -10,6 +10,13 @@ arithmetic that matters is identical and lives here once:
   scores of <= 6 named members are consumed, so this asks the engine for top-K (+ gathered member scores) instead;
 * recall      (test_fiq.py:54-60, test_cirr.py:55-80, test_200k.py:53-60): name compares on the host, percentages
   computed exactly as the reference does (float32 ``sum / len`` then ``* 100``).
+
+Under ``torch.distributed`` (torchrun, one process per GPU) the same functions shard their work and keep their
+contracts on EVERY rank: the query loop runs on this rank's contiguous slice of the relative dataset and the fused queries are
+gathered (so ``generate_*_val_predictions`` still returns all Q predictions in dataset order), the gallery is fused shard by
+shard + one all-gather (``distributed.build_gallery``), each rank ranks its own slice of the queries against the replicated
+gallery (no per-batch collective) and the [Q, K] index rows are gathered for the recall arithmetic.  With one process nothing
+changes.
 """
 from __future__ import annotations
 
@@ -18,8 +25,9 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader
+from torch.utils.data import DataLoader, Subset
 
+from .. import distributed as fd
 from ..tokenizer import get_tokenizer
 from ..utils import collate_fn
 
@@ -43,6 +51,10 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
                          feature_dim, batch_size, num_workers, clip_model_name) -> Dict[str, object]:
     tokenizer = get_tokenizer(clip_model_name)
     device = torch.device(device)
+    rank, world = fd.world_info()
+    if world > 1:       # query data parallel: this rank's contiguous slice of the queries
+        q_start, q_stop, _ = fd.shard_rows(len(relative_val_dataset), rank, world)
+        relative_val_dataset = Subset(relative_val_dataset, range(q_start, q_stop))
     loader = DataLoader(dataset=relative_val_dataset, batch_size=batch_size, num_workers=num_workers,
                         pin_memory=(device.type == "cuda"), collate_fn=collate_fn, shuffle=False)
     name_to_row = {n: i for i, n in enumerate(index_names)}      # duplicates: last row wins, like dict(zip(...)) (:88)
@@ -80,12 +92,43 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
         if members is not None:
             group_members.extend(members)
     pred = torch.cat(predicted, dim=0) if predicted else torch.empty((0, feature_dim), device=device)
+    if world > 1:       # every rank returns all Q predictions in dataset order, like the single-process loop
+        per_row = [(t, r, group_members[i] if group_members else None) for i, (t, r) in enumerate(zip(target_names, reference_names))]
+        pred, per_row = fd.gather_ragged(pred, per_row)
+        target_names, reference_names = [p[0] for p in per_row], [p[1] for p in per_row]
+        group_members = [p[2] for p in per_row] if any(p[2] is not None for p in per_row) else []
     return {"predicted": pred, "targets": target_names, "references": reference_names, "members": group_members}
 
 
 def fuse_index(model, index_features, index_local_features):
-    """test_fiq.py:45-46."""
-    return _engine_of(model).index_fuse(index_features, index_local_features, normalize_input=True)
+    """test_fiq.py:45-46.  N ranks: each fuses ceil(N/W) rows, ONE all-gather replicates the fused gallery."""
+    return fd.build_gallery(_engine_of(model), index_features, index_local_features, normalize_input=True)
+
+
+def _my_rows(q: int):
+    rank, world = fd.world_info()
+    return fd.shard_rows(q, rank, world)
+
+
+def _ranked(model, predicted, index_fused, k, exclude=None) -> np.ndarray:
+    """Top-k gallery rows of every query as a host array [Q, k]: this rank ranks its slice of the queries, the index rows are
+    gathered (rank order == query order).  The engine is synchronised before the result is read, so a ranking error the
+    kernels can only flag (fern_sync) raises here instead of being counted as misses."""
+    eng = _engine_of(model)
+    q = predicted.shape[0]
+    start, stop, per = _my_rows(q)
+    ex = None if exclude is None else torch.as_tensor(exclude[start:stop], dtype=torch.int32)
+    if stop > start:
+        _, idx = eng.sim_topk(predicted[start:stop], index_fused, k, exclude_idx=ex)
+    else:
+        idx = torch.empty((0, k), dtype=torch.int32, device=predicted.device)
+    if hasattr(eng, "sync"):
+        eng.sync()
+    if fd.world_info()[1] > 1:
+        block = torch.full((per, k), -1, dtype=torch.int32, device=idx.device)
+        block[: stop - start] = idx
+        idx = fd.all_gather_shards(block, q)
+    return idx.cpu().numpy()
 
 
 def _pct(count: int, total: int) -> float:
@@ -105,17 +148,16 @@ def recalls_unique(model, predicted, index_fused, index_names, target_names, ks)
     """FashionIQ / Shoes / VAL: R@k = % of queries whose (unique) target is ranked < k."""
     q = len(target_names)
     tgt = _unique_rows(index_names, target_names, "target")
-    _, idx = _engine_of(model).sim_topk(predicted, index_fused, max(ks))
-    hit = idx.cpu().numpy() == tgt[:, None]
+    hit = _ranked(model, predicted, index_fused, max(ks)) == tgt[:, None]
     return tuple(_pct(hit[:, :k].sum(), q) for k in ks)
 
 
 def recalls_anyhit(model, predicted, index_fused, index_names, target_names, ks):
     """Fashion200k: gallery names are caption ids with duplicates; a hit is ANY of the top-k rows (test_200k.py:59-60)."""
     q = len(target_names)
-    _, idx = _engine_of(model).sim_topk(predicted, index_fused, max(ks))
-    names = np.array(index_names)[idx.cpu().numpy().clip(min=0)]
-    hit = (names == np.array(target_names)[:, None]) & (idx.cpu().numpy() >= 0)
+    idx = _ranked(model, predicted, index_fused, max(ks))
+    names = np.array(index_names)[idx.clip(min=0)]
+    hit = (names == np.array(target_names)[:, None]) & (idx >= 0)
     return tuple(_pct((hit[:, :k].sum(1) > 0).sum(), q) for k in ks)
 
 
@@ -125,8 +167,7 @@ def recalls_cirr(model, predicted, index_fused, index_names, reference_names, ta
     eng = _engine_of(model)
     tgt = _unique_rows(index_names, target_names, "target")
     ref = _unique_rows(index_names, reference_names, "reference")
-    _, idx = eng.sim_topk(predicted, index_fused, TOPK, exclude_idx=torch.as_tensor(ref, dtype=torch.int32))
-    hit = idx.cpu().numpy() == tgt[:, None]
+    hit = _ranked(model, predicted, index_fused, TOPK, exclude=ref) == tgt[:, None]
     glob = tuple(_pct(hit[:, :k].sum(), q) for k in (1, 5, 10, 50))
     # subset: rank the target among the query's img_set members (reference excluded) by the same scores
     row = {n: i for i, n in enumerate(index_names)}
@@ -136,7 +177,11 @@ def recalls_cirr(model, predicted, index_fused, index_names, reference_names, ta
         rows = [row[m] for m in mem if m in row and m != reference_names[i]]
         assert rows.count(tgt[i]) == 1, "target must appear exactly once among the group members (test_cirr.py:69)"
         member_rows[i, :len(rows)] = rows
-    sc = eng.gather_scores(predicted, index_fused, torch.as_tensor(member_rows, dtype=torch.int32)).cpu().numpy().astype(np.float64)
+    start, stop, per = _my_rows(q)
+    sc = torch.zeros((per if fd.world_info()[1] > 1 else q, width), dtype=torch.float32, device=predicted.device)
+    if stop > start:
+        sc[: stop - start] = eng.gather_scores(predicted[start:stop], index_fused, torch.as_tensor(member_rows[start:stop], dtype=torch.int32))
+    sc = fd.all_gather_shards(sc, q).cpu().numpy().astype(np.float64)
     ranks = np.empty(q, dtype=np.int64)
     for i in range(q):
         rows_i = np.where(member_rows[i] >= 0, member_rows[i], np.iinfo(np.int64).max)

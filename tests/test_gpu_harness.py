@@ -163,6 +163,31 @@ def test_cli_driver_runs_on_synthetic_split():
         assert "Average:" in r.stdout
 
 
+def test_cli_driver_under_torchrun_prints_the_single_process_recalls():
+    """run/test_{fiq,cirr,200k} under torch.distributed.run, 2 ranks (sharing this box's one GPU over gloo -- the debug layout;
+    on a multi-GPU node the same command takes cuda:LOCAL_RANK over RCCL): sharded gallery encode + fuse + all-gather, query data
+    parallel -- rank 0 prints exactly the lines of the single-process run."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ["--clip-model-name", "tiny", "--feature-dim", "128", "--input-dim", "64", "--synthetic-gallery", "301", "--synthetic-queries", "41",
+             "--batch-size", "16"]
+    for mod in ("test_fiq", "test_cirr", "test_200k"):
+        one = subprocess.run([sys.executable, "-m", f"fashionern_aaai2024_amd.run.{mod}"] + flags, cwd=root, capture_output=True, text=True, timeout=600)
+        assert one.returncode == 0, one.stderr[-2000:]
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, FERN_DIST_BACKEND="gloo", FERN_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), "-m", f"fashionern_aaai2024_amd.run.{mod}"] + flags,
+                             cwd=root, capture_output=True, text=True, timeout=900, env=env)
+        assert two.returncode == 0, two.stderr[-3000:]
+        keep = lambda out: [ln for ln in out.splitlines() if "recalls:" in ln or ln.startswith(("R@", "Average"))]  # noqa: E731
+        assert keep(one.stdout) and keep(two.stdout) == keep(one.stdout), (keep(one.stdout), keep(two.stdout))
+
+
 def test_full_pipeline_in_bf16_perf_mode_stays_within_the_score_budget():
     """The whole FIQ harness with the encoders in bf16 perf mode vs the same run in fp32 parity mode.
 
