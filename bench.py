@@ -99,6 +99,20 @@ def _timed(fn):
     return time.perf_counter() - t0
 
 
+def _host_cpu():
+    """(model name, logical cores) of the host this rank runs on -- north_star: "core count stated"."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
 def _cpu_threads():
     # threads actually used: the host cores this process may run on, capped at 32 (torch's intra-op pool stops scaling on these
     # small per-query matrices well before that; an uncapped 256-thread pool is ~100x slower)
@@ -165,7 +179,10 @@ def cpu_baseline(clip_sd, fusion_sd, cfg, w, images, tokens, loc, gallery, sampl
         return {"feature_dim": dd, "gallery_rows": n, "query_batch": b, "index_fuse_rows_per_s": n / t_index, "dvr_fuse_queries_per_s": b / t_test,
                 "rank_ms": t_rank * 1e3, "fuse_plus_rank_queries_per_s": b / (t_test + t_rank)}
 
-    return {"value": sample / best, "unit": "composed queries/sec", "cores": threads, "kind": "port",
+    cpu_model, host_cores = _host_cpu()
+    return {"value": sample / best, "unit": "composed queries/sec", "cores": threads, "threads": threads, "host_cores": host_cores,
+            "cpu_model": cpu_model, "kind": "port",
+            "cores_note": "`cores` = torch intra-op threads actually used = min(schedulable cores, 32); `host_cores` = os.cpu_count() of the box",
             "sample": f"{sample} composed queries ({cfg.name} image + text encode, fusion, top-{k} of {gal.shape[0]} rows), "
                       f"torch CPU fp32, best of {repeats + 1}",
             "parity_vs_hip": parity,
@@ -245,13 +262,7 @@ def main():
         return block
 
     def gather(block):
-        if world == 1:
-            return block[:n_gal]
-        if gloo:
-            full = torch.empty((world * per, D), dtype=block.dtype)
-            dist.all_gather_into_tensor(full.view(torch.uint8), block.cpu().view(torch.uint8))      # bytes: gloo has no bf16 / int16
-            return full.to(device)[:n_gal]
-        return fd.all_gather_shards(block, n_gal)
+        return fd.all_gather_shards(block, n_gal)      # bytes on the wire; the gloo debug backend is staged through the host in there
 
     def barrier():
         torch.cuda.synchronize()
@@ -327,6 +338,11 @@ def main():
     for _ in range(max(args.warmup, args.lanes, n_batches)):      # every lane's workspace / every tuned shape exists before the timed region
         step()
     barrier()
+    if world > 1:      # all ranks run rank 0's tile choices: a max-over-ranks step time must not carry rank-to-rank tuner noise
+        fd.share_gemm_tiles(eng)
+        for _ in range(max(args.lanes, n_batches)):
+            step()
+        barrier()
     if args.pmc_mode:      # tools/pmc_traffic.py keys on this single-workgroup l2norm dispatch to find the measured steps
         pipe.set_precision(precision)
         for j in range(n_batches):

@@ -7,6 +7,7 @@ it rebuilds only when a source is newer than the library.
 """
 from __future__ import annotations
 
+import json
 import os
 import shutil
 import subprocess
@@ -65,13 +66,33 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
 
     usage: dict = {}
 
+    import re
+
+    def deps_time(path: str, seen=None) -> float:
+        """Newest mtime of `path` and of every file it #include "..."s, transitively."""
+        seen = set() if seen is None else seen
+        path = os.path.normpath(path)
+        if path in seen or not os.path.exists(path):
+            return 0.0
+        seen.add(path)
+        t = os.path.getmtime(path)
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(path).read(), flags=re.M):
+            t = max(t, deps_time(os.path.join(os.path.dirname(path), inc), seen))
+        return t
+
     def compile_one(src: str) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        side = obj + ".usage.json"      # the resource report of the object, so an object that is reused still gets checked for spills
+        newest = deps_time(os.path.join(CSRC, src))
+        if not force and os.path.exists(obj) and os.path.exists(side) and os.path.getmtime(obj) > newest:
+            usage[src] = json.load(open(side))
+            return obj
         cmd = [hipcc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
         usage[src] = parse_resource_usage(r.stderr)
+        json.dump(usage[src], open(side, "w"))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:

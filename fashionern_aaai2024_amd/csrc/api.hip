@@ -127,6 +127,9 @@ struct fern_ctx {
     std::vector<Block> blocks;
     size_t used = 0;                 // offset into blocks.back()
     size_t op_total = 0;
+    // bumped whenever workspace memory handed out earlier is FREED (the consolidation in ws_begin): addresses baked into a
+    // captured hipGraph of this context are dead from then on -- fern_ws_generation lets the owner of the graph notice
+    unsigned long long ws_generation = 0;
     // profiling
     bool prof_on = false;
     std::vector<ProfRec> recs;
@@ -140,6 +143,7 @@ static int ws_begin(fern_ctx* c, hipStream_t s) {
         HIP_TRY(hipStreamSynchronize(s));
         for (auto& b : c->blocks) HIP_TRY(hipFree(b.p));
         c->blocks.clear();
+        ++c->ws_generation;
         char* p = nullptr;
         HIP_TRY(hipMalloc(&p, total));
         c->blocks.push_back({p, total});
@@ -1788,6 +1792,19 @@ extern "C" int64_t fern_tuner_export(char* buf, int64_t cap) {
         buf[n] = 0;
     }
     return (int64_t)text.size();
+}
+
+extern "C" uint64_t fern_ws_generation(const fern_ctx* c) { return c ? c->ws_generation : 0; }
+
+// The reverse of fern_tuner_export: `text` (NUL-terminated lines of the export format) replaces this process's choices for the
+// shapes it lists -- e.g. rank 0's export broadcast to every rank, so that all ranks of a job run identical kernels.  Unknown or
+// inapplicable lines are skipped.  Every configuration is bit-identical, so this never changes a result.
+extern "C" int fern_tuner_import(const char* text) {
+    if (!text) return fail(FERN_ERR_ARG, "fern_tuner_import: text is NULL");
+    const std::string t(text);
+    gemm_tuner_import(t);
+    gemm_bf16_tuner_import(t);
+    return FERN_OK;
 }
 
 extern "C" int fern_prof_enable(fern_ctx* c, int on) {

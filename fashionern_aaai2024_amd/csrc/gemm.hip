@@ -600,24 +600,39 @@ static std::mutex g_tuned_mu;
 // FERN_GEMM_TILES=<file>: pin the per-shape choices (lines "f32 M N K epi aload cfg [rows_a cfg_b]", as written by gemm_tuner_export /
 // fern_tuner_export): listed shapes are never timed again, so a run's kernels -- and its HBM / L2 traffic -- are reproducible
 // from box to box.  Loaded once, before the first tuned launch.
+static void pin_tile_line(const char* line) {      // caller holds g_tuned_mu
+    char kind[16];
+    auto ok = [](int cfg, int K) { return cfg >= 0 && cfg < kNumCfgs && kCfgs[cfg].bk && K % kCfgs[cfg].bk == 0; };
+    int M, N, K, epi, aload, cfg, rows_a = 0, cfg_b = 0;
+    const int got = sscanf(line, "%15s %d %d %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &aload, &cfg, &rows_a, &cfg_b);
+    if (got < 7 || strcmp(kind, "f32") || !ok(cfg, K)) return;
+    if (got < 9 || rows_a <= 0 || rows_a >= M || !ok(cfg_b, K)) { rows_a = 0; cfg_b = cfg; }
+    g_tuned[ShapeKey{M, N, K, epi, aload}] = Plan{cfg, rows_a, cfg_b};
+}
 static void load_pinned_tiles() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char* path = getenv("FERN_GEMM_TILES");
         FILE* f = path ? fopen(path, "r") : nullptr;
         if (!f) return;
-        char line[256], kind[16];
+        char line[256];
         std::lock_guard<std::mutex> lock(g_tuned_mu);
-        auto ok = [](int cfg, int K) { return cfg >= 0 && cfg < kNumCfgs && kCfgs[cfg].bk && K % kCfgs[cfg].bk == 0; };
-        while (fgets(line, sizeof line, f)) {
-            int M, N, K, epi, aload, cfg, rows_a = 0, cfg_b = 0;
-            const int got = sscanf(line, "%15s %d %d %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &aload, &cfg, &rows_a, &cfg_b);
-            if (got < 7 || strcmp(kind, "f32") || !ok(cfg, K)) continue;
-            if (got < 9 || rows_a <= 0 || rows_a >= M || !ok(cfg_b, K)) { rows_a = 0; cfg_b = cfg; }
-            g_tuned[ShapeKey{M, N, K, epi, aload}] = Plan{cfg, rows_a, cfg_b};
-        }
+        while (fgets(line, sizeof line, f)) pin_tile_line(line);
         fclose(f);
     });
+}
+// fern_tuner_import: the lines of another process's fern_tuner_export replace this process's choices for the listed shapes
+// (rank 0 tunes, every rank runs rank 0's kernels: no rank-to-rank tile skew in a max-over-ranks step time)
+void gemm_tuner_import(const std::string& text) {
+    load_pinned_tiles();
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    size_t at = 0;
+    while (at < text.size()) {
+        size_t nl = text.find('\n', at);
+        if (nl == std::string::npos) nl = text.size();
+        pin_tile_line(text.substr(at, nl - at).c_str());
+        at = nl + 1;
+    }
 }
 void gemm_tuner_export(std::string& out) {
     std::lock_guard<std::mutex> lock(g_tuned_mu);
@@ -664,9 +679,12 @@ static hipError_t launch_plan(const Plan& pl, const GemmParams& p, hipStream_t s
     return launch_cfg(pl.cfg_b, tail_rows(p, pl.rows_a), s);
 }
 
-static Plan tune_shape(const GemmParams& p, hipStream_t s) {
+// `tuned` = false: nothing was timed (the stream is being captured, or no scratch memory) and the heuristic plan is returned --
+// the caller must NOT cache it, or the shape would stay on the untuned plan (and be exported as a tuned choice) for good.
+static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
     const int fallback_cfg = choose_cfg(p.M, p.N, p.K);
     const Plan fallback{fallback_cfg, 0, fallback_cfg};
+    tuned = false;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return fallback;
     long out_rows = p.M;
@@ -733,6 +751,7 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(scratch);
+    tuned = best_ms < 1e29f;
     return best;
 }
 
@@ -754,8 +773,13 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
         const ShapeKey key{p.M, p.N, p.K, p.epi, p.aload + 1000 * (p.ksplit > 1 ? p.ksplit : 0)};
         std::lock_guard<std::mutex> lock(g_tuned_mu);
         auto it = g_tuned.find(key);
-        if (it == g_tuned.end()) it = g_tuned.emplace(key, tune_shape(p, s)).first;
-        const Plan pl = it->second;
+        Plan pl;
+        if (it != g_tuned.end()) pl = it->second;
+        else {
+            bool tuned = false;
+            pl = tune_shape(p, s, tuned);
+            if (tuned) g_tuned.emplace(key, pl);
+        }
         if (pl.rows_a > 0 && split_ok(p)) return launch_plan(pl, p, s);
         c = pl.cfg;
     }

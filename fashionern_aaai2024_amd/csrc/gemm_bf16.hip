@@ -482,23 +482,37 @@ static std::map<ShapeKeyB, int> g_tuned_b;
 static std::mutex g_tuned_b_mu;
 
 // FERN_GEMM_TILES=<file>: lines "bf16 M N K epi ob cfg" / "fp8 M N K epi ob cfg" / "mx8 M N K epi ob cfg" pin the choices (see gemm.hip)
+static void pin_tile_line_b(const char* line) {      // caller holds g_tuned_b_mu
+    char kind[16];
+    int M, N, K, epi, ob, cfg;
+    if (sscanf(line, "%15s %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &ob, &cfg) != 7) return;
+    const bool f8 = !strcmp(kind, "fp8"), mx = !strcmp(kind, "mx8");
+    if ((f8 || mx || !strcmp(kind, "bf16")) && cfg >= 0 && cfg < (mx ? kNumCfgsMx : f8 ? kNumCfgsF8 : kNumCfgsB) &&
+        (f8 || mx || K % kCfgsB[cfg].bk == 0))
+        g_tuned_b[ShapeKeyB{M, N, K, epi, ob}] = cfg;
+}
 static void load_pinned_tiles_b() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char* path = getenv("FERN_GEMM_TILES");
         FILE* f = path ? fopen(path, "r") : nullptr;
         if (!f) return;
-        char kind[16];
-        int M, N, K, epi, ob, cfg;
+        char line[256];
         std::lock_guard<std::mutex> lock(g_tuned_b_mu);
-        while (fscanf(f, "%15s %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &ob, &cfg) == 7) {
-            const bool f8 = !strcmp(kind, "fp8"), mx = !strcmp(kind, "mx8");
-            if ((f8 || mx || !strcmp(kind, "bf16")) && cfg >= 0 && cfg < (mx ? kNumCfgsMx : f8 ? kNumCfgsF8 : kNumCfgsB) &&
-                (f8 || mx || K % kCfgsB[cfg].bk == 0))
-                g_tuned_b[ShapeKeyB{M, N, K, epi, ob}] = cfg;
-        }
+        while (fgets(line, sizeof line, f)) pin_tile_line_b(line);
         fclose(f);
     });
+}
+void gemm_bf16_tuner_import(const std::string& text) {      // see gemm_tuner_import (gemm.hip)
+    load_pinned_tiles_b();
+    std::lock_guard<std::mutex> lock(g_tuned_b_mu);
+    size_t at = 0;
+    while (at < text.size()) {
+        size_t nl = text.find('\n', at);
+        if (nl == std::string::npos) nl = text.size();
+        pin_tile_line_b(text.substr(at, nl - at).c_str());
+        at = nl + 1;
+    }
 }
 void gemm_bf16_tuner_export(std::string& out) {
     std::lock_guard<std::mutex> lock(g_tuned_b_mu);
@@ -520,7 +534,9 @@ static int heuristic_b(int M, int N) {
     return 5;
 }
 
-static int tune_shape_b(const GemmParams& p, hipStream_t s) {
+// `tuned` = false: nothing was timed (tuning off, stream capture, no scratch): the caller must not cache the fallback
+static int tune_shape_b(const GemmParams& p, hipStream_t s, bool& tuned) {
+    tuned = false;
     const bool f8 = p.fp8 != 0;
     auto launch = p.fp8 == 2 ? launch_cfg_mx : f8 ? launch_cfg_f8 : launch_cfg_b;
     const int fallback = f8 ? 0 : heuristic_b(p.M, p.N);
@@ -560,7 +576,17 @@ static int tune_shape_b(const GemmParams& p, hipStream_t s) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(scratch);
+    tuned = best_ms < 1e29f;
     return best;
+}
+static int tuned_cfg_b(const ShapeKeyB& key, const GemmParams& p, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_tuned_b_mu);
+    auto it = g_tuned_b.find(key);
+    if (it != g_tuned_b.end()) return it->second;
+    bool tuned = false;
+    const int c = tune_shape_b(p, s, tuned);
+    if (tuned) g_tuned_b.emplace(key, c);
+    return c;
 }
 
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
@@ -581,10 +607,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
             c = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) >= 256 ? 0 : 6;
             if (2.0 * p.M * (double)p.N * p.K >= 2.5e8) {
                 const ShapeKeyB key{p.M, p.N, p.K, p.epi, p.out_bf16 | 4 | (p.out_mx8 ? 8 : 0)};
-                std::lock_guard<std::mutex> lock(g_tuned_b_mu);
-                auto it = g_tuned_b.find(key);
-                if (it == g_tuned_b.end()) it = g_tuned_b.emplace(key, tune_shape_b(p, s)).first;
-                c = it->second;
+                c = tuned_cfg_b(key, p, s);
             }
         }
         return launch_cfg_mx(c, p, s);
@@ -596,10 +619,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
             c = 0;
             if (2.0 * p.M * (double)p.N * p.K >= 2.5e8) {
                 const ShapeKeyB key{p.M, p.N, p.K, p.epi, p.out_bf16 | 2};
-                std::lock_guard<std::mutex> lock(g_tuned_b_mu);
-                auto it = g_tuned_b.find(key);
-                if (it == g_tuned_b.end()) it = g_tuned_b.emplace(key, tune_shape_b(p, s)).first;
-                c = it->second;
+                c = tuned_cfg_b(key, p, s);
             }
         }
         return launch_cfg_f8(c, p, s);
@@ -609,10 +629,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
         const double flops = 2.0 * p.M * (double)p.N * p.K;
         if (flops >= 2.5e8 && flops <= 1.6e12) {
             const ShapeKeyB key{p.M, p.N, p.K, p.epi, p.out_bf16};
-            std::lock_guard<std::mutex> lock(g_tuned_b_mu);
-            auto it = g_tuned_b.find(key);
-            if (it == g_tuned_b.end()) it = g_tuned_b.emplace(key, tune_shape_b(p, s)).first;
-            c = it->second;
+            c = tuned_cfg_b(key, p, s);
         } else {
             c = heuristic_b(p.M, p.N);
         }

@@ -119,6 +119,9 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s);
 // the per-shape tile choices made so far, one text line per shape (the format FERN_GEMM_TILES=<file> reads back)
 void gemm_tuner_export(std::string& out);
 void gemm_bf16_tuner_export(std::string& out);
+// the reverse: lines of that format replace this process's choices for the listed shapes
+void gemm_tuner_import(const std::string& text);
+void gemm_bf16_tuner_import(const std::string& text);
 
 #ifdef __HIPCC__
 // 64-bit ranking keys: orderable(score) << 32 | ~index, so "score descending, index ascending" is one unsigned compare

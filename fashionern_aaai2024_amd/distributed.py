@@ -136,6 +136,19 @@ def rank_sharded(engine, queries: torch.Tensor, gallery_shard: torch.Tensor, sha
     return engine.topk_merge(all_s.view(world, b, kk), all_i.view(world, b, kk))
 
 
+def share_gemm_tiles(engine, src: int = 0) -> None:
+    """Every rank adopts rank `src`'s GEMM tile choices (the per-shape tuner runs independently in each process; all choices
+    give bit-identical results, but different tiles run at slightly different speeds and a multi-GPU step is as slow as its
+    slowest rank).  Call after the warm-up that visited the shapes."""
+    rank, world = world_info()
+    if world == 1:
+        return
+    box = [engine.tuner_export() if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    if rank != src:
+        engine.tuner_import(box[0])
+
+
 def gather_rows(x: torch.Tensor) -> torch.Tensor:
     """Concatenate equally-shaped per-rank results along dim 0 on every rank (reporting / recall on rank 0)."""
     rank, world = world_info()

@@ -448,5 +448,14 @@ class FernEngine:
         self.lib.fern_tuner_export(buf, int(n) + 1)
         return buf.value.decode()
 
+    def ws_generation(self) -> int:
+        """Changes whenever this context has freed workspace memory an earlier call used (include/fern.h: fern_ws_generation):
+        a hipGraph captured from this engine's calls is stale once the value moves."""
+        return int(self.lib.fern_ws_generation(self._h))
+
+    def tuner_import(self, text: str) -> None:
+        """Adopt another process's `tuner_export()` for the shapes it lists (all tile choices are bit-identical: speed only)."""
+        _lib.check(self.lib.fern_tuner_import(text.encode()), "fern_tuner_import")
+
     def sync(self) -> None:
         _lib.check(self.lib.fern_sync(self._h, _stream()), "fern_sync")

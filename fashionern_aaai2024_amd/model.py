@@ -35,8 +35,9 @@ class ERN:
 
         ``strict`` follows ``nn.Module.load_state_dict`` (test_fiq.py:149 calls it with the default, True): with
         ``strict=True`` a missing or an unexpected fusion key raises ``RuntimeError`` naming the keys; with ``strict=False``
-        unexpected keys are dropped, missing ones keep the values of the previous load (an error if there was none), and the
-        ``(missing_keys, unexpected_keys)`` pair is returned instead of ``self``.  Two keys are optional in both modes
+        unexpected keys are dropped and missing ones keep the values of the previous load (an error if there was none).
+        Always returns ``self`` (so ``ERN(...).load_state_dict(sd)`` chains in both modes); the two key lists of the last load
+        are left in ``self.missing_keys`` / ``self.unexpected_keys`` (what nn.Module returns as a named tuple).  Two keys are optional in both modes
         because real checkpoints differ in them: ``DVR.transformer_layer.cls_token`` (absent from GPU-trained
         checkpoints -> zeros) and ``...embeddings.position_ids`` (a buffer in transformers 4.30.2, gone in later versions)."""
         fusion, clip = {}, {}
@@ -48,7 +49,7 @@ class ERN:
                 clip.setdefault(k[len(_CLIP_PREFIXES[1]):], arr)
             else:
                 fusion[k] = arr
-        expected = set(synth.fusion_state_dict(self.feature_dim, 0).keys())
+        expected = set(synth.fusion_state_shapes(self.feature_dim))
         optional = {"DVR.transformer_layer.cls_token", "DVR.transformer_layer.bert_encoder.bert_model.embeddings.position_ids"}
         optional |= {k for k in fusion if k.endswith("num_batches_tracked")}
         missing = sorted(k for k in expected - optional if k not in fusion)
@@ -69,7 +70,8 @@ class ERN:
         cm = self.image_clip.clip_model
         if clip and hasattr(cm, "load_state_dict") and getattr(cm, "engine", None) is not None:
             cm.load_state_dict(clip)
-        return self if strict else (missing, unexpected)
+        self.missing_keys, self.unexpected_keys = missing, unexpected
+        return self
 
     def init_random(self, seed: int = 0):
         return self.load_state_dict(synth.fusion_state_dict(self.feature_dim, seed))

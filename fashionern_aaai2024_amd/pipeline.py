@@ -43,13 +43,17 @@ class _LaneGraph:
         self.graph = None
         self.inputs = None
         self.outputs = None
+        self.ws_generation = None      # the lane engine's workspace generation the graph's baked-in addresses belong to
 
 
 class ComposedQueryPipeline:
     """``graphs=True``: after two eager calls with the same shapes (workspaces sized, tiles tuned) a lane's whole step -- about
     350 kernel launches at ViT-B/16 -- is captured once into a hipGraph and replayed: inputs are copied into the lane's static
     buffers, outputs are cloned out of the graph's, so the caller sees the same interface and bit-identical results, while the
-    host enqueues one graph instead of hundreds of kernels and the kernels of a lane follow each other without launch gaps."""
+    host enqueues one graph instead of hundreds of kernels and the kernels of a lane follow each other without launch gaps.
+    A graph holds addresses inside its lane engine's workspace; when that engine later re-allocates the workspace (an eager
+    call with a bigger batch / gallery / K, another precision, a direct call on ``engines[0]``) its `ws_generation` moves and
+    every graph of the lane is dropped and re-captured on its next use instead of being replayed against freed memory."""
 
     def __init__(self, engine: FernEngine, lanes: int = 3, timing: bool = False, graphs: bool = False):
         self.timing = bool(timing)
@@ -69,6 +73,9 @@ class ComposedQueryPipeline:
         selects the bf16 sweep -- -> QueryResult.  `exclude_idx` [B] drops one gallery index per query and `members` [B,m]
         (fp32 gallery) also returns the scores of those rows: CIRR's reference removal and subset ranking
         (run/test/test_cirr.py:55-66)."""
+        if members is not None and gallery.dtype != torch.float32:
+            raise ValueError("members (subset scores) need an fp32 gallery: gather_scores has no bf16 form, and converting the "
+                             "gallery per step would copy all of it")
         lane = self._next
         self._next = (self._next + 1) % len(self.engines)
         eng, stream = self.engines[lane], self.streams[lane]
@@ -101,15 +108,19 @@ class ComposedQueryPipeline:
         key = tuple((tuple(a.shape), a.dtype) if a is not None else None for a in args) + (
             gallery.data_ptr(), tuple(gallery.shape), gallery.dtype, int(k), int(idx_offset), eng.precision)
         lg = self._lane_graphs[lane].setdefault(key, _LaneGraph())
+        if lg.graph is not None and lg.ws_generation != eng.ws_generation():
+            stream.synchronize()                                 # the workspace the graph points into was freed: start over
+            lg.graph, lg.outputs, lg.calls = None, None, 0
         lg.calls += 1
         if lg.graph is None:
             if lg.calls <= 2:                                    # eager: sizes the workspaces, lets the tile tuner see every shape
                 return self._step(eng, args, gallery, k, idx_offset)
             lg.inputs = tuple(None if a is None else a.clone() for a in args)
             stream.synchronize()
-            lg.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(lg.graph, stream=stream):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
                 lg.outputs = self._step(eng, lg.inputs, gallery, k, idx_offset)
+            lg.graph, lg.ws_generation = graph, eng.ws_generation()
         for dst, src in zip(lg.inputs, args):
             if dst is not None:
                 dst.copy_(src, non_blocking=True)

@@ -33,12 +33,19 @@ def _rng(seed: int, key: str) -> np.random.Generator:
     return np.random.default_rng([int(seed), zlib.crc32(key.encode())])
 
 
+_SHAPES_ONLY = False      # fusion_state_shapes(): the builders below then produce zero-stride placeholders of the right shape
+
+
 def _normal(seed, key, shape, std=1.0, mean=0.0):
+    if _SHAPES_ONLY:
+        return np.broadcast_to(np.float32(0), shape)
     return (_rng(seed, key).standard_normal(shape, dtype=np.float32) * np.float32(std)
             + np.float32(mean)).astype(np.float32)
 
 
 def _uniform(seed, key, shape, lo, hi):
+    if _SHAPES_ONLY:
+        return np.broadcast_to(np.float32(0), shape)
     return _rng(seed, key).uniform(lo, hi, size=shape).astype(np.float32)
 
 
@@ -110,6 +117,17 @@ def fusion_state_dict(feature_dim: int, seed: int = 0, with_cls_token: bool = Tr
     _visual_sr(sd, seed, "SR_module", d)
     _combiner(sd, seed, "Combiner_module", d)
     return sd
+
+
+def fusion_state_shapes(feature_dim: int) -> Dict[str, tuple]:
+    """Key -> shape of ``ERN.state_dict()``'s fusion part, without generating a single value (what ``load_state_dict`` checks
+    a checkpoint's key set against)."""
+    global _SHAPES_ONLY
+    _SHAPES_ONLY = True
+    try:
+        return {k: tuple(v.shape) for k, v in fusion_state_dict(feature_dim, 0).items()}
+    finally:
+        _SHAPES_ONLY = False
 
 
 def clip4cir_state_dict(clip_feature_dim: int, projection_dim: int, hidden_dim: int, seed: int = 0) -> Dict[str, np.ndarray]:

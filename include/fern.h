@@ -315,6 +315,15 @@ FERN_API int fern_attention_bf16(fern_ctx* ctx, const uint16_t* q, int64_t ldq, 
  * the return value is the full length.  Setting FERN_GEMM_TILES=<file of such lines> before the first launch pins those
  * shapes (no timing runs, same kernels on every box).  No reference counterpart (cuBLAS picks its own kernels). */
 FERN_API int64_t fern_tuner_export(char* buf, int64_t cap);
+/* The reverse: `text` (NUL-terminated lines of the export format) replaces this process's choices for the shapes it lists, e.g.
+ * rank 0's export broadcast to all ranks of a job so that every rank runs the same kernels (the step time of a multi-GPU job is
+ * the max over ranks).  Lines that do not parse or name an inapplicable configuration are skipped.  Never changes a result. */
+FERN_API int fern_tuner_import(const char* text);
+
+/* Workspace generation of a context: incremented each time the context frees workspace memory it had handed to kernels before
+ * (it consolidates its arena at the start of the next call after one that had to grow it).  A hipGraph captured from calls on
+ * this context holds those addresses: re-capture it when the value differs from the one read right after the capture. */
+FERN_API uint64_t fern_ws_generation(const fern_ctx* ctx);
 
 /* profiling ----------------------------------------------------------------------------- */
 FERN_API int fern_prof_enable(fern_ctx* ctx, int on);    /* wrap GEMM/attention/top-K launches in HIP events */

@@ -240,6 +240,26 @@ def test_pipeline_lanes_are_bit_identical_to_serial():
             torch.cuda.current_stream().synchronize()
             assert torch.equal(i, ri) and torch.equal(s, rs)
     assert all(lg.graph is not None for d_ in pipe._lane_graphs for lg in d_.values())
+    # a captured graph holds addresses inside its lane's workspace.  A later, bigger call on the same lane engines
+    # (here: a 31-query batch against a gallery 12 x as large, eager on every lane, and direct calls on engines[0]) makes the
+    # contexts re-allocate their workspaces; the old graphs must be noticed as stale and re-captured, never replayed.
+    gens = [e.ws_generation() for e in pipe.engines]
+    big_gal = eng.index_fuse(torch.from_numpy(synth.global_feats(60000, d, tag="pg2")), torch.from_numpy(synth.local_feats(60000, d, tag="pgl2")), True)
+    big = (torch.from_numpy(synth.images(31, cfg, 300)).cuda(), torch.from_numpy(synth.captions(31, cfg, 300)).cuda(),
+           torch.from_numpy(synth.local_feats(31, d, 300)).cuda())
+    for _ in range(2 * len(pipe.engines)):
+        pipe.submit(*big, big_gal, 50).wait()
+    torch.cuda.synchronize()
+    assert any(e.ws_generation() != g0 for e, g0 in zip(pipe.engines, gens)), "the bigger call was expected to move the workspaces"
+    for _ in range(3):
+        futures = [pipe.submit(im, tk, lc, gal, 20) for im, tk, lc in batches]
+        for (rs, ri), fut in zip(serial, futures):
+            s, i = fut.wait()
+            torch.cuda.current_stream().synchronize()
+            assert torch.equal(i, ri) and torch.equal(s, rs)
+    assert all(lg.graph is None or lg.ws_generation == e.ws_generation() for e, d_ in zip(pipe.engines, pipe._lane_graphs) for lg in d_.values())
+    with pytest.raises(ValueError):
+        pipe.submit(*batches[0], eng.gallery_to_bf16(gal), 20, members=torch.zeros(9, 6, dtype=torch.int32, device="cuda"))
     pipe.close()
     clip.engine.close()
 

@@ -150,6 +150,47 @@ def test_clip4cir_combiner_and_element_wise_sum(cdim):
     assert np.abs(element_wise_sum(im.cuda(), tx.cuda(), engine=comb.engine).cpu().numpy() - gold[f"ews_c{cdim}"]).max() < 1e-6
 
 
+def test_headline_shape_b64_vit_b16_matches_the_oracle():
+    """The bench's headline shape as a test of its own: ONE batch of 64 composed queries, ViT-B/16 image +
+    text towers, fusion, top-50 of a 46k-row fused gallery -- HIP vs the fp32 oracle on the same seeded inputs.  Tolerances:
+    features <= 1e-3 of the feature scale (north_star), cosine scores <= 1e-3, top-50 ordering identical except between rows
+    the oracle itself separates by < 2e-6 (its BLAS summation order is not the kernel's)."""
+    from oracle import clip as oclip, fusion as ofusion, rank as orank
+    cfg = synth.CLIP_CONFIGS["ViT-B-16"]
+    d, b, n, k = cfg.embed_dim, 64, 46_000, 50
+    clip_sd, fusion_sd = synth.clip_state_dict(cfg, seed=0), synth.fusion_state_dict(d, seed=0)
+    clip = create_model(cfg, device=DEV)
+    clip.load_state_dict(clip_sd)
+    model = ERN(clip, d, DEV, engine=clip.engine).load_state_dict(fusion_sd)
+    eng = model.engine
+    im, tk = torch.from_numpy(synth.images(b, cfg, 42)), torch.from_numpy(synth.captions(b, cfg, 42))
+    lc = torch.from_numpy(synth.local_feats(b, d, 42))
+    graw, gloc = torch.from_numpy(synth.global_feats(n, d, tag="hg")), torch.from_numpy(synth.local_feats(n, d, tag="hgl"))
+    rf = eng.encode_image(im.to(DEV))
+    tg, ts = eng.encode_text(tk.to(DEV))
+    q = eng.dvr_fuse(rf, lc.to(DEV), tg, ts)
+    gal = eng.index_fuse(graw, gloc, normalize_input=True)
+    s, i = eng.sim_topk(q, gal, k)
+    eng.sync()
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    csd, fsd = ofusion.as_torch(clip_sd), ofusion.as_torch(fusion_sd)
+    with torch.no_grad():
+        orf = oclip.encode_image(csd, cfg, im)
+        otg, ots = oclip.encode_text(csd, cfg, tk)
+        oq = ofusion.dvr_fuse(fsd, lc, ots, orf, otg)
+        ogal = torch.cat([ofusion.index_fuse(fsd, torch.nn.functional.normalize(graw[o:o + 4096], dim=-1), gloc[o:o + 4096]) for o in range(0, n, 4096)])
+        full = oq @ ogal.T
+        os_, oi = orank.cosine_topk(oq, ogal, k)
+    for name, got, want in (("image", rf, orf), ("text_global", tg, otg), ("text_seq", ts, ots)):
+        assert (got.cpu() - want).abs().max().item() <= 1e-3 * want.abs().max().item(), name
+    assert (q.cpu() - oq).abs().max().item() < 1e-4 and (gal.cpu() - ogal).abs().max().item() < 1e-4      # unit-norm fused features
+    assert (s.cpu() - os_).abs().max().item() < 1e-3
+    gi = i.cpu().long()
+    for r, c in (gi != oi).nonzero().tolist():
+        assert abs(full[r, gi[r, c]].item() - full[r, oi[r, c]].item()) < 2e-6, (r, c)
+    eng.close()
+
+
 def test_cli_driver_runs_on_synthetic_split():
     """python -m fashionern_aaai2024_amd.run.test_fiq: the reference driver's flags on a seeded synthetic split."""
     import subprocess

@@ -120,7 +120,8 @@ def test_ern_modes_and_state_dict_surface():
     short = {k: v for k, v in sd.items() if not k.startswith("Combiner_module.dynamic_scalar.3")}
     with pytest.raises(RuntimeError, match="missing key"):
         model.load_state_dict(short)
-    missing, unexpected = model.load_state_dict(dict(short, **{"DVR.not_a_weight": np.zeros(3, np.float32)}), strict=False)
+    assert model.load_state_dict(dict(short, **{"DVR.not_a_weight": np.zeros(3, np.float32)}), strict=False) is model
+    missing, unexpected = model.missing_keys, model.unexpected_keys
     assert unexpected == ["DVR.not_a_weight"] and sorted(missing) == ["Combiner_module.dynamic_scalar.3.bias", "Combiner_module.dynamic_scalar.3.weight"]
     assert torch.equal(model(ref_feats=g, ref_local_feats=loc, text_feats=g, text_seq_feats=s, mode="test"), out)   # earlier values kept
     no_cls = {k: v for k, v in sd.items() if not k.endswith("cls_token")}
