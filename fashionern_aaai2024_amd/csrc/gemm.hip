@@ -304,9 +304,27 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
     // wave still has ~16 register-only MFMAs to issue while it waits at the barrier and for the next tile's first reads
     // (A/B on MI355X: +3..6 % over draining the copy first, +6 % over pinning the barrier after all MFMAs).
     const int nk = klen / BKT;
+#ifdef FERN_GEMM_TRACE
+    long long* tr = p.trace ? p.trace + ((long)blockIdx.x * NW + wave) * FERN_GEMM_TRACE_SLOTS : nullptr;
+    int tslot = 4;
+#define FERN_TRACE_MARK()                                                                         \
+    do {                                                                                          \
+        if (tr && lane == 0 && tslot < FERN_GEMM_TRACE_SLOTS) tr[tslot] = (long long)__builtin_readcyclecounter(); \
+        ++tslot;                                                                                  \
+    } while (0)
+    if (tr && lane == 0) {
+        tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+        tr[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+        tr[2] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+#else
+#define FERN_TRACE_MARK() do {} while (0)
+#endif
+    FERN_TRACE_MARK();
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    FERN_TRACE_MARK();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BKT);   // the other buffer is free: every wave passed the last barrier
         if (SYNC == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A/B variant: drain the copy before computing
@@ -314,9 +332,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
         if (SYNC == 2) __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my DMA pieces landed, my fragment reads are done
         __builtin_amdgcn_s_barrier();
+        FERN_TRACE_MARK();
     }
     if (FILT) filter_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, bm, bn, wm, wn, l31, lh);
     else gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
+#ifdef FERN_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FERN_TRACE_MARK();
+    if (tr && lane == 0) tr[3] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---- small-M variant on v_mfma_f32_16x16x4_f32 ----------------------------------------------------------------------

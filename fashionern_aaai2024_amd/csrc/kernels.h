@@ -102,7 +102,16 @@ struct GemmParams {
     int out_mx8;
     unsigned char* mxc;
     long mxc_rows;
+#ifdef FERN_GEMM_TRACE
+    // tools/probe/gemm_timeline.hip only (the library is never built with this macro): per-wave cycle stamps of the LDS-DMA
+    // GEMM kernel -- [workgroup][wave][FERN_GEMM_TRACE_SLOTS] = {hw id, xcc id, realtime at entry, realtime at exit, cycle
+    // counter at entry, after the prologue barrier, after the barrier of every k tile, after the epilogue}
+    long long* trace;
+#endif
 };
+#ifdef FERN_GEMM_TRACE
+constexpr int FERN_GEMM_TRACE_SLOTS = 128;
+#endif
 // MX scale layout of a [rows, K] fp8 matrix: scale byte of (row r, 32-k block b) lives at
 //   ((b / 4) * srows + r) * 4 + (b % 4)      (srows >= rows: the array's row count)
 // i.e. one dword per (128-k tile, row) -- what one GEMM workgroup stages per k tile is contiguous over its rows.

@@ -241,12 +241,12 @@ def test_pipeline_lanes_are_bit_identical_to_serial():
             assert torch.equal(i, ri) and torch.equal(s, rs)
     assert all(lg.graph is not None for d_ in pipe._lane_graphs for lg in d_.values())
     # a captured graph holds addresses inside its lane's workspace.  A later, bigger call on the same lane engines
-    # (here: a 31-query batch against a gallery 12 x as large, eager on every lane, and direct calls on engines[0]) makes the
+    # (here: a 700-query batch -- 90 MB of candidate lists against the 64 MB first block -- eager on every lane) makes the
     # contexts re-allocate their workspaces; the old graphs must be noticed as stale and re-captured, never replayed.
     gens = [e.ws_generation() for e in pipe.engines]
     big_gal = eng.index_fuse(torch.from_numpy(synth.global_feats(60000, d, tag="pg2")), torch.from_numpy(synth.local_feats(60000, d, tag="pgl2")), True)
-    big = (torch.from_numpy(synth.images(31, cfg, 300)).cuda(), torch.from_numpy(synth.captions(31, cfg, 300)).cuda(),
-           torch.from_numpy(synth.local_feats(31, d, 300)).cuda())
+    big = (torch.from_numpy(synth.images(700, cfg, 300)).cuda(), torch.from_numpy(synth.captions(700, cfg, 300)).cuda(),
+           torch.from_numpy(synth.local_feats(700, d, 300)).cuda())
     for _ in range(2 * len(pipe.engines)):
         pipe.submit(*big, big_gal, 50).wait()
     torch.cuda.synchronize()

@@ -286,3 +286,45 @@ def test_gelu_approximations_meet_their_documented_bounds():
     tail = x < -3                                   # the negative tail keeps relative accuracy where GELU is still above 1e-5
     big = tail & (np.abs(ref) > 1e-5)
     assert (np.abs(g26 - ref)[big] / np.abs(ref)[big]).max() < 1e-2 and (np.abs(g28 - ref)[big] / np.abs(ref)[big]).max() < 6e-2
+
+
+def test_synthetic_clip_state_dicts_have_the_published_open_clip_layout():
+    """The CLIP towers live in open-clip-torch 2.20.0 (environment.yml:114), absent from /root/reference, so their layout cannot be
+    pinned by importing it.  What CAN be pinned offline are the published parameter counts: open_clip's docs/model_profile.csv lists
+    RN50x4 @288 px at 178.30 M parameters (image tower 87.14 M, text tower 91.16 M) and ViT-B-16 at 149.62 M (86.19 M / 63.43 M)
+    [source quoted from memory of that file; the exact totals 178 300 601 and 149 620 737 are `sum(p.numel())` of the OpenAI
+    checkpoints].  A state dict in open_clip's key layout with any tensor missing, extra or mis-shaped would miss these totals.
+    Buffers (BatchNorm running statistics, num_batches_tracked) are not parameters and are counted separately."""
+    want = {"RN50x4": (178_300_601, 87_137_080, 91_163_521), "ViT-B-16": (149_620_737, 86_192_640, 63_428_097)}
+    for name, (total, image, text) in want.items():
+        cfg = synth.CLIP_CONFIGS[name]
+        sd = synth.clip_state_dict(cfg, 0)
+        params = {k: v for k, v in sd.items() if "running_" not in k and not k.endswith("num_batches_tracked")}
+        vis = sum(v.size for k, v in params.items() if k.startswith("visual."))
+        txt = sum(v.size for k, v in params.items() if not k.startswith("visual."))
+        assert (vis + txt, vis, txt) == (total, image, text), (name, vis + txt, vis, txt)
+        assert round(vis / 1e6, 2) == {"RN50x4": 87.14, "ViT-B-16": 86.19}[name] and round(txt / 1e6, 2) == {"RN50x4": 91.16, "ViT-B-16": 63.43}[name]
+        # key names of the pieces every open_clip CLIP shares
+        for k in ("token_embedding.weight", "positional_embedding", "ln_final.weight", "ln_final.bias", "text_projection", "logit_scale",
+                  "transformer.resblocks.0.attn.in_proj_weight", "transformer.resblocks.11.mlp.c_proj.bias"):
+            assert k in sd, k
+        assert sd["token_embedding.weight"].shape == (49408, cfg.t_width) and sd["positional_embedding"].shape == (77, cfg.t_width)
+    rn = synth.clip_state_dict(synth.CLIP_CONFIGS["RN50x4"], 0)
+    # ModifiedResNet (4, 6, 10, 6) x width 80: stem 40/40/80 channels, stage outputs 320/640/1280/2560, attention pool over 9 x 9 + 1 tokens
+    assert rn["visual.conv1.weight"].shape == (40, 3, 3, 3) and rn["visual.conv3.weight"].shape == (80, 40, 3, 3)
+    assert [sum(1 for k in rn if k.startswith(f"visual.layer{i}.") and k.endswith("conv1.weight")) for i in (1, 2, 3, 4)] == [4, 6, 10, 6]
+    assert rn["visual.layer4.5.conv3.weight"].shape == (2560, 640, 1, 1)
+    assert rn["visual.attnpool.positional_embedding"].shape == (82, 2560) and rn["visual.attnpool.c_proj.weight"].shape == (640, 2560)
+
+
+@pytest.mark.skipif(not os.environ.get("FERN_CLIP_BPE_VOCAB"), reason="needs the user's bpe_simple_vocab_16e6.txt.gz (not available offline)")
+def test_builtin_tokenizer_reproduces_published_clip_token_ids():
+    """With the real merges file the built-in tokenizer must give the ids OpenAI's CLIP README prints for
+    clip.tokenize(["a diagram", "a dog", "a cat"]) -- [49406, 320, 22697 | 1929 | 2368, 49407] (quoted from memory of that README) --
+    this is the pin the merge table lacks offline; it runs wherever FERN_CLIP_BPE_VOCAB is set."""
+    from fashionern_aaai2024_amd.tokenizer import ClipBpeTokenizer
+    tok = ClipBpeTokenizer(os.environ["FERN_CLIP_BPE_VOCAB"])
+    out = tok(["a diagram", "a dog", "a cat"])
+    assert out.shape == (3, 77)
+    for row, word in zip(out.tolist(), (22697, 1929, 2368)):
+        assert row[:4] == [49406, 320, word, 49407] and not any(row[4:])
