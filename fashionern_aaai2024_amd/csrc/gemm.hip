@@ -240,11 +240,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
                 src[j] = p.A + chunk * 4;
             } else {
                 src[j] = p.A + (long)row * p.lda + chunk * 4 + kbeg;
+#ifdef FERN_GEMM_TRACE
+                if (p.packed) src[j] = p.A + (long)row * 16 + chunk * 4;
+#endif
             }
         } else {
             int row = bn * BN + (trow - BM);
             row = row < p.N ? row : p.N - 1;
             src[j] = p.W + sample_row(row, p.w_sample) * p.ldw + chunk * 4 + kbeg;
+#ifdef FERN_GEMM_TRACE
+            if (p.packed) src[j] = p.W + (long)row * 16 + chunk * 4;
+#endif
         }
     }
     auto stage = [&](int buf, int k0) {
@@ -259,6 +265,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
         for (int j = 0; j < PPW; ++j) {
             const int piece = wave + NW * j;
             const float* g = src[j] + k0;
+#ifdef FERN_GEMM_TRACE
+            if (p.packed) g = src[j] + (long)(k0 / 16) * 16 * (piece * RPP < BM ? p.M : p.N);
+#endif
             if (CONV && piece * RPP < BM) {                    // wave-uniform: this piece holds A (activation) rows
                 const int yy = cy[j] + ky, xx = cx[j] + kx;
                 const bool inside = yy >= 0 && yy < p.conv_h && xx >= 0 && xx < p.conv_w;
@@ -330,7 +339,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
         if (SYNC == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A/B variant: drain the copy before computing
         compute(kt & 1);
         if (SYNC == 2) __builtin_amdgcn_sched_barrier(0);
+#ifdef FERN_GEMM_TRACE_PHASES      // three stamps per k tile: MFMAs issued | own DMA landed | barrier passed (pins the order: attribution only)
+        __builtin_amdgcn_sched_barrier(0);
+        FERN_TRACE_MARK();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        FERN_TRACE_MARK();
+#else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my DMA pieces landed, my fragment reads are done
+#endif
         __builtin_amdgcn_s_barrier();
         FERN_TRACE_MARK();
     }
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmParams p) {
     constexpr int PIECES = ROWS / RPP;
     constexpr int PPW = PIECES / NW;
     constexpr int TILE = ROWS * BKT;                     // floats per stage
-    __shared__ __attribute__((aligned(1024))) float smem[STAGES * TILE];
+    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
     if (p.gate && *p.gate == 0) return;
     int kbeg = 0, klen = p.K;
     if (p.ksplit > 1) {      // split-K slice: raw accumulators to kpart[slice]
@@ -515,9 +531,11 @@ static const TileCfg kCfgs[] = {
     {64, 128, 16, 0.93f},    // 9
     {128, 64, 16, 0.93f},    // 10
     {64, 64, 16, 0.86f},     // 11
+    {256, 128, 16, 1.00f},   // 12: 8 waves, 256x128 macro-tile (0.75x the L2->LDS bytes per flop of 128x128), 2 workgroups per CU
+    {128, 256, 16, 1.00f},   // 13
 };
 constexpr int kNumAuto = 4;      // configs the heuristic may pick
-constexpr int kNumCfgs = 12;
+constexpr int kNumCfgs = 14;
 
 static int forced_cfg() {
     static int v = [] {
@@ -588,6 +606,8 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
         case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
         case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
         case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 12: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
+        case 13: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 256, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -738,8 +758,11 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
         (void)hipEventElapsedTime(&ms, e0, e1);
         return ms;
     };
-    static const int cands[] = {0, 1, 2, 3, 6, 8, 9, 10, 11};
-    static const int pairs[][2] = {{8, 11}, {8, 9}, {9, 11}, {10, 11}};
+    static const int cands[] = {0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13};
+    // {bulk cfg, remainder cfg, tiles per round}: the bulk covers the rows whose tiles fill whole rounds of the chip -- 256 = one tile
+    // per CU; the 8-wave macro-tiles keep two workgroups per CU, so a round of 512 gives every CU an even number of them
+    static const int pairs[][3] = {{8, 11, 256}, {8, 9, 256}, {9, 11, 256}, {10, 11, 256}, {12, 8, 256}, {12, 8, 512}, {12, 11, 256}, {12, 11, 512},
+                                   {13, 8, 256}, {13, 8, 512}, {13, 11, 256}, {13, 11, 512}};
     constexpr int NC = sizeof(cands) / sizeof(cands[0]), NP = sizeof(pairs) / sizeof(pairs[0]);
     float t_single[NC], t_pair[NP];
     Plan pair_plan[NP];
@@ -751,6 +774,7 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
         for (int i = 0; i < NC; ++i) {
             const int c = cands[i];
             if (c == 6 && !skinny_ok(p)) continue;
+            if (c >= 12 && (p.epi == EPI_TOPK_FILTER || p.aload != ALOAD_PLAIN || p.M < 2048)) continue;      // macro-tiles: plain loader, stored outputs, deep matrices
             if (c < 8 && p.epi == EPI_TOPK_FILTER) continue;
             if (c >= 8 && p.aload == ALOAD_IM2COL) continue;
             if (c < 8 && p.aload == ALOAD_CONV3) continue;
@@ -760,7 +784,7 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
         for (int i = 0; try_pairs && i < NP; ++i) {
             const int bm = kCfgs[pairs[i][0]].bm, bn = kCfgs[pairs[i][0]].bn;
             const long nbn = (p.N + bn - 1) / bn, tiles = (long)((p.M + bm - 1) / bm) * nbn;
-            const int rows_a = (int)((tiles / 256) * 256 / nbn) * bm;
+            const int rows_a = (int)((tiles / pairs[i][2]) * pairs[i][2] / nbn) * bm;
             if (rows_a < bm || rows_a >= p.M) continue;
             pair_plan[i] = Plan{pairs[i][0], rows_a, pairs[i][1]};
             t_pair[i] = std::min(t_pair[i], timed([&] { return launch_plan(pair_plan[i], q, s); }));
@@ -810,7 +834,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (c == 6 && !skinny_ok(p)) c = (p.K & 31) ? best_of(p.M, p.N, 8, 12) : best_of(p.M, p.N, 0, kNumAuto);   // forced but not applicable
     if (c != 6 && forced_cfg() < 0 && !tunable && p.M <= 64 && p.N >= 256 && skinny_ok(p)) c = 6;     // untuned small-M GEMMs
     if ((p.aload == ALOAD_CONV3 || p.epi == EPI_TOPK_FILTER) && (c < 8 || c > 11)) c = 8 + (c & 3);     // 3x3 window / filtered sweep: LDS-DMA family only
-    if (c >= 8 && p.aload == ALOAD_IM2COL) c -= 8;                        // patch loader: register-staged family only
+    if (c >= 8 && p.aload == ALOAD_IM2COL) c &= 3;                        // patch loader: register-staged family only
     return launch_cfg(c, p, s);
 }
 

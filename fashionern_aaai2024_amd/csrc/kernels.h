@@ -107,10 +107,13 @@ struct GemmParams {
     // GEMM kernel -- [workgroup][wave][FERN_GEMM_TRACE_SLOTS] = {hw id, xcc id, realtime at entry, realtime at exit, cycle
     // counter at entry, after the prologue barrier, after the barrier of every k tile, after the epilogue}
     long long* trace;
+    // layout experiment of the probe: operands stored k-slab-major, [K/16][rows][16] (a tile's 16-k slice of 128 rows is 8 KiB
+    // contiguous: every LDS-DMA instruction reads whole 128-byte lines) instead of row-major [rows][K]
+    int packed;
 #endif
 };
 #ifdef FERN_GEMM_TRACE
-constexpr int FERN_GEMM_TRACE_SLOTS = 128;
+constexpr int FERN_GEMM_TRACE_SLOTS = 256;
 #endif
 // MX scale layout of a [rows, K] fp8 matrix: scale byte of (row r, 32-k block b) lives at
 //   ((b / 4) * srows + r) * 4 + (b % 4)      (srows >= rows: the array's row count)

@@ -216,7 +216,7 @@ def test_topk_large_gallery_many_segments(engine):
     assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 6, 8, 9, 10, 11])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13])
 def test_every_gemm_tile_variant_passes_the_shape_suite(cfg):
     """The launcher autotunes the tile per shape, so each variant is also forced (FERN_GEMM_CFG, read once per process) over
     the whole GEMM shape / epilogue suite, incl. the integer-exactness test: all variants must agree bit for bit."""

@@ -15,6 +15,7 @@ int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 12608, N = argc > 2 ? atoi(argv[2]) : 2304, K = argc > 3 ? atoi(argv[3]) : 768;
     const int cfg = argc > 4 ? atoi(argv[4]) : 8, epi = argc > 5 ? atoi(argv[5]) : EPI_BIAS;
     const char* out = argc > 6 ? argv[6] : "gemm_timeline.csv";
+    const int packed = argc > 7 ? atoi(argv[7]) : 0;      // 1: operands k-slab-major (timing experiment; results are then garbage)
     float *A, *W, *C, *bias;
     hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&W, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4); hipMalloc(&bias, (size_t)N * 4);
     std::vector<float> h((size_t)std::max(M, N) * K);
@@ -25,9 +26,9 @@ int main(int argc, char** argv) {
     hipMemset(bias, 0, (size_t)N * 4);
     hipMemset(C, 0, (size_t)M * N * 4);
     GemmParams p{};
-    p.A = A; p.W = W; p.C = C; p.bias = bias; p.R = C; p.lda = K; p.ldw = K; p.ldc = N; p.M = M; p.N = N; p.K = K; p.epi = epi; p.aload = ALOAD_PLAIN;
+    p.A = A; p.W = W; p.C = C; p.bias = bias; p.R = C; p.lda = K; p.ldw = K; p.ldc = N; p.M = M; p.N = N; p.K = K; p.epi = epi; p.aload = ALOAD_PLAIN; p.packed = packed;
     const int bmv = kCfgs[cfg].bm, bnv = kCfgs[cfg].bn;
-    const long nwg = (long)((M + bmv - 1) / bmv) * ((N + bnv - 1) / bnv), waves = nwg * 4;
+    const long nwg = (long)((M + bmv - 1) / bmv) * ((N + bnv - 1) / bnv), waves = nwg * (cfg >= 12 ? 8 : 4);
     long long* trace;
     hipMalloc(&trace, waves * FERN_GEMM_TRACE_SLOTS * 8);
     hipMemset(trace, 0, waves * FERN_GEMM_TRACE_SLOTS * 8);
@@ -36,7 +37,9 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     p.trace = nullptr;
-    for (int i = 0; i < 5; ++i) launch_cfg(cfg, p, s);
+    // long warm-up: the first milliseconds after an idle spell run on ramping clocks (a 5-launch warm-up measured 1.9 GHz)
+    const int warm = (int)(3e11 / (2.0 * M * N * K)) + 20;
+    for (int i = 0; i < warm; ++i) launch_cfg(cfg, p, s);
     hipEventRecord(e0, s);
     for (int i = 0; i < 10; ++i) launch_cfg(cfg, p, s);
     hipEventRecord(e1, s);
@@ -55,13 +58,18 @@ int main(int argc, char** argv) {
     std::vector<long long> t(waves * FERN_GEMM_TRACE_SLOTS);
     hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost);
     FILE* f = fopen(out, "w");
-    const int nk = K / kCfgs[cfg].bk, marks = nk + 3;
-    fprintf(f, "# M=%d N=%d K=%d cfg=%d epi=%d nk=%d\n", M, N, K, cfg, epi, nk);
+#ifdef FERN_GEMM_TRACE_PHASES
+    const int nk = K / kCfgs[cfg].bk, marks = 3 * nk + 3, phases = 3;
+#else
+    const int nk = K / kCfgs[cfg].bk, marks = nk + 3, phases = 1;
+#endif
+    fprintf(f, "# M=%d N=%d K=%d cfg=%d epi=%d nk=%d phases=%d\n", M, N, K, cfg, epi, nk, phases);
     for (long w = 0; w < waves; ++w) {
         const long long* r = &t[w * FERN_GEMM_TRACE_SLOTS];
         const unsigned hw = (unsigned)r[0];
         // gfx9 HW_ID: wave_id[3:0] simd_id[5:4] pipe_id[7:6] cu_id[11:8] sh_id[12] se_id[15:13]
-        fprintf(f, "%ld,%ld,%u,%u,%u,%u,%lld,%lld", w / 4, w % 4, (unsigned)r[1] & 15, (hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3, r[2], r[3]);
+        const int wpw = cfg >= 12 ? 8 : 4;
+        fprintf(f, "%ld,%ld,%u,%u,%u,%u,%lld,%lld", w / wpw, w % wpw, (unsigned)r[1] & 15, (hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3, r[2], r[3]);
         for (int i = 0; i < marks && 4 + i < FERN_GEMM_TRACE_SLOTS; ++i) fprintf(f, ",%lld", r[4 + i]);
         fprintf(f, "\n");
     }
