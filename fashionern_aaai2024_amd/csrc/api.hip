@@ -117,7 +117,6 @@ struct fern_ctx {
     const fern_ctx* parent = nullptr;
     unsigned parent_generation = 0;
     int* tok_flag = nullptr;         // host-mapped: set by the text embedding kernel when a token id is out of range
-    int* rank_flag = nullptr;        // host-mapped: set when a top-K candidate list overflowed twice (result row is NaN / -1)
     FusionW fusion;
     ClipW clip;
     Clip4CirW c4c;
@@ -367,7 +366,6 @@ static int begin_group(fern_ctx* c, int group) {
     return FERN_OK;
 }
 static int check_token_flag(fern_ctx* c, const char* fn);
-static int check_rank_flag(fern_ctx* c, const char* fn);
 // Weight-reading entry points call this first: a fork made before the parent's last re-finalisation must not run.
 static int check_fresh(fern_ctx* c, const char* fn) {
     if (c->parent && c->parent->generation != c->parent_generation)
@@ -417,7 +415,6 @@ extern "C" int fern_ctx_destroy(fern_ctx* c) {
     for (auto& grp : c->owned)
         for (void* p : grp) (void)hipFree(p);
     if (c->tok_flag) (void)hipHostFree(c->tok_flag);
-    if (c->rank_flag) (void)hipHostFree(c->rank_flag);
     for (auto& b : c->blocks) (void)hipFree(b.p);
     for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -427,7 +424,6 @@ extern "C" int fern_ctx_destroy(fern_ctx* c) {
 extern "C" int fern_sync(fern_ctx* c, void* stream) {
     if (!c) return fail(FERN_ERR_ARG, "fern_sync: ctx is NULL");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    FERN_TRY(check_rank_flag(c, "fern_sync"));
     return check_token_flag(c, "fern_sync");
 }
 
@@ -1417,17 +1413,6 @@ static int check_token_flag(fern_ctx* c, const char* fn) {
                                                  "position " + std::to_string(v - 1) + " of its chunk (its features are NaN): tokenizer / vocabulary mismatch?");
 }
 
-// The fused sweep's candidate lists are sized for ~4x the expected survivors and get one retry with a tightened bound; a second
-// overflow (more than cap^2 / K rows above the sampled bound) leaves NaN / -1 in that query's row and is reported here.
-static int check_rank_flag(fern_ctx* c, const char* fn) {
-    if (!c->rank_flag) return FERN_OK;
-    const int v = __atomic_load_n(c->rank_flag, __ATOMIC_RELAXED);
-    if (v == 0) return FERN_OK;
-    __atomic_store_n(c->rank_flag, 0, __ATOMIC_RELAXED);
-    return fail(FERN_ERR_STATE, std::string(fn) + ": an earlier fern_sim_topk on this context overflowed a candidate list twice (query " +
-                                    std::to_string(v - 1) + " of its chunk): that row holds NaN scores and -1 indices");
-}
-
 extern "C" int fern_text_encode(fern_ctx* c, const int64_t* tokens, const float* visual_emb, const int64_t* visual_emb_shape, float* out_global,
                                 float* out_seq, int B, void* stream) {
     if (!c) return fail(FERN_ERR_ARG, "fern_text_encode: ctx is NULL");
@@ -1463,37 +1448,39 @@ extern "C" int fern_text_encode(fern_ctx* c, const int64_t* tokens, const float*
 //   sample pass   S = max(N / 64, min(N, 4096)) rows, one per run of R = N / S rows, scores stored [m, S]   -> PROF_TOPK
 //   bound         per query the K-th best sample key, a lower bound of the true K-th best                   -> PROF_TOPK
 //   sweep         the full pass: nothing stored, ~K*R survivors per query appended to its 256 lists         -> PROF_SWEEP
-//   select        exact top-K of the lists; an overflowed list raises the query's bound, arms the retry pair -> PROF_TOPK
-//   retry pair    the same sweep + select, gated on flags[0] (empty launches unless a list overflowed)       -> PROF_TOPK
+//   select        exact top-K of the lists; a query with an overflowed list is handed to the exact pass     -> PROF_TOPK
+//   exact pass    gated on flags[0] (an empty launch unless a list overflowed): streams the gallery for the
+//                 flagged queries through sorted wave lists -- no capacity, so the stage is exact whatever
+//                 the gallery looks like                                                                    -> PROF_TOPK
 struct RankPlan {
-    long S; int R; int cap;
+    long S; int R; int cap; int groups;
     float* sample; long ld;
-    unsigned long long* thr; int* count; int* flags;
+    unsigned long long* thr; int* count; int* flags; int* state; int* done;
+    unsigned long long* partial;
     TopkFilter filt;
 };
 static int rank_plan(fern_ctx* c, int m, int64_t N, int K, const int32_t* exclude, int64_t idx_offset, RankPlan* P) {
-    P->S = std::min<long>(std::max<long>(N / 64, std::min<long>(N, 4096)), 32768);      // the bound kernel holds a query's sample in LDS
+    P->S = std::min<long>(std::max<long>(N / 64, std::min<long>(N, 4096)), 32768);      // the bound kernel holds a query's sample in registers
     P->R = P->S > 0 ? (int)(N / P->S) : 1;
-    // a list sees ~K * R / 256 survivors (<= 16 at K = R = 64); 64 entries is what one wave load of the select kernel covers
+    // a list sees ~K * R / 256 survivors (<= 16 at K = R = 64; beyond N = 2M rows R grows past 64 and lists start to overflow:
+    // those queries are then ranked by the exact pass -- still exact, a gallery pass slower); 64 entries is what one wave load of
+    // the select kernel covers
     P->cap = 64;
     static const int cap_override = [] { const char* e = std::getenv("FERN_RANK_CAP"); return e ? std::atoi(e) : 0; }();
-    if (cap_override >= 1 && cap_override <= 64) P->cap = cap_override;     // test hook: tiny lists force the overflow / retry / error paths
+    if (cap_override >= 1 && cap_override <= 64) P->cap = cap_override;     // test hook: tiny lists force the overflow -> exact pass path
     P->ld = (std::max<long>(P->S, 4) + 3) & ~3L;
+    P->groups = (int)std::min<long>(256, std::max<long>(1, (N + 4095) / 4096));
     FERN_TRY(ws_get(c, (size_t)m * P->ld, &P->sample));
     FERN_TRY(ws_get(c, (size_t)m, &P->thr));
     FERN_TRY(ws_get(c, (size_t)m * RANK_SLOTS, &P->count));
     FERN_TRY(ws_get(c, (size_t)4, &P->flags));
+    FERN_TRY(ws_get(c, (size_t)2 * m, &P->state));
+    P->done = P->state + m;
+    FERN_TRY(ws_get(c, (size_t)m * P->groups * 64, &P->partial));
     unsigned long long* cand;
     FERN_TRY(ws_get(c, (size_t)m * RANK_SLOTS * P->cap, &cand));
     P->filt = TopkFilter{cand, P->thr, P->count, exclude, (long)idx_offset, P->cap};
     return FERN_OK;
-}
-static int rank_flag_ready(fern_ctx* c, const char* fn) {
-    if (!c->rank_flag) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->rank_flag), sizeof(int), hipHostMallocMapped));
-        *c->rank_flag = 0;
-    }
-    return check_rank_flag(c, fn);
 }
 static const size_t kRankQueryChunk = 1024;      // queries per plan: bounds cand[m][256][64] (128 KiB per query)
 
@@ -1506,7 +1493,6 @@ extern "C" int fern_sim_topk(fern_ctx* c, const float* q, const float* gallery, 
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) return FERN_OK;
-    FERN_TRY(rank_flag_ready(c, "fern_sim_topk"));
     for (long o = 0; o < B; o += (long)kRankQueryChunk) {
         const int m = (int)std::min<long>((long)kRankQueryChunk, B - o);
         const int32_t* ex = exclude_idx ? exclude_idx + o : nullptr;
@@ -1521,7 +1507,7 @@ extern "C" int fern_sim_topk(fern_ctx* c, const float* q, const float* gallery, 
             p.M = m; p.N = (int)P.S; p.K = D; p.epi = EPI_BIAS; p.aload = ALOAD_PLAIN; p.w_sample = P.R;
             HIP_TRY(launch_gemm(p, s));
         }
-        HIP_TRY(launch_topk_sample_bound(P.sample, P.ld, m, P.S, P.R, K, ex, idx_offset, P.thr, P.count, P.flags, s));
+        HIP_TRY(launch_topk_sample_bound(P.sample, P.ld, m, P.S, P.R, K, ex, idx_offset, P.thr, P.count, P.flags, P.state, s));
         FERN_TRY(prof_close(c, slot, s));
         GemmParams p{};
         p.A = q + o * D; p.lda = D; p.W = gallery; p.ldw = D; p.ldc = 4;
@@ -1529,10 +1515,9 @@ extern "C" int fern_sim_topk(fern_ctx* c, const float* q, const float* gallery, 
         // algorithmic bytes of the sweep: gallery once, queries, results
         if (N > 0) FERN_TRY(run_gemm(c, p, s, PROF_SWEEP, (double)N * D * 4 + (double)m * D * 4 + (double)m * K * 8));
         FERN_TRY(prof_open(c, PROF_TOPK, 0, s, &slot));
-        HIP_TRY(launch_topk_candidates(P.filt, P.thr, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, 0, c->rank_flag, s));
-        p.gate = P.flags;
-        if (N > 0) HIP_TRY(launch_gemm(p, s));
-        HIP_TRY(launch_topk_candidates(P.filt, P.thr, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, 1, c->rank_flag, s));
+        HIP_TRY(launch_topk_candidates(P.filt, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, P.state, s));
+        HIP_TRY(launch_rank_exact(q + o * D, gallery, 0, m, N, D, K, P.state, P.thr, ex, idx_offset, idx_offset, P.partial, P.groups, P.done,
+                                  out_scores + o * K, out_idx + o * K, P.flags, s));
         FERN_TRY(prof_close(c, slot, s));
     }
     return FERN_OK;
@@ -1557,7 +1542,6 @@ extern "C" int fern_sim_topk_bf16(fern_ctx* c, const float* q, const uint16_t* g
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) return FERN_OK;
-    FERN_TRY(rank_flag_ready(c, "fern_sim_topk_bf16"));
     for (long o = 0; o < B; o += (long)kRankQueryChunk) {
         const int m = (int)std::min<long>((long)kRankQueryChunk, B - o);
         const int32_t* ex = exclude_idx ? exclude_idx + o : nullptr;
@@ -1576,7 +1560,7 @@ extern "C" int fern_sim_topk_bf16(fern_ctx* c, const float* q, const uint16_t* g
         for (long b0 = 0; b0 < m; b0 += 64)
             HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery, P.sample + b0 * P.ld, P.ld, (int)std::min<long>(64, m - b0), N, D, P.S, P.R,
                                       nullptr, nullptr, s));
-        HIP_TRY(launch_topk_sample_bound(P.sample, P.ld, m, P.S, P.R, K, ex, idx_offset, P.thr, P.count, P.flags, s));
+        HIP_TRY(launch_topk_sample_bound(P.sample, P.ld, m, P.S, P.R, K, ex, idx_offset, P.thr, P.count, P.flags, P.state, s));
         FERN_TRY(prof_close(c, slot, s));
         for (long b0 = 0; b0 < m; b0 += 64) {
             const int mb = (int)std::min<long>(64, m - b0);
@@ -1586,12 +1570,9 @@ extern "C" int fern_sim_topk_bf16(fern_ctx* c, const float* q, const uint16_t* g
             FERN_TRY(prof_close(c, slot, s));
         }
         FERN_TRY(prof_open(c, PROF_TOPK, 0, s, &slot));
-        HIP_TRY(launch_topk_candidates(P.filt, P.thr, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, 0, c->rank_flag, s));
-        for (long b0 = 0; b0 < m; b0 += 64) {
-            const TopkFilter f = block_filter(b0);
-            HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery, nullptr, 0, (int)std::min<long>(64, m - b0), N, D, 0, 1, &f, P.flags, s));
-        }
-        HIP_TRY(launch_topk_candidates(P.filt, P.thr, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, 1, c->rank_flag, s));
+        HIP_TRY(launch_topk_candidates(P.filt, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, P.state, s));
+        HIP_TRY(launch_rank_exact(q + o * D, gallery, 1, m, N, D, K, P.state, P.thr, ex, idx_offset, idx_offset, P.partial, P.groups, P.done,
+                                  out_scores + o * K, out_idx + o * K, P.flags, s));
         FERN_TRY(prof_close(c, slot, s));
     }
     return FERN_OK;

@@ -176,9 +176,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
 // XOR the same value (conflict-free for the 16-lane groups of ds_read_b128).
 // FILT: the cosine sweep of the fused top-K (EPI_TOPK_FILTER epilogue).  A separate instantiation with a looser register
 // bound (MINW = 2): compiled into the general kernel, the filter epilogue made the 128-VGPR builds spill.
-template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool CONV = false, int SYNC = 0 /* 0: wait+barrier free to sink below the tail MFMAs (fastest), 1: drain copy first, 2: pinned after all MFMAs */,
+// The tile body is a device function of (parameters, linear tile id, LDS) so that one kernel can run tiles of several geometries
+// (gemm_f32_mixed_kernel below); gemm_f32_glds_kernel is the one-geometry wrapper.
+template <int BM, int BN, int WM, int WN, int BKT, bool CONV = false, int SYNC = 0 /* 0: wait+barrier free to sink below the tail MFMAs (fastest), 1: drain copy first, 2: pinned after all MFMAs */,
           bool FILT = false>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_glds_kernel(GemmParams p) {
+__device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* smem) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
     constexpr int NW = WAVES_M * WAVES_N;
@@ -187,18 +189,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
     constexpr int C4 = BKT / 4;                          // 16-byte chunks per tile row (4 or 8)
     constexpr int RPP = 64 / C4;                         // tile rows per 1 KiB piece (16 or 8)
     constexpr int PIECES = ROWS / RPP;
-    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
-    constexpr int PPW = PIECES / NW;                     // pieces per wave per tile
+    constexpr int PPW = (PIECES + NW - 1) / NW;          // pieces per wave per tile (the last ones may not exist: guarded, wave-uniform)
     // swizzle: chunk c of row r lives at position c ^ f(r); f(r) = (r >> 2) & 3 for 64-byte rows, (r >> 1) & 7 for 128-byte rows
     constexpr int FSH = BKT == 16 ? 2 : 1;
     constexpr int FMASK = C4 - 1;
 
-    // ONE __shared__ object: with a second LDS object next to the DMA
-    // destination hipcc drains the DMA (s_waitcnt vmcnt(0)) before the first ds_read of every k step, which serialises
-    // the copy and the MFMAs of a wave.
-    constexpr int TILE = ROWS * BKT;
-    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
-    if (p.gate && *p.gate == 0) return;
+    constexpr int TILE = ROWS * BKT;                     // floats per buffer; smem holds two
     int kbeg = 0, klen = p.K;
     if (p.ksplit > 1) {      // split-K slice: raw accumulators to kpart[slice]
         klen = p.K / p.ksplit;
@@ -214,7 +210,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
 
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const int nwg = nbm * nbn;
-    const int bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int bm = swz / nbn, bn = swz % nbn;
@@ -264,6 +259,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int piece = wave + NW * j;
+            if (PIECES % NW != 0 && piece >= PIECES) continue;   // wave-uniform: this wave has no j-th piece (tile rows do not divide over the waves)
             const float* g = src[j] + k0;
 #ifdef FERN_GEMM_TRACE
             if (p.packed) g = src[j] + (long)(k0 / 16) * 16 * (piece * RPP < BM ? p.M : p.N);
@@ -359,6 +355,48 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
 #endif
 }
 
+// ONE __shared__ object per kernel: with a second LDS object next to the DMA destination hipcc drains the DMA (s_waitcnt vmcnt(0))
+// before the first ds_read of every k step, which serialises the copy and the MFMAs of a wave.
+template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool CONV = false, int SYNC = 0, bool FILT = false>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_glds_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * BKT];
+    if (p.gate && *p.gate == 0) return;
+    glds_tile<BM, BN, WM, WN, BKT, CONV, SYNC, FILT>(p, blockIdx.x, smem);
+}
+
+// ---- mixed-geometry launch ------------------------------------------------------------------------------------------------
+// The 8-wave 256x128 (or 128x256) macro-tile has the best main loop of the family (0.75x the L2 -> LDS bytes per flop of the
+// 128x128 tile: 126-128 TFLOP/s against 121 on a shape both tile evenly, tools/probe/gemm_timeline.hip), but the encoder's GEMMs are
+// only 3.5-9 macro-tiles per CU deep, so whole-matrix macro-tiling loses more to the ragged last round than it gains.  Here ONE
+// launch covers the rows in three bands, big tiles first:  rows [0, ra) in macro-tiles, [ra, rb) in 128x128 tiles, [rb, M) in
+// 64x128 tiles -- all on 8 waves (wave tiles 64x64 / 64x32 / 32x32), every band with its own XCD-aware tile order.  The hardware
+// dispatcher hands out workgroups in block order, so the small tiles back-fill the CUs as the macro-tiles drain instead of waiting
+// behind a kernel boundary (the two-launch bulk + remainder plan serialises there).  Every geometry accumulates each output over k
+// in the same order: results are bit-identical to every other configuration, and the bands can be cut at any row.
+template <bool WIDE>
+__global__ __launch_bounds__(512, 4) void gemm_f32_mixed_kernel(GemmParams p, int ra, int rb, int n_a8, int n_b8) {
+    __shared__ __attribute__((aligned(1024))) float smem[2 * 384 * 16];
+    const int bid = blockIdx.x;
+    auto band = [&](int row0, int rows) {      // the rows [row0, row0 + rows) as a GEMM of their own (plain, row-independent epilogues only)
+        GemmParams q = p;
+        q.A = p.A + (long)row0 * p.lda;
+        q.C = p.C + (long)row0 * p.ldc;
+        if (p.R) q.R = p.R + (long)row0 * p.ldc;
+        q.M = rows;
+        return q;
+    };
+    if (bid < n_a8) {
+        constexpr int BMA = WIDE ? 128 : 256, BNA = WIDE ? 256 : 128;
+        const int tiles = (ra / BMA) * ((p.N + BNA - 1) / BNA);
+        if (bid < tiles) glds_tile<BMA, BNA, 64, 64, 16>(band(0, ra), bid, smem);
+    } else if (bid < n_a8 + n_b8) {
+        const int tiles = ((rb - ra + 127) / 128) * ((p.N + 127) / 128);
+        if (bid - n_a8 < tiles) glds_tile<128, 128, 64, 32, 16>(band(ra, rb - ra), bid - n_a8, smem);
+    } else {
+        glds_tile<64, 128, 32, 32, 16>(band(rb, p.M - rb), bid - n_a8 - n_b8, smem);
+    }
+}
+
 // ---- small-M variant on v_mfma_f32_16x16x4_f32 ----------------------------------------------------------------------
 // The fusion stage is a chain of M = 64 GEMMs (combiner MLPs, class-row chain of the last ViT block): a 32x32 MFMA tile has
 // to walk its whole k chain on one SIMD (K = 4096: 2048 dependent-pipe MFMAs of 64 cycles = 57 us) and there are only
@@ -379,7 +417,7 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(GemmParams p) {
     constexpr int PIECES = ROWS / RPP;
     constexpr int PPW = PIECES / NW;
     constexpr int TILE = ROWS * BKT;                     // floats per stage
-    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE];
+    __shared__ __attribute__((aligned(1024))) float smem[STAGES * TILE];
     if (p.gate && *p.gate == 0) return;
     int kbeg = 0, klen = p.K;
     if (p.ksplit > 1) {      // split-K slice: raw accumulators to kpart[slice]
@@ -637,7 +675,15 @@ struct ShapeKey {
 // fill whole rounds of the 256 CUs; the ragged last round (e.g. 72 of 2 376 tiles at 12608 x 3072: every CU waits for the
 // 72 that got a tenth tile) is recut into small tiles that spread over all CUs.  Every configuration produces bit-identical
 // results, so the split changes nothing but the time.
+// cfg 20 / 21: a MIXED plan (gemm_f32_mixed_kernel, macro-tile 256x128 / 128x256): rows [0, rows_a) in macro-tiles, [rows_a, cfg_b) in
+// 128x128 tiles, [cfg_b, M) in 64x128 tiles, one launch -- cfg_b then holds a ROW, not a configuration.
 struct Plan { int cfg, rows_a, cfg_b; };
+constexpr int kCfgMixed = 20;
+static bool mixed_plan_ok(const Plan& pl, int M) {
+    const int bma = pl.cfg == kCfgMixed + 1 ? 128 : 256;
+    return (pl.cfg == kCfgMixed || pl.cfg == kCfgMixed + 1) && pl.rows_a > 0 && pl.rows_a <= M && pl.rows_a % bma == 0 && pl.cfg_b >= pl.rows_a &&
+           pl.cfg_b <= M && (pl.cfg_b == M || (pl.cfg_b - pl.rows_a) % 128 == 0);
+}
 static std::map<ShapeKey, Plan> g_tuned;
 static std::mutex g_tuned_mu;
 
@@ -649,6 +695,10 @@ static void pin_tile_line(const char* line) {      // caller holds g_tuned_mu
     auto ok = [](int cfg, int K) { return cfg >= 0 && cfg < kNumCfgs && kCfgs[cfg].bk && K % kCfgs[cfg].bk == 0; };
     int M, N, K, epi, aload, cfg, rows_a = 0, cfg_b = 0;
     const int got = sscanf(line, "%15s %d %d %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &aload, &cfg, &rows_a, &cfg_b);
+    if (got == 9 && !strcmp(kind, "f32") && cfg >= kCfgMixed) {
+        if (mixed_plan_ok(Plan{cfg, rows_a, cfg_b}, M) && K % 16 == 0) g_tuned[ShapeKey{M, N, K, epi, aload}] = Plan{cfg, rows_a, cfg_b};
+        return;
+    }
     if (got < 7 || strcmp(kind, "f32") || !ok(cfg, K)) return;
     if (got < 9 || rows_a <= 0 || rows_a >= M || !ok(cfg_b, K)) { rows_a = 0; cfg_b = cfg; }
     g_tuned[ShapeKey{M, N, K, epi, aload}] = Plan{cfg, rows_a, cfg_b};
@@ -713,7 +763,21 @@ static GemmParams tail_rows(const GemmParams& p, int rows_a) {
 static thread_local int g_last_dispatches = 1;
 int gemm_last_dispatches() { return g_last_dispatches; }
 
+static hipError_t launch_mixed(const Plan& pl, const GemmParams& p, hipStream_t s) {
+    if (!mixed_plan_ok(pl, p.M)) return hipErrorInvalidValue;
+    const bool wide = pl.cfg == kCfgMixed + 1;
+    const int bma = wide ? 128 : 256, bna = wide ? 256 : 128;
+    const int ra = pl.rows_a, rb = pl.cfg_b, nbn = (p.N + 127) / 128;
+    const int n_a = (ra / bma) * ((p.N + bna - 1) / bna), n_b = ((rb - ra + 127) / 128) * nbn, n_c = ((p.M - rb + 63) / 64) * nbn;
+    const int n_a8 = (n_a + 7) & ~7, n_b8 = (n_b + 7) & ~7;      // every band starts on a multiple of 8 blocks: block % 8 stays the XCD inside the band
+    const int grid = n_c > 0 ? n_a8 + n_b8 + n_c : n_b > 0 ? n_a8 + n_b : n_a;
+    if (wide) hipLaunchKernelGGL(gemm_f32_mixed_kernel<true>, dim3(grid), dim3(512), 0, s, p, ra, rb, n_a8, n_b8);
+    else hipLaunchKernelGGL(gemm_f32_mixed_kernel<false>, dim3(grid), dim3(512), 0, s, p, ra, rb, n_a8, n_b8);
+    return hipGetLastError();
+}
+
 static hipError_t launch_plan(const Plan& pl, const GemmParams& p, hipStream_t s) {
+    if (pl.cfg >= kCfgMixed) return launch_mixed(pl, p, s);
     if (pl.rows_a <= 0 || pl.rows_a >= p.M) return launch_cfg(pl.cfg, p, s);
     g_last_dispatches = 2;
     GemmParams head = p;
@@ -790,12 +854,45 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
             t_pair[i] = std::min(t_pair[i], timed([&] { return launch_plan(pair_plan[i], q, s); }));
         }
     }
+    // mixed plans (one launch, three bands of rows: macro-tiles, 128x128, 64x128): where to cut is a balance question the
+    // dispatcher answers at run time, so a handful of cuts are simply timed
+    Plan mixed[32];
+    float t_mixed[32];
+    int nmixed = 0;
+    if (try_pairs && p.ksplit <= 1) {
+        auto add = [&](int cfg, int ra, int rb) {
+            const Plan pl{cfg, ra, rb};
+            if (!mixed_plan_ok(pl, p.M) || nmixed >= 32) return;
+            for (int i = 0; i < nmixed; ++i)
+                if (mixed[i].cfg == cfg && mixed[i].rows_a == ra && mixed[i].cfg_b == rb) return;
+            t_mixed[nmixed] = 1e30f;
+            mixed[nmixed++] = pl;
+        };
+        const int nbn = (p.N + 127) / 128;
+        for (int w = 0; w < 2; ++w) {
+            const int bma = w ? 128 : 256, bna = w ? 256 : 128;
+            const long nbna = (p.N + bna - 1) / bna, row_tiles = p.M / bma;
+            const int ras[3] = {(int)row_tiles * bma, (int)((row_tiles * nbna / 512) * 512 / nbna) * bma, (int)((row_tiles * nbna / 256) * 256 / nbna) * bma};
+            for (int ra : ras) {
+                if (ra < bma) continue;
+                const int mr = p.M - ra;
+                add(kCfgMixed + w, ra, p.M);                                   // the rest in 128x128 tiles
+                add(kCfgMixed + w, ra, ra);                                     // the rest in 64x128 tiles
+                add(kCfgMixed + w, ra, ra + (mr / 128) * 128);                  // whole 128-row tiles, the ragged tail in 64x128
+                add(kCfgMixed + w, ra, ra + (int)(((long)(mr / 128) * nbn / 256) * 256 / nbn) * 128);      // 128x128 tiles in whole rounds of the chip
+            }
+        }
+        for (int round = 0; round < 2; ++round)
+            for (int i = 0; i < nmixed; ++i) t_mixed[i] = std::min(t_mixed[i], timed([&] { return launch_mixed(mixed[i], q, s); }));
+    }
     Plan best = fallback;
     float best_ms = 1e30f;
     for (int i = 0; i < NC; ++i)
         if (t_single[i] < best_ms) { best_ms = t_single[i]; best = Plan{cands[i], 0, cands[i]}; }
     for (int i = 0; i < NP; ++i)
         if (t_pair[i] < best_ms * 0.99f) { best_ms = t_pair[i]; best = pair_plan[i]; }      // two launches must earn their keep
+    for (int i = 0; i < nmixed; ++i)
+        if (t_mixed[i] < best_ms) { best_ms = t_mixed[i]; best = mixed[i]; }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(scratch);
@@ -829,7 +926,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
             if (tuned) g_tuned.emplace(key, pl);
         }
         if (pl.rows_a > 0 && split_ok(p)) return launch_plan(pl, p, s);
-        c = pl.cfg;
+        c = pl.cfg < kCfgMixed ? pl.cfg : choose_cfg(p.M, p.N, p.K);      // a pinned mixed plan on a call it cannot serve: heuristic tile
     }
     if (c == 6 && !skinny_ok(p)) c = (p.K & 31) ? best_of(p.M, p.N, 8, 12) : best_of(p.M, p.N, 0, kNumAuto);   // forced but not applicable
     if (c != 6 && forced_cfg() < 0 && !tunable && p.M <= 64 && p.N >= 256 && skinny_ok(p)) c = 6;     // untuned small-M GEMMs

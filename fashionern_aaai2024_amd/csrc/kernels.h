@@ -13,15 +13,26 @@ namespace fern {
 // and takes each query's K-th best sample key as a lower bound of its true K-th best; the full sweep then appends only
 // the scores that reach that bound (about K*R of N per query) to the query's candidate lists, and the final kernel
 // selects the exact top-K from them.  Keys order by (score desc, gallery index asc) as one unsigned compare.
-// A query owns RANK_SLOTS lists; gallery row n appends to list n % RANK_SLOTS.  So the append counters are spread over
+// A query owns RANK_SLOTS lists; gallery row n appends to list rank_slot(n) (n % RANK_SLOTS rotated by a hash of n / RANK_SLOTS).  So the append counters are spread over
 // B * RANK_SLOTS addresses (returning atomics on ONE address serialise chip-wide at ~5 per us: with one counter per query the
 // sweep was 15x slower than its HBM time), the lanes of a tile never collide, and a run of consecutive good rows -- near
 // duplicates sit next to each other in real galleries -- lands in different lists instead of overflowing one.
 constexpr int RANK_SLOTS = 256;
+// list of gallery row n: inside every aligned block of 256 rows the mapping is a rotation (consecutive rows -- near duplicates sit
+// next to each other in real galleries -- and the lanes of a tile land in different lists), and the rotation is a hash of the
+// block number, so rows a multiple of 256 apart (a base set tiled up to 1M rows puts every copy of an item there) do NOT
+// share a list.
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline int rank_slot(long n) {
+    const unsigned blk = (unsigned)(n >> 8);
+    return (int)(((unsigned)n + ((blk * 0x9E3779B1u) >> 24)) & (RANK_SLOTS - 1));
+}
 struct TopkFilter {
     unsigned long long* cand;             // [B][RANK_SLOTS][cap] candidate keys, appended in arrival order
     const unsigned long long* thr_key;    // [B] lower bound: keys below it are not in the top-K (0: accept all, ~0: reject all)
-    int* count;                           // [B][RANK_SLOTS] candidates offered so far (may exceed cap: overflow -> retry pass)
+    int* count;                           // [B][RANK_SLOTS] candidates offered so far (may exceed cap: overflow -> exact pass for that query)
     const int* exclude;                   // [B] gallery index to drop per query (CIRR reference removal), or null ...
     long exclude_off;                     // ... as a global index: the local row is exclude[q] - exclude_off
     int cap;                              // entries per list (<= 64: the select kernel reads a list with one wave load)
@@ -164,7 +175,7 @@ __device__ __forceinline__ void topk_filter_tile(const f32x16_t& acc, const floa
     for (int r = 0; r < 16; ++r) hits |= (!(acc[r] < bound[r]) ? 1u : 0u) << r;
     hits = n_ok ? hits : 0u;
     if (!__any(hits != 0)) return;
-    const long slot = n & (RANK_SLOTS - 1);
+    const long slot = rank_slot(n);
     const bool use_ex = f.exclude != nullptr;
     // eight registers at a time: their appends are issued back to back (one round trip for the returned positions), and the
     // live state stays small -- with all 16 positions live the 128-VGPR GEMM kernels spilled
@@ -317,14 +328,21 @@ hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* sco
 // sample_row(c, R)) -> thr_key[b] (0 when the sample holds fewer than K rows); also resets count[b][*] and flags[0..1].  A sample
 // row that is the query's excluded gallery index (exclude[b] - exclude_off, exclude may be null) does not count.
 hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S, int R, int K, const int* exclude, long exclude_off,
-                                    unsigned long long* thr_key, int* count, int* flags, hipStream_t s);
+                                    unsigned long long* thr_key, int* count, int* flags, int* state, hipStream_t s);
 // Fused sweep, final step: exact top-K of each query's candidate list -> out (idx = row + idx_offset; unfilled: -inf / -1).
 // A query with an overflowed list (a count > cap) is not written in the first pass: its bound is raised to the K-th best of the
 // stored candidates, its counts reset, flags[0] set, and the sweep + this kernel run again with pass = 1 (gated on
 // flags[0]); queries that did not overflow get bound ~0 (reject all) for that pass.  An overflow in pass 1 sets *error_flag
 // (host-mapped) and writes NaN scores / idx -1.
-hipError_t launch_topk_candidates(const TopkFilter& f, unsigned long long* thr_key_rw, int B, int K, long idx_offset, float* out_scores,
-                                  int* out_idx, int* flags, int pass, int* error_flag, hipStream_t s);
+// Exact pass for the queries whose candidate lists overflowed (state[b] != 0; gated on flags[0]): every workgroup streams its share
+// of the gallery through the SAME MFMA sequence as the sweep (bit-identical scores) into sorted wave lists, the last workgroup of
+// a query merges the partial lists.  No capacity anywhere: the ranking stage is exact by construction.
+hipError_t launch_rank_exact(const float* q, const void* gallery, int gallery_bf16, int B, long N, int D, int K, const int* state,
+                             const unsigned long long* thr_key, const int* exclude, long exclude_off, long idx_offset,
+                             unsigned long long* partial, int groups, int* done, float* out_scores, int* out_idx, const int* gate,
+                             hipStream_t s);
+hipError_t launch_topk_candidates(const TopkFilter& f, int B, int K, long idx_offset, float* out_scores, int* out_idx, int* flags,
+                                  int* state, hipStream_t s);
 // Merge R lists [R,B,K] (score, idx) -> [B,K]
 hipError_t launch_topk_merge(const float* scores, const int* idx, float* out_scores, int* out_idx, int R, int B, int K,
                              hipStream_t s);

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
                 const unsigned long long key = qkey[i];
                 const int qi = qq[i];
                 const long n = (long)(0xFFFFFFFFu - (unsigned)key);
-                const long list = (long)qi * RANK_SLOTS + (n & (RANK_SLOTS - 1));
+                const long list = (long)qi * RANK_SLOTS + rank_slot(n);
                 const int pos = atomicAdd(&filt.count[list], 1);
                 if (pos < filt.cap) filt.cand[list * filt.cap + pos] = key;
             }

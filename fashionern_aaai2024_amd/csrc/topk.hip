@@ -189,10 +189,81 @@ struct WgReduce {
     }
     __device__ __forceinline__ unsigned max(unsigned local) { return ~min(~local); }
 };
-// k-th largest (k >= 1) of the workgroup's keys: thread-local hi words h[0..PER) (0 = empty slot) and lo words from lo_of(j).
-// Returns 0 when fewer than k keys exist.  Every thread of the workgroup (NW waves) must call it (barriers inside).
+// Fast path of the selection below.  A bisection step is mostly its barrier (LDS write, barrier, LDS read: ~350 ns with 4 waves,
+// more with 16), and 30-odd steps made the bound and select kernels 14-23 us each.  Instead: every wave sorts its 64 lane maxima
+// (registers only) and publishes the ceil(k / NW)-th largest; the minimum L0 of those NW values has at least k keys at or above it
+// (ceil(k / NW) lanes of every wave hold one), so the k-th largest key lies among the keys with hi >= L0 -- typically a few more
+// than k of the thousands.  Those are compacted into LDS (one prefix sum) and ranked by counting (every candidate reads the
+// compact list once, broadcast reads): the candidate with k - 1 keys above it is the answer.  Four barriers in all.  More than
+// CAPF candidates (tie-heavy galleries: thousands of keys share the k-th score) fall back to the bisection.
+__device__ __forceinline__ unsigned sort64_desc_u32(unsigned v, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            const unsigned o = __shfl_xor(v, j);
+            const bool desc = (lane & k) == 0 || k == 64;
+            const bool low = (lane & j) == 0;
+            const bool keep_max = desc ? low : !low;
+            v = keep_max ? (v > o ? v : o) : (v > o ? o : v);
+        }
+    }
+    return v;
+}
+constexpr int SELECT_CAPF = 512;
+// returns true and the k-th largest key in `out` when the fast path applies; every thread must call it (barriers inside);
+// ck: SELECT_CAPF keys of LDS, red: 4 * NW + 8 ints of LDS.  The caller has checked that at least k keys exist.
 template <int PER, int NW, class LoOf>
-__device__ __forceinline__ u64 select_kth_largest(const unsigned (&h)[PER], LoOf lo_of, int k, int* red) {
+__device__ __forceinline__ bool select_kth_fast(const unsigned (&h)[PER], LoOf lo_of, int k, u64* ck, int* red, u64& out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned tmax = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) tmax = h[j] > tmax ? h[j] : tmax;
+    const unsigned sorted = sort64_desc_u32(tmax, lane);
+    const int tw = (k + NW - 1) / NW;                                   // <= 64: k <= 64
+    const unsigned vw = (unsigned)__builtin_amdgcn_readlane((int)sorted, tw - 1);
+    unsigned* ured = reinterpret_cast<unsigned*>(red);
+    if (lane == 0) ured[wave] = vw;
+    __syncthreads();
+    unsigned l0 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) l0 = ured[w] < l0 ? ured[w] : l0;
+    l0 = l0 == 0 ? 1u : l0;                                             // 0 marks an empty slot, never a candidate
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) cnt += h[j] >= l0;
+    const int incl = wave_inclusive_sum(cnt, lane);
+    if (lane == 63) red[NW + wave] = incl;
+    __syncthreads();
+    int base = incl - cnt, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        base += w < wave ? red[NW + w] : 0;
+        total += red[NW + w];
+    }
+    if (total > SELECT_CAPF) return false;                               // uniform
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        if (h[j] >= l0) ck[base++] = ((u64)h[j] << 32) | lo_of(j);
+    if (tid == 0) { red[2 * NW] = 0; red[2 * NW + 1] = 0; }
+    __syncthreads();
+    for (int i = tid; i < total; i += NW * 64) {
+        const u64 key = ck[i];
+        int rank = 0;
+        for (int j = 0; j < total; ++j) rank += ck[j] > key;
+        if (rank == k - 1) { red[2 * NW] = (int)(unsigned)key; red[2 * NW + 1] = (int)(unsigned)(key >> 32); }
+    }
+    __syncthreads();
+    out = ((u64)(unsigned)red[2 * NW + 1] << 32) | (unsigned)red[2 * NW];
+    __syncthreads();                                                     // red / ck may be reused by the caller
+    return true;
+}
+
+// k-th largest (k >= 1) of the workgroup's keys: thread-local hi words h[0..PER) (0 = empty slot) and lo words from lo_of(j).
+// Returns 0 when fewer than k keys exist.  Every thread of the workgroup (NW waves) must call it (barriers inside).  `ck`:
+// SELECT_CAPF keys of LDS for the fast path (null: bisection only); red: 4 * NW + 8 ints.
+template <int PER, int NW, class LoOf>
+__device__ __forceinline__ u64 select_kth_largest(const unsigned (&h)[PER], LoOf lo_of, int k, int* red, u64* ck = nullptr) {
     WgReduce<NW> wg{red, 0};
     int nv = 0;
     unsigned mn = 0xFFFFFFFFu, mx = 0;
@@ -203,6 +274,12 @@ __device__ __forceinline__ u64 select_kth_largest(const unsigned (&h)[PER], LoOf
         mx = h[j] > mx ? h[j] : mx;
     }
     if (wg.sum(nv) < k) return 0;
+    if (ck) {
+        __syncthreads();                                                 // the reduction above is done with `red`
+        u64 fast;
+        if (select_kth_fast<PER, NW>(h, lo_of, k, ck, red, fast)) return fast;
+        wg.step = 0;
+    }
     unsigned lo = wg.min(mn), hi = wg.max(mx);
     while (lo < hi) {                                     // largest v with count(h >= v) >= k
         const unsigned mid = lo + (unsigned)(((u64)hi - lo + 1) >> 1);
@@ -242,10 +319,13 @@ __device__ __forceinline__ u64 select_kth_largest(const unsigned (&h)[PER], LoOf
 // registers -- 1024 threads, thread t holds columns t, t + 1024, ... (four waves per SIMD keep the compare stream dense) -- and publishes the K-th best key as the query's bound.  Sample columns
 // are in gallery order, so a key built from the column index ranks ties like one built from the row; the published key carries
 // the real row.  Fewer than K sample rows -> bound 0 (accept all).  Also resets the query's list counters.
-template <int PER>
-__global__ __launch_bounds__(1024) void topk_sample_bound_kernel(const float* scores, long ld, long S, int R, int K, const int* exclude,
-                                                                long exclude_off, u64* thr_key, int* count, int* flags) {
-    __shared__ int red[64];
+// NT threads: 256 (four waves: a barrier among them is a fraction of the 16-wave one, and a bisection step is mostly barrier) for
+// samples of <= 4096 rows, 1024 for the larger ones (registers: PER keys per thread).
+template <int PER, int NT>
+__global__ __launch_bounds__(NT) void topk_sample_bound_kernel(const float* scores, long ld, long S, int R, int K, const int* exclude,
+                                                                long exclude_off, u64* thr_key, int* count, int* flags, int* state) {
+    __shared__ int red[80];
+    __shared__ u64 ck[SELECT_CAPF];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* row = scores + (long)b * ld;
     // sample column of the excluded gallery row (if it was sampled at all): it must not count towards the K rows of the bound
@@ -257,13 +337,13 @@ __global__ __launch_bounds__(1024) void topk_sample_bound_kernel(const float* sc
     unsigned h[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const long c = tid + 1024L * j;
+        const long c = tid + (long)NT * j;
         float v = -INFINITY;
         if (c < S && c != drop) v = row[c];
         h[j] = v == -INFINITY ? 0u : orderable(v);                          // -inf marks padding
     }
-    if (tid < RANK_SLOTS) count[(long)b * RANK_SLOTS + tid] = 0;
-    const u64 kth = select_kth_largest<PER, 16>(h, [&](int j) { return 0xFFFFFFFFu - (unsigned)(tid + 1024 * j); }, K, red);
+    for (int i = tid; i < RANK_SLOTS; i += NT) count[(long)b * RANK_SLOTS + i] = 0;
+    const u64 kth = select_kth_largest<PER, NT / 64>(h, [&](int j) { return 0xFFFFFFFFu - (unsigned)(tid + NT * j); }, K, red, ck);
     if (tid == 0) {
         u64 out = 0;
         if (kth != 0) {
@@ -271,6 +351,8 @@ __global__ __launch_bounds__(1024) void topk_sample_bound_kernel(const float* sc
             out = (kth & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - (unsigned)sample_row(c, R));
         }
         thr_key[b] = out;
+        state[b] = 0;                      // 0: ranked by the select kernel; 1: lists overflowed -> exact pass; also its done-counter
+        state[gridDim.x + b] = 0;
         if (b == 0) { flags[0] = 0; flags[1] = 0; }
     }
 }
@@ -281,30 +363,29 @@ __global__ __launch_bounds__(1024) void topk_sample_bound_kernel(const float* sc
 // candidates (lists near full) take the streaming path.
 constexpr int CAND_PER = 24;                    // keys per thread
 constexpr int CAND_MAX = CAND_PER * 256;        // 6144 keys x 8 bytes of LDS
-__global__ __launch_bounds__(256) void topk_candidates_kernel(TopkFilter f, u64* thr_key_rw, int K, long idx_offset, float* out_scores,
-                                                              int* out_idx, int* flags, int pass, int* error_flag) {
+__global__ __launch_bounds__(256) void topk_candidates_kernel(TopkFilter f, int K, long idx_offset, float* out_scores, int* out_idx,
+                                                              int* flags, int* state) {
     __shared__ u64 c_key[CAND_MAX];
-    __shared__ int red[16];
+    __shared__ int red[32];
     __shared__ u64 lists[4][64];
     __shared__ int wtotal[4], over[4], nsel;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (pass == 1) {
-        if (flags[0] == 0) return;                       // no query overflowed in pass 0: nothing to redo
-        if (thr_key_rw[b] == ~0ull) return;              // this query was final after pass 0
-    }
-    int* cnt_p = f.count + (long)b * RANK_SLOTS + tid;   // thread t owns list t
-    const int cnt_raw = *cnt_p;
+    const int cnt_raw = f.count[(long)b * RANK_SLOTS + tid];      // thread t owns list t
     const int cnt = cnt_raw < f.cap ? cnt_raw : f.cap;
     const bool overflow_w = __any(cnt_raw > f.cap);
     const int incl = wave_inclusive_sum(cnt, lane);
     if (lane == 63) { wtotal[wave] = incl; over[wave] = overflow_w ? 1 : 0; }
     if (tid == 0) nsel = 0;
     __syncthreads();
+    if ((over[0] | over[1] | over[2] | over[3]) != 0) {
+        // More rows reached the sampled bound than a list holds (a sample that missed a cluster of good rows, a gallery of
+        // near-ties): this query goes to the exact pass (rank_exact_kernel), which has no capacity anywhere.
+        if (tid == 0) { state[b] = 1; flags[0] = 1; }
+        return;
+    }
     int base = incl - cnt;
     for (int w = 0; w < wave; ++w) base += wtotal[w];
     const int total = wtotal[0] + wtotal[1] + wtotal[2] + wtotal[3];
-    const bool overflow = (over[0] | over[1] | over[2] | over[3]) != 0;
-    if (overflow && pass == 0) *cnt_p = 0;               // the retry sweep appends to empty lists
     const u64* cand = f.cand + (long)b * RANK_SLOTS * f.cap;
     u64 best = 0;                                        // wave 0 ends up with the sorted top-64 (lane i = i-th best)
     if (total <= CAND_MAX) {
@@ -334,7 +415,8 @@ __global__ __launch_bounds__(256) void topk_candidates_kernel(TopkFilter f, u64*
         }
         const int want = total < K ? total : K;          // fewer candidates than K: all of them rank
         u64 kth = 0;
-        if (total > 64) kth = select_kth_largest<CAND_PER, 4>(h, [&](int j) { return (unsigned)mine[j]; }, want, red);
+        __syncthreads();                                 // every thread holds its keys in registers: c_key's head becomes the fast path's compact list
+        if (total > 64) kth = select_kth_largest<CAND_PER, 4>(h, [&](int j) { return (unsigned)mine[j]; }, want, red, c_key);
 #pragma unroll
         for (int j = 0; j < CAND_PER; ++j) {
             if (mine[j] != 0 && mine[j] >= kth) {
@@ -359,20 +441,6 @@ __global__ __launch_bounds__(256) void topk_candidates_kernel(TopkFilter f, u64*
 #pragma unroll 1
         for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, lists[w][lane], lane);
     }
-    if (overflow) {
-        // More rows reached the bound than a list holds (a sample that missed a cluster of good rows).  The K-th best of
-        // what WAS stored is still a valid -- and much tighter -- bound (K distinct rows reach it): sweep once more with it.
-        const u64 kth = shfl64(best, K - 1);
-        if (pass == 0 && kth != 0) {
-            if (lane == 0) { thr_key_rw[b] = kth; flags[0] = 1; }
-            return;
-        }
-        if (lane == 0 && error_flag) __hip_atomic_store(error_flag, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (pass == 0 && lane == 0) thr_key_rw[b] = ~0ull;
-        if (lane < K) { out_scores[(long)b * K + lane] = __builtin_nanf(""); out_idx[(long)b * K + lane] = -1; }
-        return;
-    }
-    if (pass == 0 && lane == 0) thr_key_rw[b] = ~0ull;   // final: a retry sweep (if another query needs one) must skip this query
     if (lane < K) {
         float sc = -INFINITY;
         int idx = -1;
@@ -385,25 +453,137 @@ __global__ __launch_bounds__(256) void topk_candidates_kernel(TopkFilter f, u64*
     }
 }
 
+// ---- exact pass ---------------------------------------------------------------------------------------------------------------
+// Runs (gated on flags[0]) for the queries the select kernel sent here.  One launch of `groups` workgroups; workgroup g, wave w
+// owns the 32-row gallery tiles (4g + w) + j * 4 * groups.  A tile's scores come from the SAME MFMA sequence as the sweep kernels
+// -- fp32: v_mfma_f32_32x32x2_f32 per 8-group g8 and e = 0..3 with lane half h feeding k = 8 g8 + 4 h + e (gemm.hip); bf16:
+// v_mfma_f32_32x32x16_bf16 per 16-k step with lane half h feeding k = 16 ks + 8 h .. + 7, the query rounded to bf16 like
+// sweep_bf16.hip does -- with the query broadcast to all 32 A rows, so lane n & 31 ends up with the bit-identical score of gallery
+// row n.  Keys that reach the query's (still valid) sampled bound are offered to the wave's sorted list; the four wave lists are
+// merged through LDS into partial[b][g], and the last workgroup to finish a query (a ticket in done[b]) merges the partial lists
+// and writes the ranking.  Nothing here has a capacity: whatever the gallery looks like, the result is the exact top-K.
+typedef float f32x16e __attribute__((ext_vector_type(16)));
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+typedef short bf16x8e __attribute__((ext_vector_type(8)));
+template <bool BF16>
+__global__ __launch_bounds__(256) void rank_exact_kernel(const float* q, const void* gallery, int B, long N, int D, int K, const int* state,
+                                                         const u64* thr_key, const int* exclude, long exclude_off, long idx_offset,
+                                                         u64* partial, int* done, float* out_scores, int* out_idx, const int* gate) {
+    if (*gate == 0) return;
+    __shared__ u64 lists[4][64];
+    __shared__ int last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int G = gridDim.x, g = blockIdx.x;
+    const long ntiles = (N + 31) / 32;
+    for (int b = 0; b < B; ++b) {
+        if (state[b] == 0) continue;                               // uniform
+        const u64 thr = thr_key[b];
+        const long ex = exclude ? (long)exclude[b] - exclude_off : -1;
+        const float* qrow = q + (long)b * D;
+        u64 best = 0;
+        for (long t = (long)g * 4 + wave; t < ntiles; t += (long)G * 4) {
+            const long n = t * 32 + l31;
+            const long nc = n < N ? n : N - 1;
+            f32x16e acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            if (BF16) {
+                const unsigned short* grow = reinterpret_cast<const unsigned short*>(gallery) + nc * D;
+                for (int ks = 0; ks < D / 16; ++ks) {
+                    const f32x4e a0 = *reinterpret_cast<const f32x4e*>(qrow + ks * 16 + lh * 8);
+                    const f32x4e a1 = *reinterpret_cast<const f32x4e*>(qrow + ks * 16 + lh * 8 + 4);
+                    bf16x8e af;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { af[e] = (short)f32_to_bf16_bits(a0[e]); af[4 + e] = (short)f32_to_bf16_bits(a1[e]); }
+                    const bf16x8e bf = *reinterpret_cast<const bf16x8e*>(grow + ks * 16 + lh * 8);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+                }
+            } else {
+                const float* grow = reinterpret_cast<const float*>(gallery) + nc * D;
+                for (int g8 = 0; g8 < D / 8; ++g8) {
+                    const f32x4e af = *reinterpret_cast<const f32x4e*>(qrow + g8 * 8 + lh * 4);
+                    const f32x4e bf = *reinterpret_cast<const f32x4e*>(grow + g8 * 8 + lh * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+                }
+            }
+            u64 cand = 0;                                          // every A row is the query: acc[0] of lane n & 31 is row n's score
+            if (lane < 32 && n < N && n != ex) {
+                const u64 key = make_key(acc[0], (unsigned)n);
+                cand = key >= thr ? key : 0;
+            }
+            wave_offer(best, cand, K, lane);
+        }
+        lists[wave][lane] = best;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll 1
+            for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, lists[w][lane], lane);
+            partial[((long)b * G + g) * 64 + lane] = best;
+            __threadfence();
+            int ticket = 0;
+            if (lane == 0) ticket = atomicAdd(&done[b], 1);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            if (lane == 0) last = ticket == G - 1;
+        }
+        __syncthreads();
+        if (last && wave == 0) {                                   // every other workgroup's partial list is visible (its fence precedes its ticket)
+            __threadfence();
+            u64 top = 0;
+#pragma unroll 1
+            for (int gg = 0; gg < G; ++gg) {
+                const u64 other = __hip_atomic_load(&partial[((long)b * G + gg) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                top = gg == 0 ? other : merge_sorted_desc(top, other, lane);
+            }
+            if (lane < K) {
+                float sc = -INFINITY;
+                int idx = -1;
+                if (top != 0) {
+                    sc = unorderable((unsigned)(top >> 32));
+                    idx = (int)((long)(0xFFFFFFFFu - (unsigned)top) + idx_offset);
+                }
+                out_scores[(long)b * K + lane] = sc;
+                out_idx[(long)b * K + lane] = idx;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S, int R, int K, const int* exclude, long exclude_off,
-                                    u64* thr_key, int* count, int* flags, hipStream_t s) {
+                                    u64* thr_key, int* count, int* flags, int* state, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (K < 1 || K > 64 || S < 0 || R < 1) return hipErrorInvalidValue;
     // keys per thread of the bisection (registers): the plan caps S at 32768 (api.hip: rank_plan)
-    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(B), dim3(1024), 0, s, scores, ld, S, R, K, exclude, exclude_off, thr_key, count, flags); };
-    if (S <= 4 * 1024) go(topk_sample_bound_kernel<4>);
-    else if (S <= 16 * 1024) go(topk_sample_bound_kernel<16>);
-    else if (S <= 32 * 1024) go(topk_sample_bound_kernel<32>);
+    auto go = [&](auto kern, int nt) { hipLaunchKernelGGL(kern, dim3(B), dim3(nt), 0, s, scores, ld, S, R, K, exclude, exclude_off, thr_key, count, flags, state); };
+    if (S <= 1024) go(topk_sample_bound_kernel<4, 256>, 256);
+    else if (S <= 4096) go(topk_sample_bound_kernel<16, 256>, 256);
+    else if (S <= 16 * 1024) go(topk_sample_bound_kernel<16, 1024>, 1024);
+    else if (S <= 32 * 1024) go(topk_sample_bound_kernel<32, 1024>, 1024);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
-hipError_t launch_topk_candidates(const TopkFilter& f, u64* thr_key_rw, int B, int K, long idx_offset, float* out_scores, int* out_idx,
-                                  int* flags, int pass, int* error_flag, hipStream_t s) {
+hipError_t launch_topk_candidates(const TopkFilter& f, int B, int K, long idx_offset, float* out_scores, int* out_idx, int* flags,
+                                  int* state, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (K < 1 || K > 64 || f.cap < 1 || f.cap > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(topk_candidates_kernel, dim3(B), dim3(256), 0, s, f, thr_key_rw, K, idx_offset, out_scores, out_idx, flags, pass,
-                       error_flag);
+    hipLaunchKernelGGL(topk_candidates_kernel, dim3(B), dim3(256), 0, s, f, K, idx_offset, out_scores, out_idx, flags, state);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_exact(const float* q, const void* gallery, int gallery_bf16, int B, long N, int D, int K, const int* state,
+                             const unsigned long long* thr_key, const int* exclude, long exclude_off, long idx_offset,
+                             unsigned long long* partial, int groups, int* done, float* out_scores, int* out_idx, const int* gate,
+                             hipStream_t s) {
+    if (B <= 0 || N <= 0) return hipSuccess;
+    if (K < 1 || K > 64 || groups < 1 || D % (gallery_bf16 ? 16 : 8)) return hipErrorInvalidValue;
+    if (gallery_bf16)
+        hipLaunchKernelGGL(rank_exact_kernel<true>, dim3(groups), dim3(256), 0, s, q, gallery, B, N, D, K, state, thr_key, exclude, exclude_off,
+                           idx_offset, partial, done, out_scores, out_idx, gate);
+    else
+        hipLaunchKernelGGL(rank_exact_kernel<false>, dim3(groups), dim3(256), 0, s, q, gallery, B, N, D, K, state, thr_key, exclude, exclude_off,
+                           idx_offset, partial, done, out_scores, out_idx, gate);
     return hipGetLastError();
 }
 

@@ -127,7 +127,7 @@ typedef struct {
     double attn_ms;
     double attn_flops;
     int64_t attn_launches;
-    double topk_ms;        /* the rest of the ranking stage: sample pass, bound, candidate selection, gated retry pair */
+    double topk_ms;        /* the rest of the ranking stage: sample pass, bound, candidate selection, gated exact pass */
     int64_t topk_launches;
     double sweep_ms;       /* the filtered similarity sweep inside fern_sim_topk / fern_sim_topk_bf16 */
     double sweep_bytes;    /* algorithmic bytes of those sweeps: N*D*s_g + B*D*4 + B*K*8 */
@@ -236,7 +236,8 @@ FERN_API int fern_u8_to_normalized_chw(fern_ctx* ctx, const uint8_t* src, int64_
  * Scores are cosines (q.g), sorted descending, ties -> lower gallery index.  out_idx holds
  * local row + idx_offset; exclude_idx (may be NULL) [B] removes one global index per query
  * (CIRR reference removal, run/test/test_cirr.py:55-58).  Unfilled slots: score -inf, idx -1.
- * 1 <= K <= 64. */
+ * 1 <= K <= 64.  Exact for every gallery: the [B, N] scores are never stored -- a sampled bound filters the sweep into candidate
+ * lists -- and a query whose lists overflow is ranked by a capacity-free exact pass inside the same call. */
 FERN_API int fern_sim_topk(fern_ctx* ctx, const float* q /*[B,D]*/, const float* gallery /*[N,D]*/, int B,
                   int64_t N, int D, int K, float* out_scores /*[B,K]*/, int32_t* out_idx /*[B,K]*/,
                   int64_t idx_offset, const int32_t* exclude_idx, void* stream);

@@ -230,6 +230,26 @@ def test_every_gemm_tile_variant_passes_the_shape_suite(cfg):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("m,n,k", [(3000, 768, 768), (2500, 700, 256), (4100, 1536, 512)])
+def test_mixed_geometry_plans_are_bit_identical(engine, m, n, k):
+    """One launch, three bands of rows -- 8-wave macro-tiles (256x128 or 128x256), 128x128, 64x128 -- cut at arbitrary legal rows
+    (plans pinned through fern_tuner_import): every plan must give the bits of the plain 128x128 configuration, ragged last tiles,
+    empty bands and every row-independent epilogue included."""
+    a, w, b, r = _rand(m, k, seed=21), _rand(n, k, seed=22, scale=k ** -0.5), _rand(n, seed=23), _rand(m, n, seed=24)
+    hi = (m // 256) * 256
+    plans = [(20, hi, m), (20, hi, hi), (20, 1024, 1024 + ((m - 1024) // 128) * 128), (20, 256, 256), (20, 512, m),
+             (21, (m // 128) * 128, m), (21, 1152, 2048), (21, 128, 128), (21, 2048, 2048 + 256)]
+    for epi in (0, 1, 2, 3):
+        run = lambda: engine.gemm(a, w, b, residual=r if epi == 3 else None, epilogue=epi).cpu()  # noqa: E731
+        engine.tuner_import(f"f32 {m} {n} {k} {epi} 0 8 0 8\n")
+        base = run()
+        for cfg, ra, rb in plans:
+            engine.tuner_import(f"f32 {m} {n} {k} {epi} 0 {cfg} {ra} {rb}\n")
+            assert f"f32 {m} {n} {k} {epi} 0 {cfg} {ra} {rb}" in engine.tuner_export(), "the plan was refused"
+            assert torch.equal(run(), base), (epi, cfg, ra, rb)
+        engine.tuner_import(f"f32 {m} {n} {k} {epi} 0 8 0 8\n")
+
+
 def test_gemm_variants_are_bit_identical(engine):
     """Same k summation order in every tile shape: forcing nothing but changing M (which changes the tuned tile) must not
     change a row's bits."""

@@ -2,9 +2,9 @@
 
 Reference semantics: `distances = 1 - q @ g.T; argsort(distances)[:, :K]` (run/test/test_fiq.py:49-50); the oracle
 (oracle/rank.py) is pinned to the imported reference by tests/golden.  These cases aim at the parts the plain parity
-tests do not reach: a sample that misses the good rows (list overflow -> retry with a raised bound), floods of exact
-ties at the bound, the excluded row inside the sample, the bf16 sweep's 64-query blocks, and the loud failure of a
-second overflow."""
+tests do not reach: a sample that misses the good rows (list overflow -> the exact pass), floods of exact ties at the bound,
+the excluded row inside the sample, the bf16 sweep's 64-query blocks, galleries whose good rows are a multiple of 256 rows
+apart, and lists forced down to one entry: the stage has no capacity left anywhere, every case must equal the oracle."""
 import os
 import subprocess
 import sys
@@ -39,11 +39,11 @@ def plan(n):
     return s, (n // s if s else 1)
 
 
-def test_sample_misses_every_good_row_overflow_then_retry(engine):
+def test_sample_misses_every_good_row_overflow_then_exact_pass(engine):
     """Query 0 scores its lowest on exactly the sampled rows, so its bound is useless and ~N rows reach it: the candidate lists
-    overflow, the select kernel raises the bound to the K-th best of what was stored and the gated retry sweep
-    finishes the job.  The other queries take the normal path in the same launch.  (A query's candidates live in 256 lists of
-    64 entries, list = row % 256: ~96k survivors are ~375 per list.)"""
+    overflow, the select kernel hands the query to the exact pass (rank_exact_kernel: the gallery streamed through sorted wave
+    lists, scores from the sweep's own MFMA sequence).  The other queries take the normal path in the same launch.  (A query's
+    candidates live in 256 lists of 64 entries: ~96k survivors are ~375 per list.)"""
     n, d, k = 100_000, 64, 50
     q, g = _int_unit(4, d, 21), _int_unit(n, d, 22)
     q[0] = torch.where(q[0] == 0, torch.full_like(q[0], 0.125), q[0])
@@ -53,7 +53,6 @@ def test_sample_misses_every_good_row_overflow_then_retry(engine):
     g[rows] = -torch.sign(q[0]) / 8.0                     # the worst possible score for query 0
     rs, ri = orank.cosine_topk(q, g, k)
     sc, ix = engine.sim_topk(q, g, k)
-    engine.sync()                                         # would raise if a list overflowed twice
     assert torch.equal(ix.cpu(), ri) and torch.equal(sc.cpu(), rs)
     # the bf16 sweep shares the plan / select kernels (operands here are exact in bf16)
     sc, ix = engine.sim_topk_bf16(q, engine.gallery_to_bf16(g), k)
@@ -132,50 +131,61 @@ _SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, {root!r})
 from fashionern_aaai2024_amd.engine import FernEngine
-from fashionern_aaai2024_amd._lib import FernError
 from oracle import rank as orank
 eng = FernEngine("cuda:0")
 g = torch.Generator().manual_seed(1)
 unit = lambda n, d: torch.randint(-1, 2, (n, d), generator=g).float() / 8.0
 mode = {mode!r}
-if mode == "retry":
+if mode == "cluster":
     # lists of 4 entries; rows 4096.. are outside the sample (N = 5000 -> the sample is rows 0..4095) and all of them beat it for
-    # query 0: ~3.5 survivors per list -> overflow; the bound raised to the 10th best of what was stored lets ~11 rows through
+    # query 0: ~3.5 survivors per list -> overflow -> exact pass for query 0, the other queries stay on the list path
     q, gal = unit(16, 64), unit(5000, 64)
     q[0] = torch.where(q[0] == 0, torch.full_like(q[0], 0.125), q[0])
     gal[:4096] = torch.where(gal[:4096] * q[0] > 0, -gal[:4096], gal[:4096])       # sampled rows: never positive against query 0
     gal[4096:] = torch.sign(q[0]) / 8.0 * (torch.rand(904, 64, generator=g) < 0.9)  # the rest: strongly positive, all different
-    rs, ri = orank.cosine_topk(q, gal, 10)
-    s, i = eng.sim_topk(q, gal, 10)
-    eng.sync()
-    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs), "retry path"
-    print("OK")
+    k = 10
 else:
-    # lists of ONE entry, all scores equal, K = 64: the raised bound still lets ~3 rows per list through -> second overflow -> loud failure
+    # lists of ONE entry, all scores equal, K = 64: every list overflows for every query -- the case that used to end in NaN / -1
+    # and an error at the next sync.  The exact pass must return rows 0..63 (ties -> lower index) with the common score.
     q, gal = unit(2, 64), unit(1, 64).repeat(200000, 1)
-    s, i = eng.sim_topk(q, gal, 64)
-    try:
-        eng.sync()
-    except FernError as e:
-        assert "overflowed a candidate list twice" in str(e), str(e)
-        rs, ri = orank.cosine_topk(q, gal, 64)
-        failed = [b for b in range(2) if torch.isnan(s[b].cpu()).all() and (i[b].cpu() == -1).all()]
-        assert failed, "the reported query's row must hold NaN / -1"
-        for b in set(range(2)) - set(failed):       # a query whose retry happened to fit is still exact
-            assert torch.equal(i[b].cpu(), ri[b]) and torch.equal(s[b].cpu(), rs[b])
-        eng.sync()                      # the flag is reported once
-        print("OK")
-    else:
-        raise SystemExit("second overflow went unreported")
+    k = 64
+rs, ri = orank.cosine_topk(q, gal, k)
+for ex in (None, torch.tensor([3] + [-1] * (q.shape[0] - 1), dtype=torch.int32)):
+    if ex is not None:
+        rs, ri = orank.cosine_topk(q, gal, k, exclude_idx=ex)
+    s, i = eng.sim_topk(q, gal, k, exclude_idx=ex)
+    eng.sync()
+    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs), (mode, "fp32", ex is not None)
+    s, i = eng.sim_topk_bf16(q, eng.gallery_to_bf16(gal), k, exclude_idx=ex)      # operands are exact in bf16: same oracle
+    eng.sync()
+    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs), (mode, "bf16", ex is not None)
+s, i = eng.sim_topk(q, gal, k, idx_offset=1000)
+assert torch.equal(i.cpu(), orank.cosine_topk(q, gal, k, idx_offset=1000)[1])
+print("OK")
 """
 
 
-@pytest.mark.parametrize("cap,mode", [("4", "retry"), ("1", "error")])
-def test_forced_tiny_lists_retry_then_report(cap, mode):
-    """FERN_RANK_CAP (test hook, read once per process) shrinks the candidate lists."""
+@pytest.mark.parametrize("cap,mode", [("4", "cluster"), ("1", "all-equal")])
+def test_forced_tiny_lists_go_through_the_exact_pass(cap, mode):
+    """FERN_RANK_CAP (test hook, read once per process) shrinks the candidate lists so that they overflow; the result must
+    still be the oracle's, bit for bit (the stage is exact by construction, no NaN rows, no late error)."""
     env = dict(os.environ, FERN_RANK_CAP=cap)
     r = subprocess.run([sys.executable, "-c", _SCRIPT.format(root=ROOT, mode=mode)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_periodic_gallery_does_not_pile_into_one_list(engine):
+    """ADVICE r2: a base set tiled up to a large gallery (period a multiple of 256) puts every copy of a top item 256k rows apart;
+    with list = row % 256 they all shared one list and overflowed it twice.  Lists are now chosen by a hash of the row's 256-block,
+    and whatever still overflows is ranked by the exact pass: the top-50 are the 50 lowest-index copies of the best items."""
+    base = _int_unit(1024, 64, 31)
+    g = base.repeat(300, 1)                                # 307 200 rows, period 1024
+    q = _int_unit(5, 64, 32)
+    rs, ri = orank.cosine_topk(q, g, 50)
+    s, i = engine.sim_topk(q, g, 50)
+    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
+    s, i = engine.sim_topk_bf16(q, engine.gallery_to_bf16(g), 50)
+    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
 
 
 def test_stale_fork_bad_tokens_and_short_sequences_fail_loudly(engine):
