@@ -8,7 +8,7 @@ low-occupancy kernels with another lane's encoder tiles.  Results are bit-identi
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -67,12 +67,16 @@ class ComposedQueryPipeline:
         self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(lanes)]
         self._next = 0
 
-    def submit(self, images: torch.Tensor, tokens: torch.Tensor, local: torch.Tensor, gallery: torch.Tensor, k: int,
-               exclude_idx=None, members=None, idx_offset: int = 0) -> QueryResult:
+    def submit(self, images: Optional[torch.Tensor], tokens: torch.Tensor, local: torch.Tensor, gallery: torch.Tensor, k: int,
+               exclude_idx=None, members=None, idx_offset: int = 0, ref_feats: Optional[torch.Tensor] = None) -> QueryResult:
         """images [B,3,S,S], tokens [B,77] int64, local [B,13,D] (device tensors), fused gallery [N,D] fp32 -- or bf16, which
         selects the bf16 sweep -- -> QueryResult.  `exclude_idx` [B] drops one gallery index per query and `members` [B,m]
         (fp32 gallery) also returns the scores of those rows: CIRR's reference removal and subset ranking
-        (run/test/test_cirr.py:55-66)."""
+        (run/test/test_cirr.py:55-66).  `ref_feats` [B,D] (with `images=None`) is the reference harness's own query form: the
+        reference image's RAW feature is looked up in the gallery index instead of being encoded again (test_fiq.py:104-107), so
+        the step is text tower + fusion + rank."""
+        if (images is None) == (ref_feats is None):
+            raise ValueError("give either images (encoded per query) or ref_feats (looked up in the index), not both / neither")
         if members is not None and gallery.dtype != torch.float32:
             raise ValueError("members (subset scores) need an fp32 gallery: gather_scores has no bf16 form, and converting the "
                              "gallery per step would copy all of it")
@@ -80,7 +84,7 @@ class ComposedQueryPipeline:
         self._next = (self._next + 1) % len(self.engines)
         eng, stream = self.engines[lane], self.streams[lane]
         stream.wait_stream(torch.cuda.current_stream())          # inputs produced on the caller's stream
-        args = (images, tokens, local, exclude_idx, members)
+        args = (images, tokens, local, exclude_idx, members, ref_feats)
         with torch.cuda.stream(stream):
             if self.graphs:
                 outs = self._replay(lane, eng, stream, args, gallery, k, idx_offset)
@@ -93,8 +97,8 @@ class ComposedQueryPipeline:
 
     @staticmethod
     def _step(eng, args, gallery, k, idx_offset):
-        images, tokens, local, exclude_idx, members = args
-        ref = eng.encode_image(images)
+        images, tokens, local, exclude_idx, members, ref_feats = args
+        ref = eng.encode_image(images) if ref_feats is None else ref_feats
         tg, ts = eng.encode_text(tokens)
         fused = eng.dvr_fuse(ref, local, tg, ts)
         if gallery.dtype == torch.bfloat16:
