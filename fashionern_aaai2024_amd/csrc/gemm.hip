@@ -330,6 +330,12 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     FERN_TRACE_MARK();
+    // Waves inside the main loop outrank co-resident waves that are in their prologue or epilogue: the epilogue is a few thousand
+    // VALU issue slots (GELU: ~20 per element), and VALU and MFMA share the issue port -- at equal priority another workgroup's
+    // epilogue delays this wave's next MFMA.  One switch per tile (round 2 toggled the priority around every 16-MFMA cluster and lost
+    // 6 %: that disturbs the arbitration between waves that are all in their loops).  A/B on one box, 12608x3072x768 + GELU:
+    // 112.4 -> 115.7 TFLOP/s (128x128 tiles), 115.2 -> 117.8 (macro-tiles); shapes with a plain epilogue are unchanged.
+    __builtin_amdgcn_s_setprio(2);
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BKT);   // the other buffer is free: every wave passed the last barrier
         if (SYNC == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A/B variant: drain the copy before computing
@@ -346,6 +352,7 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
         __builtin_amdgcn_s_barrier();
         FERN_TRACE_MARK();
     }
+    __builtin_amdgcn_s_setprio(0);
     if (FILT) filter_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, bm, bn, wm, wn, l31, lh);
     else gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
 #ifdef FERN_GEMM_TRACE

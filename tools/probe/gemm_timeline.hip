@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
     GemmParams p{};
     p.A = A; p.W = W; p.C = C; p.bias = bias; p.R = C; p.lda = K; p.ldw = K; p.ldc = N; p.M = M; p.N = N; p.K = K; p.epi = epi; p.aload = ALOAD_PLAIN; p.packed = packed;
     const int bmv = kCfgs[cfg].bm, bnv = kCfgs[cfg].bn;
-    const long nwg = (long)((M + bmv - 1) / bmv) * ((N + bnv - 1) / bnv), waves = nwg * (cfg >= 12 ? 8 : 4);
+    const long nwg = (long)((M + bmv - 1) / bmv) * ((N + bnv - 1) / bnv), waves = nwg * ((cfg == 12 || cfg == 13) ? 8 : 4);
     long long* trace;
     hipMalloc(&trace, waves * FERN_GEMM_TRACE_SLOTS * 8);
     hipMemset(trace, 0, waves * FERN_GEMM_TRACE_SLOTS * 8);
@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
         const long long* r = &t[w * FERN_GEMM_TRACE_SLOTS];
         const unsigned hw = (unsigned)r[0];
         // gfx9 HW_ID: wave_id[3:0] simd_id[5:4] pipe_id[7:6] cu_id[11:8] sh_id[12] se_id[15:13]
-        const int wpw = cfg >= 12 ? 8 : 4;
+        const int wpw = (cfg == 12 || cfg == 13) ? 8 : 4;
         fprintf(f, "%ld,%ld,%u,%u,%u,%u,%lld,%lld", w / wpw, w % wpw, (unsigned)r[1] & 15, (hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3, r[2], r[3]);
         for (int i = 0; i < marks && 4 + i < FERN_GEMM_TRACE_SLOTS; ++i) fprintf(f, ",%lld", r[4 + i]);
         fprintf(f, "\n");
