@@ -17,6 +17,8 @@
 // K rows are padded to HDP+4 floats so the ds_read_b128 fragment reads are bank-conflict free.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace fern {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -154,6 +156,128 @@ __global__ __launch_bounds__(NW * 64) void attn_f32_kernel(AttnParams p) {
                 }
         }
     }
+}
+
+// ---- key-chunked form (197-token ViT heads) -----------------------------------------------------------------------------
+// The kernel above keeps ALL keys of a head in LDS: 224 padded rows x (68 + 64) floats = 118 KB, so one workgroup fills a CU
+// (160 KB) and its phases -- staging (memory), S^T and P V (MFMA), softmax (VALU) -- run back to back with nothing beside them:
+// the phases of the 197 x 197 x 64 shape add up (32 + 42 + 34 + 13 us measured with parts switched off), and while an attention
+// workgroup is resident only one 32 KB GEMM workgroup of another stream fits next to it.  Here the keys are staged in KH chunks of
+// CT 32-key tiles (4 + 3 tiles for 197 keys: 68 KB), the online softmax simply carries (m, sum, O) across the chunk boundary, and
+// TWO workgroups (or one and two GEMM workgroups) share a CU: one's staging overlaps the other's MFMAs, four waves per SIMD cover
+// each other's softmax.  Each wave owns at most one 32-query tile (launch condition: s_q <= 32 NW).  Arithmetic per (query, key)
+// is the kernel above's, in the same order: bit-identical results.
+template <int HDP, int NT, int NW, int KH>
+__global__ __launch_bounds__(NW * 64, 2) void attn_f32_chunked_kernel(AttnParams p) {
+    constexpr int KS = HDP + 4;
+    constexpr int CT = (NT + KH - 1) / KH;      // key tiles per chunk
+    constexpr int ROWS = CT * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                    // [ROWS][KS]
+    float* Vs = smem + ROWS * KS;        // [ROWS][HDP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+    const int hd = p.hd;
+    const bool active = wave * 32 < p.s_q;
+    const int qi = wave * 32 + l31;
+    const int qrow = qi < p.s_q ? qi : p.s_q - 1;
+    f32x4 qf[HDP / 8];
+    {
+        const float* qb = p.q + ((long)b * p.s_q + qrow) * p.ldq + (long)h * hd;
+#pragma unroll
+        for (int kk = 0; kk < HDP / 8; ++kk) {
+            const int d = kk * 8 + 4 * lh;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (active && d < hd) t = *reinterpret_cast<const f32x4*>(qb + d);
+            qf[kk] = t * p.scale;
+        }
+    }
+    f32x16 o[HDP / 32];
+#pragma unroll
+    for (int db = 0; db < HDP / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
+    float m = -INFINITY, sum = 0.0f;
+    const float* kb = p.k + (long)b * p.s_k * p.ldk + (long)h * hd;
+    const float* vb = p.v + (long)b * p.s_k * p.ldv + (long)h * hd;
+#pragma unroll 1
+    for (int c = 0; c < KH; ++c) {
+        if (c) __syncthreads();                                      // every wave is done with the previous chunk
+        {
+            constexpr int C4 = HDP / 4;
+            for (int i = tid; i < ROWS * C4; i += NW * 64) {
+                const int row = i / C4, cc = (i % C4) * 4, key = c * ROWS + row;
+                f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+                if (key < p.s_k && cc < hd) {
+                    kv = *reinterpret_cast<const f32x4*>(kb + (long)key * p.ldk + cc);
+                    vv = *reinterpret_cast<const f32x4*>(vb + (long)key * p.ldv + cc);
+                }
+                *reinterpret_cast<f32x4*>(&Ks[row * KS + cc]) = kv;
+                *reinterpret_cast<f32x4*>(&Vs[row * HDP + cc]) = vv;
+            }
+        }
+        __syncthreads();
+        if (!active) continue;
+        const int nt = (c + 1) * CT <= NT ? CT : NT - c * CT;
+#pragma unroll 1
+        for (int t = 0; t < nt; ++t) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < HDP / 8; ++kk) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[(t * 32 + l31) * KS + kk * 8 + 4 * lh]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[kk][e], st, 0, 0, 0);
+            }
+            float mt = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = (c * CT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                st[r] = key < p.s_k ? st[r] : -INFINITY;
+                mt = fmaxf(mt, st[r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m, mt);
+            const float alpha = __expf(m - m_new);
+            float ps = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(st[r] - m_new);
+                st[r] = e;
+                ps += e;
+            }
+            sum = sum * alpha + ps;
+            m = m_new;
+#pragma unroll
+            for (int db = 0; db < HDP / 32; ++db) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float vf = Vs[row * HDP + db * 32 + l31];
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, st[r], o[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active || qi >= p.s_q) return;
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    float* ob = p.out + ((long)b * p.s_q + qi) * p.ldo + (long)h * hd;
+#pragma unroll
+    for (int db = 0; db < HDP / 32; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = db * 32 + 8 * g + 4 * lh;
+            if (d < hd) {
+                f32x4 t = {o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(ob + d) = t;
+            }
+        }
 }
 
 // ---- bf16 operand form ---------------------------------------------------------------------------------------------
@@ -362,7 +486,22 @@ static hipError_t launch_hd(const AttnParams& p, hipStream_t s) {
     }
     if (nt <= 1) return launch_inst<HDP, 1, false>(p, s);
     if (nt <= 3) return launch_inst<HDP, 3, false>(p, s);
-    if (nt <= 7) return launch_inst<HDP, 7, false>(p, s);
+    if (nt <= 7) {
+        static const bool chunked = [] { const char* e = getenv("FERN_ATTN_CHUNKED"); return !(e && e[0] == '0'); }();      // A/B switch
+        if (chunked && nt > 4 && p.s_q <= 256 && !p.out_b) {      // the key-chunked form: every wave owns one query tile
+            constexpr size_t lds = (size_t)4 * 32 * (HDP + 4 + HDP) * sizeof(float);
+            static bool attr_set = false;
+            auto kern = attn_f32_chunked_kernel<HDP, 7, 8, 2>;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(p.batch * p.heads), dim3(8 * 64), lds, s, p);
+            return hipGetLastError();
+        }
+        return launch_inst<HDP, 7, false>(p, s);
+    }
     return hipErrorInvalidValue;
 }
 
