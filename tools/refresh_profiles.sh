@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerate the measurement artefacts under gpurun_out/refresh on the GPU box (copy the ones to keep into profiles/):
-#   bash tools/refresh_profiles.sh [round tag, default r02]          (run from the repo root, via gpurun)
+#   bash tools/refresh_profiles.sh [round tag, default r03]          (run from the repo root, via gpurun)
 # rocprofv3 needs the program itself after `--` (python3 ...), TMPDIR on /tmp, and --pmc in passes of its own; every profiled
 # command runs under `timeout` (a profiler hang must not eat the GPU budget).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh
 mkdir -p $O
@@ -35,11 +35,15 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sw
 python3 $R/tools/kstats.py /tmp/prof_sweep 16 $O/${TAG}_sweep_1M_kernel_stats.csv > $O/${TAG}_sweep_1M_kernel_stats_top.txt 2>&1
 timeout 200 python3 $R/tools/attn_bench.py > $O/${TAG}_attn_bench.txt 2>&1
 cd $R
-for c in c2 c3 c4 c5; do
+for c in c2 c3 c4 c5; do      # the c2 line is the driver's default command: it carries cpu_baseline and the c3 / c4 / c5 child runs (other_configs)
     timeout 900 python3 bench.py --config $c $( [ $c = c2 ] || echo --no-cpu-baseline ) > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err
 done
-FERN_DIST_BACKEND=gloo FERN_BENCH_SHARE_GPU=1 timeout 900 python3 bench.py --gpus 2 --headline-only > $O/${TAG}_bench_2ranks_one_gpu_gloo.json 2> $O/${TAG}_bench_2ranks_one_gpu_gloo.err
-FERN_DIST_BACKEND=gloo FERN_BENCH_SHARE_GPU=1 timeout 900 python3 bench.py --gpus 2 --config c5 --headline-only > $O/${TAG}_bench_c5_2ranks_one_gpu_gloo.json 2> $O/${TAG}_bench_c5_2ranks_one_gpu_gloo.err
-timeout 600 bash tools/mx_cfg_sweep.sh > $O/${TAG}_mx_cfg_sweep.txt 2>&1
+# world = 8 rehearsal: eight ranks share this box's one GPU over gloo (tools/r03_rehearsal.sh) -- every multi-rank path at its real shard sizes
+bash tools/r03_rehearsal.sh > $O/${TAG}_rehearsal.log 2>&1
+for c in c2 c3 c4 c5; do grep '^{' gpurun_out/r03_bench_${c}_8ranks_one_gpu_gloo.json | tail -1 > $O/${TAG}_bench_${c}_8ranks_one_gpu_gloo.json; done
+# fp32 GEMM: per-wave timeline of the two dominant shapes + PMC view, MFMA issue-rate probe
+for shp in "12608 2304 768 8 0" "12608 2304 768 12 0" "12608 768 3072 12 3"; do set -- $shp; timeout 120 tools/probe/gemm_timeline $1 $2 $3 $4 $5 /tmp/tl.csv; python3 tools/gemm_timeline.py /tmp/tl.csv; done > $O/${TAG}_gemm_timeline.txt 2>&1
+timeout 60 tools/probe/mfma_issue_probe > $O/${TAG}_mfma_issue_probe.txt 2>&1
+for c in 8 12; do echo "== cfg $c"; bash tools/pmc_probe.sh 12608 2304 768 $c 0; done > $O/${TAG}_pmc_gemm_probe.txt 2>&1
 tail -c 400 $O/${TAG}_bench_c2.json
 ls -la $O
