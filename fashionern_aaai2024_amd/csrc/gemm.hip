@@ -283,7 +283,60 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int sw = (l31 >> FSH) & FMASK;                        // read-side swizzle of this lane's rows
+#ifdef FERN_GEMM_SPLIT
+    // EXPERIMENT (tools/probe/gemm_timeline.hip -DFERN_GEMM_SPLIT=3|2, never in the library): fp32 operands split IN REGISTERS,
+    // after the LDS read, into FERN_GEMM_SPLIT bf16 planes by truncation (x1 = top 16 bits of x, r1 = x - x1 exactly, x2 = top 16
+    // bits of r1, ...: 8 + 8 + 8 mantissa bits), products of total order <= FERN_GEMM_SPLIT + 1 on v_mfma_f32_32x32x16_bf16 (6 MFMAs
+    // of 32 cycles per fp32 pair of 64-cycle MFMAs for 3 planes, 3 for 2 planes).  The two 8-groups of a 16-k tile supply the 8 k
+    // values a lane feeds to one bf16 MFMA (same k -> slot map for both operands).  NOT the fp32 fma chain: fp32-accurate, not
+    // bit-identical.  VERDICT r2 item 9.
+    typedef short bf16x8s __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    auto split = [&](const f32x4& g0, const f32x4& g1, bf16x8s (&pl)[FERN_GEMM_SPLIT]) {
+        float x[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+#pragma unroll
+        for (int lv = 0; lv < FERN_GEMM_SPLIT; ++lv) {
+            u32x4s packed;
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2)      // bytes 2-3 of two floats -> one dword of two bf16
+                packed[q2] = __builtin_amdgcn_perm(__float_as_uint(x[2 * q2 + 1]), __float_as_uint(x[2 * q2]), 0x07060302u);
+            pl[lv] = __builtin_bit_cast(bf16x8s, packed);
+            if (lv + 1 < FERN_GEMM_SPLIT) {
+#pragma unroll
+                for (int q2 = 0; q2 < 8; ++q2) x[q2] = x[q2] - __uint_as_float(__float_as_uint(x[q2]) & 0xFFFF0000u);
+            }
+        }
+    };
     auto compute = [&](int buf) {
+        static_assert(BKT == 16, "the split experiment pairs the two 8-groups of a 16-k tile");
+        const float* As = smem + buf * TILE;
+        const float* Ws = As + BM * BKT;
+        bf16x8s ap[TM][FERN_GEMM_SPLIT], bp[TN][FERN_GEMM_SPLIT];
+        const int pc0 = ((0 + lh) ^ sw) * 4, pc1 = ((2 + lh) ^ sw) * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float* r = &As[(wm * WM + i * 32 + l31) * BKT];
+            split(*reinterpret_cast<const f32x4*>(r + pc0), *reinterpret_cast<const f32x4*>(r + pc1), ap[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float* r = &Ws[(wn * WN + j * 32 + l31) * BKT];
+            split(*reinterpret_cast<const f32x4*>(r + pc0), *reinterpret_cast<const f32x4*>(r + pc1), bp[j]);
+        }
+#pragma unroll
+        for (int la = 0; la < FERN_GEMM_SPLIT; ++la)
+#pragma unroll
+            for (int lb = 0; lb + la < FERN_GEMM_SPLIT; ++lb)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][la], bp[j][lb], acc[i][j], 0, 0, 0);
+    };
+    auto compute_fp32_unused = [&](int buf) {
+#else
+    auto compute = [&](int buf) {
+#endif
         const float* As = smem + buf * TILE;
         const float* Ws = As + BM * BKT;
 #pragma unroll
@@ -578,9 +631,17 @@ static const TileCfg kCfgs[] = {
     {64, 64, 16, 0.86f},     // 11
     {256, 128, 16, 1.00f},   // 12: 8 waves, 256x128 macro-tile (0.75x the L2->LDS bytes per flop of 128x128), 2 workgroups per CU
     {128, 256, 16, 1.00f},   // 13
+#ifdef FERN_GEMM_SPLIT
+    {128, 128, 16, 1.00f},   // 14, 15: probe builds of the bf16-split experiment only (looser register bound: the planes need room)
+    {256, 128, 16, 1.00f},
+#endif
 };
 constexpr int kNumAuto = 4;      // configs the heuristic may pick
+#ifdef FERN_GEMM_SPLIT
+constexpr int kNumCfgs = 16;
+#else
 constexpr int kNumCfgs = 14;
+#endif
 
 static int forced_cfg() {
     static int v = [] {
@@ -653,6 +714,10 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
         case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
         case 12: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
         case 13: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 256, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
+#ifdef FERN_GEMM_SPLIT
+        case 14: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 2>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 15: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 128, 64, 16, 2>), dim3(nb, ks), dim3(256), 0, s, p); break;
+#endif
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

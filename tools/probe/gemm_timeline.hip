@@ -8,6 +8,7 @@
 #define FERN_GEMM_TRACE 1
 #include "../../fashionern_aaai2024_amd/csrc/gemm.hip"
 
+#include <cmath>
 #include <vector>
 
 int main(int argc, char** argv) {
@@ -48,6 +49,24 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ms, e0, e1);
     printf("untraced: %.2f us per launch = %.1f TFLOP/s (%d x %d x %d, cfg %d, epi %d, %ld workgroups)\n", ms * 100, 2.0 * M * N * K / (ms * 1e-4) / 1e12,
            M, N, K, cfg, epi, nwg);
+    {   // accuracy of whatever arithmetic this build runs: 512 sampled outputs against double precision (epilogue 0 only)
+        std::vector<float> hc((size_t)M * N);
+        hipMemset(C, 0, (size_t)M * N * 4);
+        launch_cfg(cfg, p, s);
+        hipStreamSynchronize(s);
+        hipMemcpy(hc.data(), C, hc.size() * 4, hipMemcpyDeviceToHost);
+        double max_err = 0, sum2 = 0;
+        if (epi == EPI_BIAS && !packed) {
+            for (int t = 0; t < 512; ++t) {
+                const long r = (long)(rand() % M), c = (long)(rand() % N);
+                double ref = 0;
+                for (int k = 0; k < K; ++k) ref += (double)h[(size_t)r * K + k] * (double)h[(size_t)c * K + k];
+                max_err = std::max(max_err, std::fabs(ref - (double)hc[(size_t)r * N + c]));
+                sum2 += ref * ref;
+            }
+            printf("accuracy: max |error| %.3e over 512 sampled outputs, output rms %.3f -> %.2e relative\n", max_err, std::sqrt(sum2 / 512), max_err / std::sqrt(sum2 / 512));
+        }
+    }
     p.trace = trace;
     hipEventRecord(e0, s);
     launch_cfg(cfg, p, s);
