@@ -43,8 +43,9 @@ class FernCLIP:
         """"fp32": parity mode (default, the reference's arithmetic).  "bf16": perf mode of the transformer towers --
         bf16 operands / fp32 accumulation on the block GEMMs and attention; "fp8": e4m3fn operands on those GEMMs
         with per-token / per-channel scales; "mx8": e4m3fn operands with one power-of-two scale per 32-element block on the
-        block-scaled MFMA (BASELINE config 5) -- include/fern.h:fern_precision; no reference counterpart (the reference evaluates in fp32, test_fiq.py:141-149)."""
-        if precision != "fp32" and self.cfg.v_arch == "resnet":
+        block-scaled MFMA (BASELINE config 5); "f32x3": fp32 data, the large plain GEMMs computed from three bf16 planes per operand
+        (fp32-accurate, not the bit-exact chain; every tower incl. RN50x4's 1x1 convolutions) -- include/fern.h:fern_precision; no reference counterpart (the reference evaluates in fp32, test_fiq.py:141-149)."""
+        if precision not in ("fp32", "f32x3") and self.cfg.v_arch == "resnet":
             raise ValueError("reduced precisions cover the transformer towers; RN50x4's image tower has no bf16 / fp8 path")
         self.engine.set_precision(precision)
         self._text_cache = None

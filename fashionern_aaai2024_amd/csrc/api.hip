@@ -121,6 +121,7 @@ struct fern_ctx {
     ClipW clip;
     Clip4CirW c4c;
     int precision = FERN_PREC_FP32;  // operand precision of the CLIP towers' token-level GEMMs (fern_set_precision)
+    bool f32x3 = false;              // FERN_PREC_F32X3: `precision` stays FP32 (same buffers, same code paths), GEMMs run split (run_gemm)
     // workspace arena (bump allocator; blocks are consolidated at the start of the next op)
     struct Block { char* p; size_t cap; };
     std::vector<Block> blocks;
@@ -196,6 +197,11 @@ static int prof_close(fern_ctx* c, int slot, hipStream_t s) {
 static int run_gemm(fern_ctx* c, const GemmParams& p, hipStream_t s, int kind = PROF_GEMM, double work = -1.0) {
     int slot;
     FERN_TRY(prof_open(c, kind, work >= 0 ? work : 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, p.epi));
+    if (c->f32x3 && kind == PROF_GEMM && p.w_sample <= 1) {      // FERN_PREC_F32X3: never the ranking stage (PROF_SWEEP / sample pass)
+        GemmParams q = p;
+        q.split = 3;                                             // launch_gemm falls back to the fp32 kernels where the split family does not apply
+        HIP_TRY(launch_gemm(q, s));
+    } else
     HIP_TRY(launch_gemm(p, s));
     if (slot >= 0) c->recs[slot].dispatches = gemm_last_dispatches();
     return prof_close(c, slot, s);
@@ -404,6 +410,7 @@ extern "C" int fern_ctx_fork(fern_ctx* parent, fern_ctx** out) {
     c->clip = parent->clip;
     c->c4c = parent->c4c;
     c->precision = parent->precision;
+    c->f32x3 = parent->f32x3;
     *out = c;
     return FERN_OK;
 }
@@ -705,8 +712,11 @@ extern "C" int fern_finalize_clip(fern_ctx* c, const fern_clip_config* cfg) {
 
 extern "C" int fern_set_precision(fern_ctx* c, int precision) {
     if (!c) return fail(FERN_ERR_ARG, "fern_set_precision: ctx is NULL");
-    if (precision != FERN_PREC_FP32 && precision != FERN_PREC_BF16 && precision != FERN_PREC_FP8 && precision != FERN_PREC_MX8)
+    if (precision != FERN_PREC_FP32 && precision != FERN_PREC_BF16 && precision != FERN_PREC_FP8 && precision != FERN_PREC_MX8 &&
+        precision != FERN_PREC_F32X3)
         return fail(FERN_ERR_ARG, "fern_set_precision: unknown precision");
+    c->f32x3 = precision == FERN_PREC_F32X3;
+    if (c->f32x3) precision = FERN_PREC_FP32;      // fp32 data flow; only the GEMM arithmetic changes
     if (precision == FERN_PREC_MX8 && c->clip.ready) {
         for (const auto* blocks : {&c->clip.vblocks, &c->clip.tblocks})
             for (const auto& b : *blocks)
@@ -722,7 +732,7 @@ extern "C" int fern_set_precision(fern_ctx* c, int precision) {
     c->precision = precision;
     return FERN_OK;
 }
-extern "C" int fern_get_precision(fern_ctx* c) { return c ? c->precision : FERN_ERR_ARG; }
+extern "C" int fern_get_precision(fern_ctx* c) { return !c ? FERN_ERR_ARG : c->f32x3 ? FERN_PREC_F32X3 : c->precision; }
 
 // ------------------------------------------------------------------------------------------------
 // fusion building blocks (internal; workspace comes from the caller's arena)

@@ -178,8 +178,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
 // bound (MINW = 2): compiled into the general kernel, the filter epilogue made the 128-VGPR builds spill.
 // The tile body is a device function of (parameters, linear tile id, LDS) so that one kernel can run tiles of several geometries
 // (gemm_f32_mixed_kernel below); gemm_f32_glds_kernel is the one-geometry wrapper.
+// SPLIT = 3: the "f32x3" arithmetic (FERN_PREC_F32X3) -- fp32 operands split into three bf16 planes in registers, six
+// v_mfma_f32_32x32x16_bf16 per k pair of fp32 MFMAs (see the compute step below).
 template <int BM, int BN, int WM, int WN, int BKT, bool CONV = false, int SYNC = 0 /* 0: wait+barrier free to sink below the tail MFMAs (fastest), 1: drain copy first, 2: pinned after all MFMAs */,
-          bool FILT = false>
+          bool FILT = false, int SPLIT = 0>
 __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* smem) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
@@ -283,35 +285,36 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int sw = (l31 >> FSH) & FMASK;                        // read-side swizzle of this lane's rows
-#ifdef FERN_GEMM_SPLIT
-    // EXPERIMENT (tools/probe/gemm_timeline.hip -DFERN_GEMM_SPLIT=3|2, never in the library): fp32 operands split IN REGISTERS,
-    // after the LDS read, into FERN_GEMM_SPLIT bf16 planes by truncation (x1 = top 16 bits of x, r1 = x - x1 exactly, x2 = top 16
-    // bits of r1, ...: 8 + 8 + 8 mantissa bits), products of total order <= FERN_GEMM_SPLIT + 1 on v_mfma_f32_32x32x16_bf16 (6 MFMAs
-    // of 32 cycles per fp32 pair of 64-cycle MFMAs for 3 planes, 3 for 2 planes).  The two 8-groups of a 16-k tile supply the 8 k
-    // values a lane feeds to one bf16 MFMA (same k -> slot map for both operands).  NOT the fp32 fma chain: fp32-accurate, not
-    // bit-identical.  VERDICT r2 item 9.
+    // f32x3 (SPLIT = 3): fp32 operands split IN REGISTERS, after the LDS read, into three bf16 planes by truncation (x1 = top 16
+    // bits of x -- one v_perm_b32 packs two --, r1 = x - x1 exactly, x2 = top 16 bits of r1, ...: 8 + 8 + 8 mantissa bits), the six
+    // products of total order <= 4 on v_mfma_f32_32x32x16_bf16 (32 cycles each against two 64-cycle fp32 MFMAs).  The two 8-groups
+    // of a 16-k tile supply the 8 k values a lane feeds to one bf16 MFMA (same k -> slot map for both operands).  The error against
+    // exact arithmetic is the fp32 kernel's own (measured 1.7-2.3e-6 of the output rms against 2.0e-6), at 1.4-1.5x its speed; it
+    // is NOT the fp32 fma chain, so nothing that must be bit-identical to the sweep's scores may use it.  Every configuration walks
+    // k in the same order with the same six products: results are bit-identical across tile shapes and batch-invariant.
     typedef short bf16x8s __attribute__((ext_vector_type(8)));
     typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-    auto split = [&](const f32x4& g0, const f32x4& g1, bf16x8s (&pl)[FERN_GEMM_SPLIT]) {
+    constexpr int NPL = SPLIT > 0 ? SPLIT : 1;
+    auto split = [&](const f32x4& g0, const f32x4& g1, bf16x8s (&pl)[NPL]) {
         float x[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
 #pragma unroll
-        for (int lv = 0; lv < FERN_GEMM_SPLIT; ++lv) {
+        for (int lv = 0; lv < NPL; ++lv) {
             u32x4s packed;
 #pragma unroll
             for (int q2 = 0; q2 < 4; ++q2)      // bytes 2-3 of two floats -> one dword of two bf16
                 packed[q2] = __builtin_amdgcn_perm(__float_as_uint(x[2 * q2 + 1]), __float_as_uint(x[2 * q2]), 0x07060302u);
             pl[lv] = __builtin_bit_cast(bf16x8s, packed);
-            if (lv + 1 < FERN_GEMM_SPLIT) {
+            if (lv + 1 < NPL) {
 #pragma unroll
                 for (int q2 = 0; q2 < 8; ++q2) x[q2] = x[q2] - __uint_as_float(__float_as_uint(x[q2]) & 0xFFFF0000u);
             }
         }
     };
-    auto compute = [&](int buf) {
-        static_assert(BKT == 16, "the split experiment pairs the two 8-groups of a 16-k tile");
+    auto compute_split = [&](int buf) {
+        static_assert(SPLIT == 0 || BKT == 16, "the split form pairs the two 8-groups of a 16-k tile");
         const float* As = smem + buf * TILE;
         const float* Ws = As + BM * BKT;
-        bf16x8s ap[TM][FERN_GEMM_SPLIT], bp[TN][FERN_GEMM_SPLIT];
+        bf16x8s ap[TM][NPL], bp[TN][NPL];
         const int pc0 = ((0 + lh) ^ sw) * 4, pc1 = ((2 + lh) ^ sw) * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -324,19 +327,16 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
             split(*reinterpret_cast<const f32x4*>(r + pc0), *reinterpret_cast<const f32x4*>(r + pc1), bp[j]);
         }
 #pragma unroll
-        for (int la = 0; la < FERN_GEMM_SPLIT; ++la)
+        for (int la = 0; la < NPL; ++la)
 #pragma unroll
-            for (int lb = 0; lb + la < FERN_GEMM_SPLIT; ++lb)
+            for (int lb = 0; lb + la < NPL; ++lb)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][la], bp[j][lb], acc[i][j], 0, 0, 0);
     };
-    auto compute_fp32_unused = [&](int buf) {
-#else
-    auto compute = [&](int buf) {
-#endif
+    auto compute_fp32 = [&](int buf) {
         const float* As = smem + buf * TILE;
         const float* Ws = As + BM * BKT;
 #pragma unroll
@@ -355,6 +355,10 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
+    };
+    auto compute = [&](int buf) {
+        if constexpr (SPLIT > 0) compute_split(buf);
+        else compute_fp32(buf);
     };
 
     // LDS-DMA data is published by the issuing wave's vmcnt wait followed by a barrier.  The copy of tile kt+1 overlaps the
@@ -417,11 +421,11 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
 
 // ONE __shared__ object per kernel: with a second LDS object next to the DMA destination hipcc drains the DMA (s_waitcnt vmcnt(0))
 // before the first ds_read of every k step, which serialises the copy and the MFMAs of a wave.
-template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool CONV = false, int SYNC = 0, bool FILT = false>
+template <int BM, int BN, int WM, int WN, int BKT, int MINW, bool CONV = false, int SYNC = 0, bool FILT = false, int SPLIT = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_glds_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * BKT];
     if (p.gate && *p.gate == 0) return;
-    glds_tile<BM, BN, WM, WN, BKT, CONV, SYNC, FILT>(p, blockIdx.x, smem);
+    glds_tile<BM, BN, WM, WN, BKT, CONV, SYNC, FILT, SPLIT>(p, blockIdx.x, smem);
 }
 
 // ---- mixed-geometry launch ------------------------------------------------------------------------------------------------
@@ -631,17 +635,9 @@ static const TileCfg kCfgs[] = {
     {64, 64, 16, 0.86f},     // 11
     {256, 128, 16, 1.00f},   // 12: 8 waves, 256x128 macro-tile (0.75x the L2->LDS bytes per flop of 128x128), 2 workgroups per CU
     {128, 256, 16, 1.00f},   // 13
-#ifdef FERN_GEMM_SPLIT
-    {128, 128, 16, 1.00f},   // 14, 15: probe builds of the bf16-split experiment only (looser register bound: the planes need room)
-    {256, 128, 16, 1.00f},
-#endif
 };
 constexpr int kNumAuto = 4;      // configs the heuristic may pick
-#ifdef FERN_GEMM_SPLIT
-constexpr int kNumCfgs = 16;
-#else
 constexpr int kNumCfgs = 14;
-#endif
 
 static int forced_cfg() {
     static int v = [] {
@@ -714,10 +710,6 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
         case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
         case 12: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
         case 13: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 256, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
-#ifdef FERN_GEMM_SPLIT
-        case 14: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 2>), dim3(nb, ks), dim3(256), 0, s, p); break;
-        case 15: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 128, 64, 16, 2>), dim3(nb, ks), dim3(256), 0, s, p); break;
-#endif
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -758,11 +750,19 @@ static bool mixed_plan_ok(const Plan& pl, int M) {
 }
 static std::map<ShapeKey, Plan> g_tuned;
 static std::mutex g_tuned_mu;
+static std::map<ShapeKey, int>& tuned_split_map();      // the f32x3 family's choices (defined with that family below)
 
 // FERN_GEMM_TILES=<file>: pin the per-shape choices (lines "f32 M N K epi aload cfg [rows_a cfg_b]", as written by gemm_tuner_export /
 // fern_tuner_export): listed shapes are never timed again, so a run's kernels -- and its HBM / L2 traffic -- are reproducible
 // from box to box.  Loaded once, before the first tuned launch.
 static void pin_tile_line(const char* line) {      // caller holds g_tuned_mu
+    {
+        int M, N, K, epi, cfg;
+        if (sscanf(line, "f32x3 %d %d %d %d %d", &M, &N, &K, &epi, &cfg) == 5) {
+            if (cfg >= 0 && cfg < 6) tuned_split_map()[ShapeKey{M, N, K, epi, 0}] = cfg;
+            return;
+        }
+    }
     char kind[16];
     auto ok = [](int cfg, int K) { return cfg >= 0 && cfg < kNumCfgs && kCfgs[cfg].bk && K % kCfgs[cfg].bk == 0; };
     int M, N, K, epi, aload, cfg, rows_a = 0, cfg_b = 0;
@@ -802,6 +802,11 @@ void gemm_tuner_import(const std::string& text) {
 }
 void gemm_tuner_export(std::string& out) {
     std::lock_guard<std::mutex> lock(g_tuned_mu);
+    for (const auto& kv : tuned_split_map()) {
+        char line[128];
+        snprintf(line, sizeof line, "f32x3 %d %d %d %d %d\n", kv.first.M, kv.first.N, kv.first.K, kv.first.epi, kv.second);
+        out += line;
+    }
     for (const auto& kv : g_tuned) {
         char line[128];
         snprintf(line, sizeof line, "f32 %d %d %d %d %d %d %d %d\n", kv.first.M, kv.first.N, kv.first.K, kv.first.epi, kv.first.aload, kv.second.cfg,
@@ -972,6 +977,94 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
     return best;
 }
 
+// ---- f32x3 family (GemmParams.split == 3) --------------------------------------------------------------------------------
+// The planes of a wave tile are 12 VGPRs per 32-row fragment, so the configurations trade occupancy for room: the 128x128 tile at
+// <= 170 VGPRs (three workgroups per CU), the macro-tiles on four fat waves (wave tile 128x64 / 64x128, two workgroups per CU),
+// and the small tiles at the usual 128.  All bit-identical to each other; tuned per shape like the fp32 family.
+constexpr int kNumCfgsS = 6;
+static const TileCfg kCfgsS[kNumCfgsS] = {{128, 128, 16, 1.f}, {256, 128, 16, 1.f}, {128, 256, 16, 1.f}, {64, 128, 16, 1.f}, {128, 64, 16, 1.f}, {64, 64, 16, 1.f}};
+static bool split_family_ok(const GemmParams& p) {
+    return p.split == 3 && split_ok(p) && p.M >= 256 && p.K % 16 == 0;
+}
+static hipError_t launch_cfg_split(int c, const GemmParams& p, hipStream_t s) {
+    const int nb = ((p.M + kCfgsS[c].bm - 1) / kCfgsS[c].bm) * ((p.N + kCfgsS[c].bn - 1) / kCfgsS[c].bn);
+    switch (c) {
+        case 0: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 3, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 128, 64, 16, 2, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 256, 64, 128, 16, 2, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 5: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+static std::map<ShapeKey, int> g_tuned_s;      // guarded by g_tuned_mu
+static std::map<ShapeKey, int>& tuned_split_map() { return g_tuned_s; }
+static int forced_cfg_split() {
+    static int v = [] { const char* e = getenv("FERN_GEMM_SPLIT_CFG"); return e ? atoi(e) : -1; }();
+    return v;
+}
+static int heuristic_split(const GemmParams& p) {
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    return t128 >= 1024 ? 1 : t128 >= 384 ? 0 : 5;
+}
+static int tune_shape_split(const GemmParams& p, hipStream_t s, bool& tuned) {
+    tuned = false;
+    const int fallback = heuristic_split(p);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (!tuning_enabled() || hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return fallback;
+    float* scratch = nullptr;
+    if (hipMalloc(&scratch, (size_t)p.M * p.ldc * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fallback; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    GemmParams q = p;
+    q.C = scratch;      // the residual input is only read
+    float t[kNumCfgsS];
+    for (float& v : t) v = 1e30f;
+    for (int round = 0; round < 2; ++round)
+        for (int c = 0; c < kNumCfgsS; ++c) {
+            if (launch_cfg_split(c, q, s) != hipSuccess) continue;
+            (void)hipEventRecord(e0, s);
+            (void)launch_cfg_split(c, q, s);
+            (void)launch_cfg_split(c, q, s);
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) continue;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            t[c] = std::min(t[c], ms);
+        }
+    int best = fallback;
+    float best_ms = 1e30f;
+    for (int c = 0; c < kNumCfgsS; ++c)
+        if (t[c] < best_ms) { best_ms = t[c]; best = c; }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(scratch);
+    tuned = best_ms < 1e29f;
+    return best;
+}
+static hipError_t launch_gemm_split(const GemmParams& p, hipStream_t s) {
+    int c = forced_cfg_split();
+    if (c < 0 || c >= kNumCfgsS) {
+        const double flops = 2.0 * p.M * (double)p.N * p.K;
+        c = heuristic_split(p);
+        if (tuning_enabled() && flops >= 2.5e8 && flops <= 2e11) {
+            const ShapeKey key{p.M, p.N, p.K, p.epi, 0};
+            std::lock_guard<std::mutex> lock(g_tuned_mu);
+            auto it = g_tuned_s.find(key);
+            if (it != g_tuned_s.end()) c = it->second;
+            else {
+                bool tuned = false;
+                c = tune_shape_split(p, s, tuned);
+                if (tuned) g_tuned_s.emplace(key, c);
+            }
+        }
+    }
+    return launch_cfg_split(c, p, s);
+}
+
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     g_last_dispatches = 1;
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
@@ -980,6 +1073,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return hipErrorInvalidValue;
     if (p.aload == ALOAD_IM2COL && ((p.patch & 3) || (p.img & 3))) return hipErrorInvalidValue;
     if (p.ksplit > 1 && (p.aload != ALOAD_PLAIN || !p.kpart || p.K % (p.ksplit * 64) || (p.N & 3))) return hipErrorInvalidValue;
+    if (split_family_ok(p)) return launch_gemm_split(p, s);
     int c = choose_cfg(p.M, p.N, p.K);
     // tuned: problems big enough to matter and small enough that ~30 trial launches are cheap (beyond ~0.2 TFLOP per launch
     // -- the gallery-side GEMMs over tens of thousands of rows -- every candidate fills the chip and the heuristic is used)

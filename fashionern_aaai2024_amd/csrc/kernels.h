@@ -93,6 +93,10 @@ struct GemmParams {
     int w_sample;                 // > 1: W row r is gallery row sample_row(r, w_sample) (the sample pass of the fused top-K sweep)
     TopkFilter filt;              // EPI_TOPK_FILTER
     const int* gate;              // when set: the launch does nothing unless *gate != 0 (retry pass of the fused top-K sweep)
+    // split == 3: "f32x3" arithmetic (FERN_PREC_F32X3): fp32 operands split into three bf16 planes in registers, six bf16 MFMAs per
+    // pair of fp32 ones -- fp32-accurate (error vs exact arithmetic = the fp32 kernel's), not the fp32 fma chain.  Plain loader,
+    // stored (non-reduce) epilogues, no split-K, M >= 256; anything else runs the fp32 kernels.
+    int split;
     // bf16 operand form (launch_gemm_bf16): A [M, lda] and W [N, ldw] hold bf16 bit patterns, strides in elements
     const unsigned short* Ab;
     const unsigned short* Wb;

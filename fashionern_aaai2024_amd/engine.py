@@ -21,8 +21,8 @@ COMBINER_TARGET, COMBINER_DVR_GLOBAL, COMBINER_DVR_LOCAL, COMBINER_DVR_FINAL = 0
 SR_TARGET, SR_DVR = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
 PART_DVR, PART_TARGET_SR, PART_TARGET_COMBINER, PART_ALL = 1, 2, 4, 7
-PREC_FP32, PREC_BF16, PREC_FP8, PREC_MX8 = 0, 1, 2, 3
-_PREC_NAMES = {"fp32": PREC_FP32, "bf16": PREC_BF16, "fp8": PREC_FP8, "mx8": PREC_MX8}
+PREC_FP32, PREC_BF16, PREC_FP8, PREC_MX8, PREC_F32X3 = 0, 1, 2, 3, 4
+_PREC_NAMES = {"fp32": PREC_FP32, "bf16": PREC_BF16, "fp8": PREC_FP8, "mx8": PREC_MX8, "f32x3": PREC_F32X3}
 PATCH_NUM = 13
 
 
@@ -66,7 +66,8 @@ class FernEngine:
 
     def set_precision(self, precision) -> None:
         """Operand precision of the CLIP towers' token-level GEMMs: "fp32" (parity mode, default), "bf16", "fp8" (per-row
-        scales) or "mx8" (block-scaled fp8 on the scaled MFMA) -- include/fern.h:fern_precision."""
+        scales), "mx8" (block-scaled fp8 on the scaled MFMA) -- or "f32x3": fp32 data, every large plain GEMM computed from three
+        bf16 planes per operand (fp32-accurate, ~1.4x faster, not the bit-exact fma chain) -- include/fern.h:fern_precision."""
         prec = _PREC_NAMES[precision] if isinstance(precision, str) else int(precision)
         _lib.check(self.lib.fern_set_precision(self._h, prec), "fern_set_precision")
 

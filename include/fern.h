@@ -92,7 +92,15 @@ typedef enum {
      * activations and per (output channel, 32 consecutive inputs) of the weights (fern_quantize_mx8), applied inside the MFMA --
      * an outlier channel costs the precision of its own 32-block, not of the whole token row.  The ViT patch embedding runs the same way
      * (patch rows quantised once, conv1 as a block-scaled GEMM) when 3 * patch^2 is a multiple of 128.  Needs tower / MLP widths % 128 == 0. */
-    FERN_PREC_MX8 = 3
+    FERN_PREC_MX8 = 3,
+    /* fp32 data everywhere (the FP32 mode's buffers, statistics, attention, epilogues), but every plain-epilogue GEMM of 256 rows or
+     * more computes its fp32 dot products as "f32x3": both operands split in registers into three bf16 planes (8 + 8 + 8 mantissa bits,
+     * by truncation) and the six partial products of total order <= 4 run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The
+     * error against exact arithmetic is the fp32 MFMA kernel's own (~2e-6 of the output rms), at ~1.4-1.5x its speed; it is not the
+     * sequential fp32 fma chain, so results are fp32-accurate but not bit-identical to FERN_PREC_FP32 (they are bit-identical across
+     * tile shapes and batch sizes).  The ranking stage never uses it: fern_sim_topk* scores stay the exact chain.  No reference
+     * counterpart (cuBLAS's own TF32x3-style modes are the closest relative). */
+    FERN_PREC_F32X3 = 4
 } fern_precision;
 
 typedef enum {

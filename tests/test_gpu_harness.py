@@ -229,6 +229,39 @@ def test_cli_driver_under_torchrun_prints_the_single_process_recalls():
         assert keep(one.stdout) and keep(two.stdout) == keep(one.stdout), (keep(one.stdout), keep(two.stdout))
 
 
+def test_full_pipeline_in_f32x3_mode_is_fp32_accurate():
+    """FERN_PREC_F32X3 end to end (encode image + text, fusion, ranking): query / gallery features within 2e-5 of the fp32 mode's
+    (unit-norm features; measured ~1e-6), cosine scores within 1e-5, and the ranking identical except between rows the fp32 mode itself
+    separates by < 2e-6 -- the same near-tie allowance the fp32 mode gets against the BLAS-ordered oracle."""
+    cfg = synth.CLIP_CONFIGS["tiny-w256"]
+    d = cfg.embed_dim
+    im, tk = torch.from_numpy(synth.images(40, cfg, 7)), torch.from_numpy(synth.captions(40, cfg, 7))
+    lc = torch.from_numpy(synth.local_feats(40, d, 7))
+    graw, gloc = torch.from_numpy(synth.global_feats(3000, d, tag="xg")), torch.from_numpy(synth.local_feats(3000, d, tag="xgl"))
+    out = {}
+    for prec in ("fp32", "f32x3"):
+        clip = create_model(cfg, device=DEV, seed=9, precision=prec)
+        model = ERN(clip, d, DEV, engine=clip.engine).init_random(4)
+        eng = model.engine
+        assert eng.precision == prec
+        rf = eng.encode_image(im.to(DEV))
+        tg, ts = eng.encode_text(tk.to(DEV))
+        q = eng.dvr_fuse(rf, lc.to(DEV), tg, ts)
+        gal = eng.index_fuse(graw, gloc, normalize_input=True)
+        s, i = eng.sim_topk(q, gal, 50)
+        out[prec] = tuple(t.cpu() for t in (rf, q, gal, s, i))
+        eng.close()
+    rf0, q0, g0, s0, i0 = out["fp32"]
+    rf1, q1, g1, s1, i1 = out["f32x3"]
+    assert not torch.equal(rf0, rf1), "the mode was expected to change the arithmetic of the tower GEMMs"
+    assert (rf0 - rf1).abs().max().item() <= 2e-5 * rf0.abs().max().item()
+    assert (q0 - q1).abs().max().item() < 2e-5 and (g0 - g1).abs().max().item() < 2e-5
+    assert (s0 - s1).abs().max().item() < 1e-5
+    full = q0.double() @ g0.double().T
+    for r, c in (i0 != i1).nonzero().tolist():
+        assert abs(full[r, i0[r, c]].item() - full[r, i1[r, c]].item()) < 2e-6, (r, c)
+
+
 def test_full_pipeline_in_bf16_perf_mode_stays_within_the_score_budget():
     """The whole FIQ harness with the encoders in bf16 perf mode vs the same run in fp32 parity mode.
 

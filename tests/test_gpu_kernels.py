@@ -250,6 +250,41 @@ def test_mixed_geometry_plans_are_bit_identical(engine, m, n, k):
         engine.tuner_import(f"f32 {m} {n} {k} {epi} 0 8 0 8\n")
 
 
+@pytest.mark.parametrize("m,n,k", [(1000, 520, 256), (4096, 768, 768), (300, 96, 64)])
+def test_gemm_f32x3_is_fp32_accurate_and_configuration_independent(m, n, k):
+    """FERN_PREC_F32X3: fp32 operands as three bf16 planes (truncation split in registers), six bf16 MFMAs per pair of fp32 ones.
+    Tolerance: the error against double-precision arithmetic must stay within 2x the fp32 MFMA kernel's own and below 1e-5 of the output
+    rms.  All six tile configurations of the family are bit-identical (pinned through fern_tuner_import), a row's bits do not depend on
+    the batch it travels in, and shapes below 256 rows run the exact fp32 kernels."""
+    from fashionern_aaai2024_amd.engine import FernEngine
+    eng = FernEngine("cuda:0")
+    a, w, b, r = _rand(m, k, seed=31), _rand(n, k, seed=32, scale=k ** -0.5), _rand(n, seed=33), _rand(m, n, seed=34)
+    for epi in (0, 1, 2, 3):
+        ref = a.double() @ w.double().T + b.double()
+        ref = F.gelu(ref) if epi == 1 else F.relu(ref) if epi == 2 else ref + r.double() if epi == 3 else ref
+        run = lambda: eng.gemm(a, w, b, residual=r if epi == 3 else None, epilogue=epi).cpu()  # noqa: E731
+        eng.set_precision("fp32")
+        exact = run()
+        eng.set_precision("f32x3")
+        assert eng.precision == "f32x3"
+        outs = []
+        for cfg in range(6):
+            eng.tuner_import(f"f32x3 {m} {n} {k} {epi} {cfg}\n")
+            outs.append(run())
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), "f32x3 tile configurations must be bit-identical"
+        rms = ref.pow(2).mean().sqrt().item()
+        err_x3 = (outs[0].double() - ref).abs().max().item()
+        err_f32 = (exact.double() - ref).abs().max().item()
+        assert err_x3 <= max(2.0 * err_f32, 2e-6 * rms) and err_x3 < 1e-5 * rms, (epi, err_x3, err_f32, rms)
+        lo, hi = 17, 17 + 256                                   # a 256-row slice is still served by the split family
+        part = eng.gemm(a[lo:hi], w, b, residual=r[lo:hi] if epi == 3 else None, epilogue=epi).cpu()
+        assert torch.equal(part, outs[0][lo:hi]), "batch invariance"
+        small = eng.gemm(a[:100], w, b, residual=r[:100] if epi == 3 else None, epilogue=epi).cpu()
+        assert torch.equal(small, exact[:100]), "fewer than 256 rows: the exact fp32 kernels"
+    eng.close()
+
+
 def test_gemm_variants_are_bit_identical(engine):
     """Same k summation order in every tile shape: forcing nothing but changing M (which changes the tuned tile) must not
     change a row's bits."""
