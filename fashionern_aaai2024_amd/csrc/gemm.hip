@@ -326,15 +326,18 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
             const float* r = &Ws[(wn * WN + j * 32 + l31) * BKT];
             split(*reinterpret_cast<const f32x4*>(r + pc0), *reinterpret_cast<const f32x4*>(r + pc1), bp[j]);
         }
+        // products in order of the planes they need -- a1 b1 | a1 b2, a2 b1 | a2 b2, a1 b3, a3 b1 -- so that the VALU work of the
+        // deeper planes can run under the MFMAs of the shallower ones (left to hipcc's scheduler: pinning 1 MFMA : 6 VALU groups with
+        // sched_group_barrier was measured and changed nothing on the 128x128 tile, -4 % on the fat-wave macro-tile)
 #pragma unroll
-        for (int la = 0; la < NPL; ++la)
+        for (int ord = 0; ord < NPL; ++ord)
 #pragma unroll
-            for (int lb = 0; lb + la < NPL; ++lb)
+            for (int la = 0; la <= ord; ++la)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][la], bp[j][lb], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][la], bp[j][ord - la], acc[i][j], 0, 0, 0);
     };
     auto compute_fp32 = [&](int buf) {
         const float* As = smem + buf * TILE;
@@ -437,8 +440,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
 // dispatcher hands out workgroups in block order, so the small tiles back-fill the CUs as the macro-tiles drain instead of waiting
 // behind a kernel boundary (the two-launch bulk + remainder plan serialises there).  Every geometry accumulates each output over k
 // in the same order: results are bit-identical to every other configuration, and the bands can be cut at any row.
-template <bool WIDE>
-__global__ __launch_bounds__(512, 4) void gemm_f32_mixed_kernel(GemmParams p, int ra, int rb, int n_a8, int n_b8) {
+// SPLIT = 3 (f32x3 family): the same three bands on FOUR waves -- macro-tile on fat waves (wave tile 128x64 / 64x128: the bf16
+// planes need the registers of two waves per SIMD), 128x128 and 64x128 on 64x64 / 32x64 wave tiles.
+template <bool WIDE, int SPLIT = 0>
+__global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 2 : 4) void gemm_f32_mixed_kernel(GemmParams p, int ra, int rb, int n_a8, int n_b8) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * 384 * 16];
     const int bid = blockIdx.x;
     auto band = [&](int row0, int rows) {      // the rows [row0, row0 + rows) as a GEMM of their own (plain, row-independent epilogues only)
@@ -449,15 +454,16 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_mixed_kernel(GemmParams p, in
         q.M = rows;
         return q;
     };
+    constexpr int BMA = WIDE ? 128 : 256, BNA = WIDE ? 256 : 128;
+    constexpr int WMA = SPLIT ? BMA / 2 : 64, WNA = SPLIT ? BNA / 2 : 64;      // 2 x 2 fat waves, or 8 waves of 64x64
     if (bid < n_a8) {
-        constexpr int BMA = WIDE ? 128 : 256, BNA = WIDE ? 256 : 128;
         const int tiles = (ra / BMA) * ((p.N + BNA - 1) / BNA);
-        if (bid < tiles) glds_tile<BMA, BNA, 64, 64, 16>(band(0, ra), bid, smem);
+        if (bid < tiles) glds_tile<BMA, BNA, WMA, WNA, 16, false, 0, false, SPLIT>(band(0, ra), bid, smem);
     } else if (bid < n_a8 + n_b8) {
         const int tiles = ((rb - ra + 127) / 128) * ((p.N + 127) / 128);
-        if (bid - n_a8 < tiles) glds_tile<128, 128, 64, 32, 16>(band(ra, rb - ra), bid - n_a8, smem);
+        if (bid - n_a8 < tiles) glds_tile<128, 128, 64, SPLIT ? 64 : 32, 16, false, 0, false, SPLIT>(band(ra, rb - ra), bid - n_a8, smem);
     } else {
-        glds_tile<64, 128, 32, 32, 16>(band(rb, p.M - rb), bid - n_a8 - n_b8, smem);
+        glds_tile<64, 128, 32, SPLIT ? 64 : 32, 16, false, 0, false, SPLIT>(band(rb, p.M - rb), bid - n_a8 - n_b8, smem);
     }
 }
 
@@ -750,16 +756,18 @@ static bool mixed_plan_ok(const Plan& pl, int M) {
 }
 static std::map<ShapeKey, Plan> g_tuned;
 static std::mutex g_tuned_mu;
-static std::map<ShapeKey, int>& tuned_split_map();      // the f32x3 family's choices (defined with that family below)
+static std::map<ShapeKey, Plan>& tuned_split_map();     // the f32x3 family's choices (defined with that family below)
 
 // FERN_GEMM_TILES=<file>: pin the per-shape choices (lines "f32 M N K epi aload cfg [rows_a cfg_b]", as written by gemm_tuner_export /
 // fern_tuner_export): listed shapes are never timed again, so a run's kernels -- and its HBM / L2 traffic -- are reproducible
 // from box to box.  Loaded once, before the first tuned launch.
 static void pin_tile_line(const char* line) {      // caller holds g_tuned_mu
     {
-        int M, N, K, epi, cfg;
-        if (sscanf(line, "f32x3 %d %d %d %d %d", &M, &N, &K, &epi, &cfg) == 5) {
-            if (cfg >= 0 && cfg < 6) tuned_split_map()[ShapeKey{M, N, K, epi, 0}] = cfg;
+        int M, N, K, epi, cfg, ra = 0, rb = 0;
+        const int got = sscanf(line, "f32x3 %d %d %d %d %d %d %d", &M, &N, &K, &epi, &cfg, &ra, &rb);
+        if (got >= 5) {
+            if (cfg >= 0 && cfg < 6) tuned_split_map()[ShapeKey{M, N, K, epi, 0}] = Plan{cfg, 0, cfg};
+            else if (got == 7 && mixed_plan_ok(Plan{cfg, ra, rb}, M)) tuned_split_map()[ShapeKey{M, N, K, epi, 0}] = Plan{cfg, ra, rb};
             return;
         }
     }
@@ -804,7 +812,8 @@ void gemm_tuner_export(std::string& out) {
     std::lock_guard<std::mutex> lock(g_tuned_mu);
     for (const auto& kv : tuned_split_map()) {
         char line[128];
-        snprintf(line, sizeof line, "f32x3 %d %d %d %d %d\n", kv.first.M, kv.first.N, kv.first.K, kv.first.epi, kv.second);
+        snprintf(line, sizeof line, "f32x3 %d %d %d %d %d %d %d\n", kv.first.M, kv.first.N, kv.first.K, kv.first.epi, kv.second.cfg, kv.second.rows_a,
+                 kv.second.cfg_b);
         out += line;
     }
     for (const auto& kv : g_tuned) {
@@ -848,9 +857,40 @@ static hipError_t launch_mixed(const Plan& pl, const GemmParams& p, hipStream_t 
     const int n_a = (ra / bma) * ((p.N + bna - 1) / bna), n_b = ((rb - ra + 127) / 128) * nbn, n_c = ((p.M - rb + 63) / 64) * nbn;
     const int n_a8 = (n_a + 7) & ~7, n_b8 = (n_b + 7) & ~7;      // every band starts on a multiple of 8 blocks: block % 8 stays the XCD inside the band
     const int grid = n_c > 0 ? n_a8 + n_b8 + n_c : n_b > 0 ? n_a8 + n_b : n_a;
-    if (wide) hipLaunchKernelGGL(gemm_f32_mixed_kernel<true>, dim3(grid), dim3(512), 0, s, p, ra, rb, n_a8, n_b8);
+    if (p.split == 3) {
+        if (wide) hipLaunchKernelGGL((gemm_f32_mixed_kernel<true, 3>), dim3(grid), dim3(256), 0, s, p, ra, rb, n_a8, n_b8);
+        else hipLaunchKernelGGL((gemm_f32_mixed_kernel<false, 3>), dim3(grid), dim3(256), 0, s, p, ra, rb, n_a8, n_b8);
+    } else if (wide) hipLaunchKernelGGL(gemm_f32_mixed_kernel<true>, dim3(grid), dim3(512), 0, s, p, ra, rb, n_a8, n_b8);
     else hipLaunchKernelGGL(gemm_f32_mixed_kernel<false>, dim3(grid), dim3(512), 0, s, p, ra, rb, n_a8, n_b8);
     return hipGetLastError();
+}
+
+// the cuts the tuners time for a mixed plan: ra by whole rounds of 512 / 256 macro-tiles or every full macro row, rb = everything /
+// nothing / whole 128-row tiles / 128x128 tiles in whole rounds of the chip
+static int mixed_candidates(int M, int N, Plan (&out)[32]) {
+    int n = 0;
+    auto add = [&](int cfg, int ra, int rb) {
+        const Plan pl{cfg, ra, rb};
+        if (!mixed_plan_ok(pl, M) || n >= 32) return;
+        for (int i = 0; i < n; ++i)
+            if (out[i].cfg == cfg && out[i].rows_a == ra && out[i].cfg_b == rb) return;
+        out[n++] = pl;
+    };
+    const int nbn = (N + 127) / 128;
+    for (int w = 0; w < 2; ++w) {
+        const int bma = w ? 128 : 256, bna = w ? 256 : 128;
+        const long nbna = (N + bna - 1) / bna, row_tiles = M / bma;
+        const int ras[3] = {(int)row_tiles * bma, (int)((row_tiles * nbna / 512) * 512 / nbna) * bma, (int)((row_tiles * nbna / 256) * 256 / nbna) * bma};
+        for (int ra : ras) {
+            if (ra < bma) continue;
+            const int mr = M - ra;
+            add(kCfgMixed + w, ra, M);
+            add(kCfgMixed + w, ra, ra);
+            add(kCfgMixed + w, ra, ra + (mr / 128) * 128);
+            add(kCfgMixed + w, ra, ra + (int)(((long)(mr / 128) * nbn / 256) * 256 / nbn) * 128);
+        }
+    }
+    return n;
 }
 
 static hipError_t launch_plan(const Plan& pl, const GemmParams& p, hipStream_t s) {
@@ -937,28 +977,8 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
     float t_mixed[32];
     int nmixed = 0;
     if (try_pairs && p.ksplit <= 1) {
-        auto add = [&](int cfg, int ra, int rb) {
-            const Plan pl{cfg, ra, rb};
-            if (!mixed_plan_ok(pl, p.M) || nmixed >= 32) return;
-            for (int i = 0; i < nmixed; ++i)
-                if (mixed[i].cfg == cfg && mixed[i].rows_a == ra && mixed[i].cfg_b == rb) return;
-            t_mixed[nmixed] = 1e30f;
-            mixed[nmixed++] = pl;
-        };
-        const int nbn = (p.N + 127) / 128;
-        for (int w = 0; w < 2; ++w) {
-            const int bma = w ? 128 : 256, bna = w ? 256 : 128;
-            const long nbna = (p.N + bna - 1) / bna, row_tiles = p.M / bma;
-            const int ras[3] = {(int)row_tiles * bma, (int)((row_tiles * nbna / 512) * 512 / nbna) * bma, (int)((row_tiles * nbna / 256) * 256 / nbna) * bma};
-            for (int ra : ras) {
-                if (ra < bma) continue;
-                const int mr = p.M - ra;
-                add(kCfgMixed + w, ra, p.M);                                   // the rest in 128x128 tiles
-                add(kCfgMixed + w, ra, ra);                                     // the rest in 64x128 tiles
-                add(kCfgMixed + w, ra, ra + (mr / 128) * 128);                  // whole 128-row tiles, the ragged tail in 64x128
-                add(kCfgMixed + w, ra, ra + (int)(((long)(mr / 128) * nbn / 256) * 256 / nbn) * 128);      // 128x128 tiles in whole rounds of the chip
-            }
-        }
+        nmixed = mixed_candidates(p.M, p.N, mixed);
+        for (int i = 0; i < nmixed; ++i) t_mixed[i] = 1e30f;
         for (int round = 0; round < 2; ++round)
             for (int i = 0; i < nmixed; ++i) t_mixed[i] = std::min(t_mixed[i], timed([&] { return launch_mixed(mixed[i], q, s); }));
     }
@@ -999,8 +1019,8 @@ static hipError_t launch_cfg_split(int c, const GemmParams& p, hipStream_t s) {
     }
     return hipGetLastError();
 }
-static std::map<ShapeKey, int> g_tuned_s;      // guarded by g_tuned_mu
-static std::map<ShapeKey, int>& tuned_split_map() { return g_tuned_s; }
+static std::map<ShapeKey, Plan> g_tuned_s;      // guarded by g_tuned_mu; Plan{cfg, 0, cfg} or a mixed plan {20|21, ra, rb}
+static std::map<ShapeKey, Plan>& tuned_split_map() { return g_tuned_s; }
 static int forced_cfg_split() {
     static int v = [] { const char* e = getenv("FERN_GEMM_SPLIT_CFG"); return e ? atoi(e) : -1; }();
     return v;
@@ -1009,9 +1029,13 @@ static int heuristic_split(const GemmParams& p) {
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     return t128 >= 1024 ? 1 : t128 >= 384 ? 0 : 5;
 }
-static int tune_shape_split(const GemmParams& p, hipStream_t s, bool& tuned) {
+static hipError_t launch_plan_split(const Plan& pl, const GemmParams& p, hipStream_t s) {
+    return pl.cfg >= kCfgMixed ? launch_mixed(pl, p, s) : launch_cfg_split(pl.cfg, p, s);
+}
+static Plan tune_shape_split(const GemmParams& p, hipStream_t s, bool& tuned) {
     tuned = false;
-    const int fallback = heuristic_split(p);
+    const int fb = heuristic_split(p);
+    const Plan fallback{fb, 0, fb};
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (!tuning_enabled() || hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return fallback;
     float* scratch = nullptr;
@@ -1021,24 +1045,32 @@ static int tune_shape_split(const GemmParams& p, hipStream_t s, bool& tuned) {
     (void)hipEventCreate(&e1);
     GemmParams q = p;
     q.C = scratch;      // the residual input is only read
-    float t[kNumCfgsS];
+    Plan cand[kNumCfgsS + 32];
+    int nc = 0;
+    for (int c = 0; c < kNumCfgsS; ++c) cand[nc++] = Plan{c, 0, c};
+    if (p.M >= 2048) {
+        Plan mixed[32];
+        const int nm = mixed_candidates(p.M, p.N, mixed);
+        for (int i = 0; i < nm; ++i) cand[nc++] = mixed[i];
+    }
+    float t[kNumCfgsS + 32];
     for (float& v : t) v = 1e30f;
     for (int round = 0; round < 2; ++round)
-        for (int c = 0; c < kNumCfgsS; ++c) {
-            if (launch_cfg_split(c, q, s) != hipSuccess) continue;
+        for (int c = 0; c < nc; ++c) {
+            if (launch_plan_split(cand[c], q, s) != hipSuccess) continue;
             (void)hipEventRecord(e0, s);
-            (void)launch_cfg_split(c, q, s);
-            (void)launch_cfg_split(c, q, s);
+            (void)launch_plan_split(cand[c], q, s);
+            (void)launch_plan_split(cand[c], q, s);
             (void)hipEventRecord(e1, s);
             if (hipEventSynchronize(e1) != hipSuccess) continue;
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, e0, e1);
             t[c] = std::min(t[c], ms);
         }
-    int best = fallback;
+    Plan best = fallback;
     float best_ms = 1e30f;
-    for (int c = 0; c < kNumCfgsS; ++c)
-        if (t[c] < best_ms) { best_ms = t[c]; best = c; }
+    for (int c = 0; c < nc; ++c)
+        if (t[c] < best_ms) { best_ms = t[c]; best = cand[c]; }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(scratch);
@@ -1046,23 +1078,23 @@ static int tune_shape_split(const GemmParams& p, hipStream_t s, bool& tuned) {
     return best;
 }
 static hipError_t launch_gemm_split(const GemmParams& p, hipStream_t s) {
-    int c = forced_cfg_split();
-    if (c < 0 || c >= kNumCfgsS) {
-        const double flops = 2.0 * p.M * (double)p.N * p.K;
-        c = heuristic_split(p);
-        if (tuning_enabled() && flops >= 2.5e8 && flops <= 2e11) {
-            const ShapeKey key{p.M, p.N, p.K, p.epi, 0};
-            std::lock_guard<std::mutex> lock(g_tuned_mu);
-            auto it = g_tuned_s.find(key);
-            if (it != g_tuned_s.end()) c = it->second;
-            else {
-                bool tuned = false;
-                c = tune_shape_split(p, s, tuned);
-                if (tuned) g_tuned_s.emplace(key, c);
-            }
+    const int f = forced_cfg_split();
+    if (f >= 0 && f < kNumCfgsS) return launch_cfg_split(f, p, s);
+    const double flops = 2.0 * p.M * (double)p.N * p.K;
+    const int hb = heuristic_split(p);
+    Plan pl{hb, 0, hb};
+    if (tuning_enabled() && flops >= 2.5e8 && flops <= 2e11) {
+        const ShapeKey key{p.M, p.N, p.K, p.epi, 0};
+        std::lock_guard<std::mutex> lock(g_tuned_mu);
+        auto it = g_tuned_s.find(key);
+        if (it != g_tuned_s.end()) pl = it->second;
+        else {
+            bool tuned = false;
+            pl = tune_shape_split(p, s, tuned);
+            if (tuned) g_tuned_s.emplace(key, pl);
         }
     }
-    return launch_cfg_split(c, p, s);
+    return launch_plan_split(pl, p, s);
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {

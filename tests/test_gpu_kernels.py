@@ -271,6 +271,11 @@ def test_gemm_f32x3_is_fp32_accurate_and_configuration_independent(m, n, k):
         for cfg in range(6):
             eng.tuner_import(f"f32x3 {m} {n} {k} {epi} {cfg}\n")
             outs.append(run())
+        if m >= 2048:      # one-launch mixed plans of the family (fat-wave macro-tiles + 128x128 + 64x128 bands)
+            for cfg, ra, rb in ((20, 2048, m), (20, 3840, 3840), (21, 1920, 3072), (21, 4096, 4096)):
+                eng.tuner_import(f"f32x3 {m} {n} {k} {epi} {cfg} {ra} {rb}\n")
+                assert f"f32x3 {m} {n} {k} {epi} {cfg} {ra} {rb}" in eng.tuner_export(), "the plan was refused"
+                outs.append(run())
         for o in outs[1:]:
             assert torch.equal(o, outs[0]), "f32x3 tile configurations must be bit-identical"
         rms = ref.pow(2).mean().sqrt().item()
