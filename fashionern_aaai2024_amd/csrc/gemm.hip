@@ -295,18 +295,23 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
     typedef short bf16x8s __attribute__((ext_vector_type(8)));
     typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
     constexpr int NPL = SPLIT > 0 ? SPLIT : 1;
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
     auto split = [&](const f32x4& g0, const f32x4& g1, bf16x8s (&pl)[NPL]) {
-        float x[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        f32x2s x[4] = {{g0[0], g0[1]}, {g0[2], g0[3]}, {g1[0], g1[1]}, {g1[2], g1[3]}};      // pairs: the residual is one packed fp32 subtract
 #pragma unroll
         for (int lv = 0; lv < NPL; ++lv) {
             u32x4s packed;
 #pragma unroll
             for (int q2 = 0; q2 < 4; ++q2)      // bytes 2-3 of two floats -> one dword of two bf16
-                packed[q2] = __builtin_amdgcn_perm(__float_as_uint(x[2 * q2 + 1]), __float_as_uint(x[2 * q2]), 0x07060302u);
+                packed[q2] = __builtin_amdgcn_perm(__float_as_uint(x[q2][1]), __float_as_uint(x[q2][0]), 0x07060302u);
             pl[lv] = __builtin_bit_cast(bf16x8s, packed);
             if (lv + 1 < NPL) {
 #pragma unroll
-                for (int q2 = 0; q2 < 8; ++q2) x[q2] = x[q2] - __uint_as_float(__float_as_uint(x[q2]) & 0xFFFF0000u);
+                for (int q2 = 0; q2 < 4; ++q2) {
+                    const u32x2s top = __builtin_bit_cast(u32x2s, x[q2]) & 0xFFFF0000u;
+                    x[q2] = x[q2] - __builtin_bit_cast(f32x2s, top);
+                }
             }
         }
     };
