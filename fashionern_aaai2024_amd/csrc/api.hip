@@ -1558,7 +1558,9 @@ extern "C" int fern_sim_topk_bf16(fern_ctx* c, const float* q, const uint16_t* g
         FERN_TRY(ws_begin(c, s));
         RankPlan P;
         FERN_TRY(rank_plan(c, m, N, K, ex, idx_offset, &P));
-        // the sweep kernel keeps <= 64 queries resident in LDS: one launch per 64-query block, shared plan buffers
+        // one sweep launch per query block, shared plan buffers: 128 queries per gallery pass where the kernel has the two-block form
+        // (D = 64 / 128 / 256 / 512: second block's bf16 image in LDS), else 64
+        const long QBLK = (D == 64 || D == 128 || D == 256 || D == 512) ? 128 : 64;
         auto block_filter = [&](long b0) {
             TopkFilter f = P.filt;
             f.cand += b0 * RANK_SLOTS * P.cap; f.thr_key += b0; f.count += b0 * RANK_SLOTS;
@@ -1567,13 +1569,13 @@ extern "C" int fern_sim_topk_bf16(fern_ctx* c, const float* q, const uint16_t* g
         };
         int slot;
         FERN_TRY(prof_open(c, PROF_TOPK, 0, s, &slot));
-        for (long b0 = 0; b0 < m; b0 += 64)
-            HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery, P.sample + b0 * P.ld, P.ld, (int)std::min<long>(64, m - b0), N, D, P.S, P.R,
+        for (long b0 = 0; b0 < m; b0 += QBLK)
+            HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery, P.sample + b0 * P.ld, P.ld, (int)std::min<long>(QBLK, m - b0), N, D, P.S, P.R,
                                       nullptr, nullptr, s));
         HIP_TRY(launch_topk_sample_bound(P.sample, P.ld, m, P.S, P.R, K, ex, idx_offset, P.thr, P.count, P.flags, P.state, s));
         FERN_TRY(prof_close(c, slot, s));
-        for (long b0 = 0; b0 < m; b0 += 64) {
-            const int mb = (int)std::min<long>(64, m - b0);
+        for (long b0 = 0; b0 < m; b0 += QBLK) {
+            const int mb = (int)std::min<long>(QBLK, m - b0);
             const TopkFilter f = block_filter(b0);
             FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + (double)mb * D * 4 + (double)mb * K * 8, s, &slot, mb, (int)N, D, 16));
             HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery, nullptr, 0, mb, N, D, 0, 1, &f, nullptr, s));

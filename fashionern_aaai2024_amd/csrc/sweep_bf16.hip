@@ -46,7 +46,7 @@ constexpr int STAGE_BYTES = ROWS_T * KSTAGE * 2;   // 4096
 // Filter form: survivors are queued per wave in LDS and flushed to the candidate lists QFLUSH.. at a time -- the list append is
 // a RETURNING global atomic (~1-2 us round trip); one per finished tile stalled the wave's DMA ring and cost 40 % of the stream
 constexpr int QCAP = 128;                          // queue entries per wave (a register can add up to 64 at once)
-constexpr int QUEUE_BYTES = 4 * QCAP * 12 + 64 * 8;      // 4 waves x (key 8 B + query 4 B) + the 64 bounds as keys
+constexpr int QUEUE_BYTES = 4 * QCAP * 12 + 128 * 8 + 128 * 4;     // 4 waves x (key 8 B + query 4 B) + the (<= 128) bounds as keys and as floats
 
 // FILTER = false: the sample pass -- tile rows are the gallery rows sample_row(c, R) of S sample columns, scores are stored
 // ([B, ld], 128-byte coalesced).  FILTER = true: the full sweep -- nothing is stored; every finished 32x32 score tile is
@@ -55,30 +55,39 @@ constexpr int QUEUE_BYTES = 4 * QCAP * 12 + 64 * 8;      // 4 waves x (key 8 B +
 // VGPRs at D = 512 -- the kernel runs one wave per SIMD, so it owns the whole 512-entry file), and the LDS the query image
 // occupied goes to the ring: 9 stages per wave, 128 KiB in flight per CU instead of 64.  HBM latency under this load is ~4 us,
 // and 64 KiB in flight per CU is then 16 GB/s per CU (3.8 TB/s on the chip) by Little's law.  KCH = 0: queries stay in LDS (any D).
-template <int STAGES, bool FILTER, int KCH>
+// QB = 2 (KCH > 0 only): 65..128 queries in ONE pass over the gallery (round 2 swept the gallery once per 64-query block).  Queries
+// 0..63 keep their fragments in registers as before; the bf16 image of queries 64..127 stays in LDS (66 KB at D = 512) and their
+// fragments are read per k step -- 3 LDS reads per k step instead of 1, a fifth of the LDS bandwidth at the gallery's HBM rate -- and
+// the ring shrinks from 9 to 5 stages per wave to make room.  MFMA time per gallery byte doubles and stays far below the HBM time.
+template <int STAGES, bool FILTER, int KCH, int QB = 1>
 __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u16* g, float* scores, long ld, int B, long N, int D, long S, int R,
                                                          TopkFilter filt, const int* gate) {
+    static_assert(QB == 1 || KCH > 0, "two query blocks need the register-resident form");
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int q_stride = D * 2 + 16;                               // bytes; +16 spreads rows over the banks
-    unsigned char* ring_base = KCH > 0 ? smem : smem + ((64 * q_stride + 1023) & ~1023);      // KCH > 0: the ring overlays the query image
+    // KCH > 0, QB = 1: the ring overlays the query image; QB = 2: the image of queries 64..127 stays, the ring follows it
+    unsigned char* ring_base = (KCH > 0 && QB == 1) ? smem : smem + ((64 * q_stride + 1023) & ~1023);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // ---- queries -> bf16 -> LDS (rows >= B are zero) ----
-    for (int i = tid; i < 64 * (D / 8); i += 256) {
-        const int row = i / (D / 8), c8 = (i % (D / 8)) * 8;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row < B) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(q + (long)row * D + c8);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(q + (long)row * D + c8 + 4);
+    // ---- queries -> bf16 -> LDS (rows >= B are zero); block 0 = queries 0..63, block 1 = 64..127 ----
+    auto stage_queries = [&](int q0) {
+        for (int i = tid; i < 64 * (D / 8); i += 256) {
+            const int row = i / (D / 8), c8 = (i % (D / 8)) * 8;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (q0 + row < B) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(q + (long)(q0 + row) * D + c8);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(q + (long)(q0 + row) * D + c8 + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = (short)f32_to_bf16_rne(a[e]); v[4 + e] = (short)f32_to_bf16_rne(b[e]); }
+                for (int e = 0; e < 4; ++e) { v[e] = (short)f32_to_bf16_rne(a[e]); v[4 + e] = (short)f32_to_bf16_rne(b[e]); }
+            }
+            *reinterpret_cast<bf16x8*>(smem + row * q_stride + c8 * 2) = v;
         }
-        *reinterpret_cast<bf16x8*>(smem + row * q_stride + c8 * 2) = v;
-    }
+    };
+    stage_queries(0);
     __syncthreads();
     constexpr int NFR = KCH > 0 ? 8 * KCH : 1;
     bf16x8 afr[NFR];
@@ -90,22 +99,30 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
                 afr[tm * 4 * KCH + kidx] = *reinterpret_cast<const bf16x8*>(smem + (tm * 32 + l31) * q_stride + (kidx * 16 + lh * 8) * 2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();                                           // every wave holds its fragments: the image may be overwritten
+        if (QB == 2) {                                             // ... by the second query block, which stays in LDS
+            stage_queries(64);
+            __syncthreads();
+        }
     }
 
     // per-query bounds of the filter, laid out like the accumulator registers (query = tm*32 + (r&3) + 8(r>>2) + 4 lh)
-    float bound[2][16];
+    float bound[QB == 1 ? 2 : 1][16];                                // QB = 2: the bounds are re-read from LDS per tile (registers are full)
     unsigned char* qbase = ring_base + 4 * STAGES * STAGE_BYTES;
     unsigned long long* thr_lds = reinterpret_cast<unsigned long long*>(qbase + 4 * QCAP * 12);
+    float* thr_f = reinterpret_cast<float*>(qbase + 4 * QCAP * 12 + 128 * 8);      // QB = 2: the bounds as floats, [128]
     unsigned long long* qkey = reinterpret_cast<unsigned long long*>(qbase + wave * QCAP * 12);
     int* qq = reinterpret_cast<int*>(qbase + wave * QCAP * 12 + QCAP * 8);
     int qlen = 0;                                                  // wave-uniform
     if (FILTER) {
-        if (tid < 64) thr_lds[tid] = tid < B ? filt.thr_key[tid] : ~0ull;
+        if (tid < 64 * QB) thr_lds[tid] = tid < B ? filt.thr_key[tid] : ~0ull;
+        if (QB == 2 && tid < 128) thr_f[tid] = filter_bound(tid < B ? filt.thr_key[tid] : ~0ull);
         __syncthreads();
+        if (QB == 1) {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bound[tm][r] = filter_bound(thr_lds[tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]);
+                for (int r = 0; r < 16; ++r) bound[tm][r] = filter_bound(thr_lds[tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]);
+        }
     }
     // append the queued survivors to their lists: one batch of returning atomics per <= 64 entries
     auto flush = [&]() {
@@ -176,9 +193,9 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
         }
     };
 
-    f32x16 acc[2];
+    f32x16 acc[2 * QB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2 * QB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
@@ -198,10 +215,10 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
         for (int ks = 0; ks < KSTAGE / 16; ++ks) {
             const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(st + l31 * 128 + (((2 * ks + lh) ^ sw) * 16));
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
+            for (int tm = 0; tm < 2 * QB; ++tm) {
                 bf16x8 afrag;
-                if (KCH > 0) afrag = afr[KCH > 0 ? tm * 4 * KCH + kc * 4 + ks : 0];      // kc is a compile-time constant on this path
-                else afrag = *reinterpret_cast<const bf16x8*>(smem + (tm * 32 + l31) * q_stride + (kc * KSTAGE + ks * 16 + lh * 8) * 2);
+                if (KCH > 0 && tm < 2) afrag = afr[KCH > 0 ? tm * 4 * KCH + kc * 4 + ks : 0];      // kc is a compile-time constant on this path
+                else afrag = *reinterpret_cast<const bf16x8*>(smem + ((tm & 1) * 32 + l31) * q_stride + (kc * KSTAGE + ks * 16 + lh * 8) * 2);
                 acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[tm], 0, 0, 0);
             }
         }
@@ -210,15 +227,23 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
         const long n = t * ROWS_T + l31;
         if (FILTER) {
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                filter_tile(acc[tm], bound[tm], tm, n, n < N);
+            for (int tm = 0; tm < 2 * QB; ++tm) {
+                if (QB == 2) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(thr_f + tm * 32 + 8 * g4 + 4 * lh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bound[0][4 * g4 + e] = b4[e];
+                    }
+                }
+                filter_tile(acc[tm], bound[QB == 2 ? 0 : tm], tm, n, n < N);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[tm][r] = 0.0f;
             }
         } else {                                                 // sample pass: 128-byte coalesced score stores
             const long grow = sample_row(n < S ? n : S - 1, R);
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < 2 * QB; ++tm)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int qi = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -250,14 +275,14 @@ hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStre
     return hipGetLastError();
 }
 
-template <int STAGES, bool FILTER, int KCH>
+template <int STAGES, bool FILTER, int KCH, int QB = 1>
 static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
                                     const TopkFilter& filt, const int* gate, hipStream_t s) {
     const size_t qbytes = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024;
     const size_t ringq = (size_t)4 * STAGES * STAGE_BYTES + QUEUE_BYTES;
-    const size_t lds = KCH > 0 ? std::max(qbytes, ringq) : qbytes + ringq;
+    const size_t lds = (KCH > 0 && QB == 1) ? std::max(qbytes, ringq) : qbytes + ringq;
     static size_t attr_set = 0;
-    auto kern = sweep_bf16_kernel<STAGES, FILTER, KCH>;
+    auto kern = sweep_bf16_kernel<STAGES, FILTER, KCH, QB>;
     if (lds > attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -274,6 +299,15 @@ template <bool FILTER>
 static hipError_t launch_sweep_mode(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
                                     const TopkFilter& filt, const int* gate, hipStream_t s) {
     static const bool regq = [] { const char* e = getenv("FERN_SWEEP_REGQ"); return !(e && e[0] == '0'); }();      // A/B switch
+    if (B > 64) {    // 65..128 queries per gallery pass: second query block in LDS, 5-stage ring
+        switch (D) {
+            case 64: return launch_sweep_inst<5, FILTER, 1, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+            case 128: return launch_sweep_inst<5, FILTER, 2, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+            case 256: return launch_sweep_inst<5, FILTER, 4, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+            case 512: return launch_sweep_inst<5, FILTER, 8, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     if (regq) {      // register-resident queries, 9-stage ring
         switch (D) {
             case 64: return launch_sweep_inst<9, FILTER, 1>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
@@ -295,7 +329,7 @@ static hipError_t launch_sweep_mode(const float* q, const unsigned short* g, flo
 hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
                              const TopkFilter* filt, const int* gate, hipStream_t s) {
     if (B <= 0 || N <= 0) return hipSuccess;
-    if (B > 64 || D % 64 || D > 1024 || R < 1) return hipErrorInvalidValue;
+    if (B > 128 || (B > 64 && D != 64 && D != 128 && D != 256 && D != 512) || D % 64 || D > 1024 || R < 1) return hipErrorInvalidValue;
     if (filt) return launch_sweep_mode<true>(q, g, nullptr, 0, B, N, D, 0, 1, *filt, gate, s);
     if (S <= 0) return hipSuccess;
     if (!scores || (S - 1) * (long)R >= N) return hipErrorInvalidValue;      // every sample run must start inside the gallery
