@@ -762,6 +762,7 @@ static bool mixed_plan_ok(const Plan& pl, int M) {
 static std::map<ShapeKey, Plan> g_tuned;
 static std::mutex g_tuned_mu;
 static std::map<ShapeKey, Plan>& tuned_split_map();     // the f32x3 family's choices (defined with that family below)
+constexpr int kNumCfgsS = 6;                             // ... and its number of single configurations
 
 // FERN_GEMM_TILES=<file>: pin the per-shape choices (lines "f32 M N K epi aload cfg [rows_a cfg_b]", as written by gemm_tuner_export /
 // fern_tuner_export): listed shapes are never timed again, so a run's kernels -- and its HBM / L2 traffic -- are reproducible
@@ -771,7 +772,7 @@ static void pin_tile_line(const char* line) {      // caller holds g_tuned_mu
         int M, N, K, epi, cfg, ra = 0, rb = 0;
         const int got = sscanf(line, "f32x3 %d %d %d %d %d %d %d", &M, &N, &K, &epi, &cfg, &ra, &rb);
         if (got >= 5) {
-            if (cfg >= 0 && cfg < 6) tuned_split_map()[ShapeKey{M, N, K, epi, 0}] = Plan{cfg, 0, cfg};
+            if (cfg >= 0 && cfg < kNumCfgsS) tuned_split_map()[ShapeKey{M, N, K, epi, 0}] = Plan{cfg, 0, cfg};
             else if (got == 7 && mixed_plan_ok(Plan{cfg, ra, rb}, M)) tuned_split_map()[ShapeKey{M, N, K, epi, 0}] = Plan{cfg, ra, rb};
             return;
         }
@@ -1006,7 +1007,6 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
 // The planes of a wave tile are 12 VGPRs per 32-row fragment, so the configurations trade occupancy for room: the 128x128 tile at
 // <= 170 VGPRs (three workgroups per CU), the macro-tiles on four fat waves (wave tile 128x64 / 64x128, two workgroups per CU),
 // and the small tiles at the usual 128.  All bit-identical to each other; tuned per shape like the fp32 family.
-constexpr int kNumCfgsS = 6;
 static const TileCfg kCfgsS[kNumCfgsS] = {{128, 128, 16, 1.f}, {256, 128, 16, 1.f}, {128, 256, 16, 1.f}, {64, 128, 16, 1.f}, {128, 64, 16, 1.f}, {64, 64, 16, 1.f}};
 static bool split_family_ok(const GemmParams& p) {
     return p.split == 3 && split_ok(p) && p.M >= 256 && p.K % 16 == 0;
