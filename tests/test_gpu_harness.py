@@ -229,11 +229,13 @@ def test_cli_driver_under_torchrun_prints_the_single_process_recalls():
         assert keep(one.stdout) and keep(two.stdout) == keep(one.stdout), (keep(one.stdout), keep(two.stdout))
 
 
-def test_full_pipeline_in_f32x3_mode_is_fp32_accurate():
-    """FERN_PREC_F32X3 end to end (encode image + text, fusion, ranking): query / gallery features within 2e-5 of the fp32 mode's
+@pytest.mark.parametrize("cfg_name", ["tiny-w256", "tiny-resnet"])
+def test_full_pipeline_in_f32x3_mode_is_fp32_accurate(cfg_name):
+    """FERN_PREC_F32X3 end to end (encode image + text, fusion, ranking; ViT and ModifiedResNet image towers -- the ResNet's 1x1
+    convolutions run split, its 3x3 window loader stays on the exact kernels): query / gallery features within 2e-5 of the fp32 mode's
     (unit-norm features; measured ~1e-6), cosine scores within 1e-5, and the ranking identical except between rows the fp32 mode itself
     separates by < 2e-6 -- the same near-tie allowance the fp32 mode gets against the BLAS-ordered oracle."""
-    cfg = synth.CLIP_CONFIGS["tiny-w256"]
+    cfg = synth.CLIP_CONFIGS[cfg_name]
     d = cfg.embed_dim
     im, tk = torch.from_numpy(synth.images(40, cfg, 7)), torch.from_numpy(synth.captions(40, cfg, 7))
     lc = torch.from_numpy(synth.local_feats(40, d, 7))
