@@ -18,6 +18,7 @@ int main(int argc, char** argv) {
     const int cfg = argc > 4 ? atoi(argv[4]) : 8, epi = argc > 5 ? atoi(argv[5]) : EPI_BIAS;
     const char* out = argc > 6 ? argv[6] : "gemm_timeline.csv";
     const int packed = argc > 7 ? atoi(argv[7]) : 0;      // 1: operands k-slab-major (timing experiment; results are then garbage)
+    const int ksplit = argc > 8 ? atoi(argv[8]) : 1;      // > 1: split-K slices (raw partial sums to a scratch buffer; the reduce pass is not timed here)
     float *A, *W, *C, *bias;
     hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&W, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4); hipMalloc(&bias, (size_t)N * 4);
     std::vector<float> h((size_t)std::max(M, N) * K);
@@ -29,6 +30,7 @@ int main(int argc, char** argv) {
     hipMemset(C, 0, (size_t)M * N * 4);
     GemmParams p{};
     p.A = A; p.W = W; p.C = C; p.bias = bias; p.R = C; p.lda = K; p.ldw = K; p.ldc = N; p.M = M; p.N = N; p.K = K; p.epi = epi; p.aload = ALOAD_PLAIN; p.packed = packed;
+    if (ksplit > 1) { p.ksplit = ksplit; hipMalloc(&p.kpart, (size_t)ksplit * M * N * 4); }
     // cfg >= 100: configuration cfg - 100 of the f32x3 family (three bf16 planes per operand); untraced timing + accuracy only
     const bool x3 = cfg >= 100;
     auto launch_any = [&](const GemmParams& q) { return x3 ? launch_cfg_split(cfg - 100, q, s_) : launch_cfg(cfg, q, s_); };
