@@ -167,30 +167,49 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
     };
 
     unsigned char* ring = ring_base + wave * (STAGES * STAGE_BYTES);
-    const int kchunks = D / KSTAGE;                                // stages per tile
+    const int kchunks = KCH > 0 ? KCH : D / KSTAGE;                // stages per tile (a compile-time power of two on the register path)
     const long rows_total = FILTER ? N : S;
     const long ntiles = (rows_total + ROWS_T - 1) / ROWS_T;
     const long gw = (long)blockIdx.x * 4 + wave, GW = (long)gridDim.x * 4;
-    const long my_tiles = gw < ntiles ? (ntiles - gw + GW - 1) / GW : 0;
-    const long nstages = my_tiles * kchunks;
+    const int my_tiles = gw < ntiles ? (int)((ntiles - gw + GW - 1) / GW) : 0;
+    const int nstages = my_tiles * kchunks;
 
     // DMA source of this lane inside a stage: piece p = 8 rows x 128 B; lane -> row p*8 + lane/8, position lane%8 holds
-    // logical chunk (lane%8) ^ ((row >> 1) & 7)
-    auto issue = [&](long s) {
-        const long t = gw + (s / kchunks) * GW;
-        const int kc = (int)(s % kchunks);
-        unsigned char* dst = ring + (int)(s % STAGES) * STAGE_BYTES;
+    // logical chunk (lane%8) ^ ((row >> 1) & 7).  The stage sequence (tile, k chunk, ring slot) advances by running counters:
+    // a 64-bit division per stage (stage index -> tile, chunk) was ~300 scalar instructions in a loop that one wave per SIMD
+    // runs alone.  Full tiles of the filtered sweep address their rows as (uniform tile base) + (per-lane 32-bit offset).
+    long t_issue = gw;                                             // wave-uniform
+    int kc_issue = 0, slot_issue = 0, issued = 0;
+    unsigned lane_off[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = p * 8 + (lane >> 3);
-            long n = t * ROWS_T + row;
-            if (!FILTER) n = sample_row(n < S ? n : S - 1, R);
-            n = n < N ? n : N - 1;
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            const u16* src = g + n * D + kc * KSTAGE + chunk * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 2);      // aux 2 = nt: every gallery byte is read once
+    for (int p = 0; p < 4; ++p) {
+        const int row = p * 8 + (lane >> 3);
+        lane_off[p] = (unsigned)((row * D + (((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2);      // bytes; 32 rows x D <= 64 KiB
+    }
+    auto issue_next = [&]() {
+        unsigned char* dst = ring + slot_issue * STAGE_BYTES;
+        if (FILTER && (t_issue + 1) * ROWS_T <= N) {
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(g) + (t_issue * ROWS_T * D + (long)kc_issue * KSTAGE) * 2;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lane_off[p]),
+                                                 (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 2);      // aux 2 = nt: every gallery byte is read once
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = p * 8 + (lane >> 3);
+                long n = t_issue * ROWS_T + row;
+                if (!FILTER) n = sample_row(n < S ? n : S - 1, R);
+                n = n < N ? n : N - 1;
+                const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+                const u16* src = g + n * D + kc_issue * KSTAGE + chunk * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 2);
+            }
         }
+        if (++kc_issue == kchunks) { kc_issue = 0; t_issue += GW; }
+        slot_issue = slot_issue + 1 == STAGES ? 0 : slot_issue + 1;
+        ++issued;
     };
 
     f32x16 acc[2 * QB];
@@ -199,18 +218,20 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    for (long s = 0; s < STAGES - 1 && s < nstages; ++s) issue(s);
+    for (int i = 0; i < STAGES - 1 && i < nstages; ++i) issue_next();
     const int sw = (l31 >> 1) & 7;
-    // one ring stage: refill the slot that was just read, wait for stage s (the newer ones stay in flight), 4 k-steps of MFMAs
-    auto stage_step = [&](long s, int kc) {
+    int slot_read = 0;                                             // ring slot of the stage being consumed
+    // one ring stage: refill the slot that was just read, wait for this stage (the newer ones stay in flight), 4 k-steps of MFMAs
+    auto stage_step = [&](int kc) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot about to be refilled has been read
-        if (s + STAGES - 1 < nstages) {
-            issue(s + STAGES - 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (STAGES - 1)) : "memory");   // stage s landed; newer ones stay in flight
+        if (issued < nstages) {
+            issue_next();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (STAGES - 1)) : "memory");   // this stage landed; newer ones stay in flight
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const unsigned char* st = ring + (int)(s % STAGES) * STAGE_BYTES;
+        const unsigned char* st = ring + slot_read * STAGE_BYTES;
+        slot_read = slot_read + 1 == STAGES ? 0 : slot_read + 1;
 #pragma unroll
         for (int ks = 0; ks < KSTAGE / 16; ++ks) {
             const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(st + l31 * 128 + (((2 * ks + lh) ^ sw) * 16));
@@ -252,17 +273,19 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
                 }
         }
     };
+    long t_read = gw;
     if (KCH > 0) {
-        for (long ti = 0; ti < my_tiles; ++ti) {
+        for (int ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
-            for (int kc = 0; kc < (KCH > 0 ? KCH : 1); ++kc) stage_step(ti * KCH + kc, kc);
-            tile_done(gw + ti * GW);
+            for (int kc = 0; kc < (KCH > 0 ? KCH : 1); ++kc) stage_step(kc);
+            tile_done(t_read);
+            t_read += GW;
         }
     } else {
-        for (long s = 0; s < nstages; ++s) {
-            const int kc = (int)(s % kchunks);
-            stage_step(s, kc);
-            if (kc == kchunks - 1) tile_done(gw + (s / kchunks) * GW);
+        int kc = 0;
+        for (int s = 0; s < nstages; ++s) {
+            stage_step(kc);
+            if (++kc == kchunks) { kc = 0; tile_done(t_read); t_read += GW; }
         }
     }
     if (FILTER) flush();
