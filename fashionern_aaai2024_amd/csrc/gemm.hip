@@ -214,7 +214,14 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
     const int nwg = nbm * nbn;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int bm = swz / nbn, bn = swz % nbn;
+    int bm = swz / nbn, bn = swz % nbn;
+#ifdef FERN_GEMM_TRACE
+    if (const int sw = p.packed >> 8) {        // probe: column stripes of `sw` tiles, rows fastest across a stripe's columns
+        const int stripe = sw * nbm, nfull = nbn / sw;
+        if (swz < nfull * stripe) { const int r = swz % stripe; bm = r / sw; bn = (swz / stripe) * sw + r % sw; }
+        else { const int r = swz - nfull * stripe, w = nbn - nfull * sw; bm = r / w; bn = nfull * sw + r % w; }
+    }
+#endif
 
     // per-lane source row pointers (already offset by the swizzled 16-byte chunk) for this wave's pieces
     const float* src[PPW];
@@ -238,7 +245,7 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
             } else {
                 src[j] = p.A + (long)row * p.lda + chunk * 4 + kbeg;
 #ifdef FERN_GEMM_TRACE
-                if (p.packed) src[j] = p.A + (long)row * 16 + chunk * 4;
+                if (p.packed & 1) src[j] = p.A + (long)row * 16 + chunk * 4;
 #endif
             }
         } else {
@@ -246,7 +253,7 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
             row = row < p.N ? row : p.N - 1;
             src[j] = p.W + sample_row(row, p.w_sample) * p.ldw + chunk * 4 + kbeg;
 #ifdef FERN_GEMM_TRACE
-            if (p.packed) src[j] = p.W + (long)row * 16 + chunk * 4;
+            if (p.packed & 1) src[j] = p.W + (long)row * 16 + chunk * 4;
 #endif
         }
     }
@@ -264,7 +271,7 @@ __device__ __forceinline__ void glds_tile(GemmParams p, const int bid, float* sm
             if (PIECES % NW != 0 && piece >= PIECES) continue;   // wave-uniform: this wave has no j-th piece (tile rows do not divide over the waves)
             const float* g = src[j] + k0;
 #ifdef FERN_GEMM_TRACE
-            if (p.packed) g = src[j] + (long)(k0 / 16) * 16 * (piece * RPP < BM ? p.M : p.N);
+            if (p.packed & 1) g = src[j] + (long)(k0 / 16) * 16 * (piece * RPP < BM ? p.M : p.N);
 #endif
             if (CONV && piece * RPP < BM) {                    // wave-uniform: this piece holds A (activation) rows
                 const int yy = cy[j] + ky, xx = cx[j] + kx;

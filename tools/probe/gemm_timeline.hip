@@ -17,7 +17,7 @@ int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 12608, N = argc > 2 ? atoi(argv[2]) : 2304, K = argc > 3 ? atoi(argv[3]) : 768;
     const int cfg = argc > 4 ? atoi(argv[4]) : 8, epi = argc > 5 ? atoi(argv[5]) : EPI_BIAS;
     const char* out = argc > 6 ? argv[6] : "gemm_timeline.csv";
-    const int packed = argc > 7 ? atoi(argv[7]) : 0;      // 1: operands k-slab-major (timing experiment; results are then garbage)
+    const int packed = argc > 7 ? atoi(argv[7]) : 0;      // bit 0: operands k-slab-major (timing experiment; results are then garbage); bits 8+: tile order in column stripes of that many tiles
     const int ksplit = argc > 8 ? atoi(argv[8]) : 1;      // > 1: split-K slices (raw partial sums to a scratch buffer; the reduce pass is not timed here)
     float *A, *W, *C, *bias;
     hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&W, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4); hipMalloc(&bias, (size_t)N * 4);
