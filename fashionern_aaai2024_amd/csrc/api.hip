@@ -1800,6 +1800,15 @@ extern "C" int fern_tuner_import(const char* text) {
     return FERN_OK;
 }
 
+// How many batches the caller keeps in flight on separate streams (process-wide, like the tile choices themselves): the
+// reduced-precision GEMM families then score a trial by duration x (share of the chip it fills)^0.75 instead of duration alone.
+// Set before the first launch of a shape; shapes already tuned keep their choice.  Never changes a result.
+extern "C" int fern_tuner_set_concurrency(int lanes) {
+    if (lanes < 1) return fail(FERN_ERR_ARG, "fern_tuner_set_concurrency: lanes must be >= 1");
+    gemm_bf16_tuner_set_concurrency(lanes);
+    return FERN_OK;
+}
+
 extern "C" int fern_prof_enable(fern_ctx* c, int on) {
     if (!c) return fail(FERN_ERR_ARG, "fern_prof_enable: ctx is NULL");
     c->prof_on = on != 0;

@@ -13,6 +13,8 @@
 // results and a row's result does not depend on the batch it is part of.
 #include "gemm_epilogue.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -378,17 +380,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
         }
 }
 
-struct TileCfgB { int bm, bn, bk; };
+struct TileCfgB { int bm, bn, bk, per_cu; };     // per_cu: workgroups of the configuration one CU holds (LDS / registers / waves)
 // The tuner's candidates.  Retired after A/B runs on MI355X: 3- and 4-stage rings of the 128x128 tile and
 // 128x64 / 128x128 per-wave tiles -- fewer resident workgroups cost more than the deeper prefetch or the saved LDS reads gain.
 static const TileCfgB kCfgsB[] = {
-    {128, 128, 32},   // 0: 4 waves of 64x64, 64-byte rows, 2 stages, 4 workgroups per CU
-    {256, 128, 32},   // 1: 8 waves of 64x64, 3 stages
-    {256, 256, 32},   // 2: 16 waves of 64x64, 3 stages
-    {64, 128, 32},    // 3: 4 waves of 32x64, 2 stages
-    {128, 64, 32},    // 4: 4 waves of 64x32, 2 stages
-    {64, 64, 32},     // 5: 4 waves of 32x32, 2 stages
-    {128, 128, 64},   // 6: as 0 with 128-byte rows (64-element k tiles): whole 128-byte lines per request, half the barriers, 2 per CU
+    {128, 128, 32, 4},   // 0: 4 waves of 64x64, 64-byte rows, 2 stages, 4 workgroups per CU
+    {256, 128, 32, 2},   // 1: 8 waves of 64x64, 3 stages
+    {256, 256, 32, 1},   // 2: 16 waves of 64x64, 3 stages
+    {64, 128, 32, 4},    // 3: 4 waves of 32x64, 2 stages
+    {128, 64, 32, 4},    // 4: 4 waves of 64x32, 2 stages
+    {64, 64, 32, 8},     // 5: 4 waves of 32x32, 2 stages
+    {128, 128, 64, 2},   // 6: as 0 with 128-byte rows (64-element k tiles): whole 128-byte lines per request, half the barriers, 2 per CU
 };
 constexpr int kNumCfgsB = 7;
 
@@ -408,7 +410,7 @@ static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
 }
 
 // fp8 tile family (k tile = 64 elements = 64-byte rows, 2 stages): same block shapes as the bf16 candidates
-static const TileCfgB kCfgsF8[] = {{128, 128, 64}, {256, 128, 64}, {256, 256, 64}, {64, 128, 64}, {128, 64, 64}, {64, 64, 64}};
+static const TileCfgB kCfgsF8[] = {{128, 128, 64, 4}, {256, 128, 64, 2}, {256, 256, 64, 1}, {64, 128, 64, 4}, {128, 64, 64, 4}, {64, 64, 64, 8}};
 constexpr int kNumCfgsF8 = 6;
 static hipError_t launch_cfg_f8(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsF8[c].bm - 1) / kCfgsF8[c].bm) * ((p.N + kCfgsF8[c].bn - 1) / kCfgsF8[c].bn);
@@ -426,17 +428,17 @@ static hipError_t launch_cfg_f8(int c, const GemmParams& p, hipStream_t s) {
 
 // MX tile family (k tile = 128 bytes).  LDS per stage = (bm + bn) * 132 bytes.
 static const TileCfgB kCfgsMx[] = {
-    {128, 128, 128},   // 0: 4 waves of 64x64, 2 stages (66 KiB: 2 workgroups per CU)
-    {256, 128, 128},   // 1: 8 waves of 64x64, 2 stages (99 KiB)
-    {256, 128, 128},   // 2: 4 waves of 128x64, 2 stages: 12 LDS reads per 8 MFMAs instead of 8 per 4
-    {128, 128, 128},   // 3: as 0 with a 3-stage ring (99 KiB)
-    {64, 128, 128},    // 4: 4 waves of 32x64
-    {128, 64, 128},    // 5: 4 waves of 64x32
-    {64, 64, 128},     // 6: 4 waves of 32x32
-    {256, 256, 128},   // 7: 16 waves of 64x64, 2 stages (132 KiB)
-    {128, 128, 64},    // 8: as 0 with 64-byte rows (one MFMA step per barrier), 3 stages: 50 KiB, 3 workgroups per CU
-    {256, 128, 64},    // 9: as 1 with 64-byte rows, 3 stages: 75 KiB, 2 workgroups per CU (needs <= 128 VGPRs)
-    {256, 256, 64},    // 10: 8 waves of 128x64, 64-byte rows, 4 stages (136 KiB): fewest staged bytes per FLOP, deep prefetch instead of occupancy
+    {128, 128, 128, 2},   // 0: 4 waves of 64x64, 2 stages (66 KiB: 2 workgroups per CU)
+    {256, 128, 128, 1},   // 1: 8 waves of 64x64, 2 stages (99 KiB)
+    {256, 128, 128, 1},   // 2: 4 waves of 128x64, 2 stages: 12 LDS reads per 8 MFMAs instead of 8 per 4
+    {128, 128, 128, 1},   // 3: as 0 with a 3-stage ring (99 KiB)
+    {64, 128, 128, 3},    // 4: 4 waves of 32x64
+    {128, 64, 128, 3},    // 5: 4 waves of 64x32
+    {64, 64, 128, 4},     // 6: 4 waves of 32x32
+    {256, 256, 128, 1},   // 7: 16 waves of 64x64, 2 stages (132 KiB)
+    {128, 128, 64, 3},    // 8: as 0 with 64-byte rows (one MFMA step per barrier), 3 stages: 50 KiB, 3 workgroups per CU
+    {256, 128, 64, 2},    // 9: as 1 with 64-byte rows, 3 stages: 75 KiB, 2 workgroups per CU (needs <= 128 VGPRs)
+    {256, 256, 64, 1},    // 10: 8 waves of 128x64, 64-byte rows, 4 stages (136 KiB): fewest staged bytes per FLOP, deep prefetch instead of occupancy
 };
 constexpr int kNumCfgsMx = 11;
 static hipError_t launch_cfg_mx(int c, const GemmParams& p, hipStream_t s) {
@@ -480,6 +482,16 @@ struct ShapeKeyB {
 };
 static std::map<ShapeKeyB, int> g_tuned_b;
 static std::mutex g_tuned_b_mu;
+// Launches of other streams expected to run beside one of these GEMMs (fern_tuner_set_concurrency; the query pipeline sets its
+// lane count).  1: a trial's score is its duration.  > 1: duration x (share of the chip's workgroup slots the launch fills)^0.75 --
+// a launch that leaves CUs to its neighbours is worth more to the pipeline than its own latency says.  Measured on the c5 pipeline
+// (3 lanes, tools/c5_tiles_ab.sh): 256x256 tiles for the N = 768 block GEMMs (150 workgroups on 150 CUs) instead of the 1 200
+// small workgroups the latency score picks: 17.7 -> 18.9 k queries/s, although each of those launches takes longer.
+static int g_tune_concurrency = 1;
+void gemm_bf16_tuner_set_concurrency(int n) {
+    std::lock_guard<std::mutex> lock(g_tuned_b_mu);
+    g_tune_concurrency = n < 1 ? 1 : n;
+}
 
 // FERN_GEMM_TILES=<file>: lines "bf16 M N K epi ob cfg" / "fp8 M N K epi ob cfg" / "mx8 M N K epi ob cfg" pin the choices (see gemm.hip)
 static void pin_tile_line_b(const char* line) {      // caller holds g_tuned_b_mu
@@ -571,8 +583,18 @@ static int tune_shape_b(const GemmParams& p, hipStream_t s, bool& tuned) {
         }
     int best = fallback;
     float best_ms = 1e30f;
-    for (int c = 0; c < ncand; ++c)
-        if (t[c] < best_ms) { best_ms = t[c]; best = c; }
+    const TileCfgB* cfgs = p.fp8 == 2 ? kCfgsMx : f8 ? kCfgsF8 : kCfgsB;
+    for (int c = 0; c < ncand; ++c) {
+        if (t[c] > 1e29f) continue;
+        float score = t[c];
+        if (g_tune_concurrency > 1) {      // caller holds g_tuned_b_mu
+            const double nwg = (double)((p.M + cfgs[c].bm - 1) / cfgs[c].bm) * ((p.N + cfgs[c].bn - 1) / cfgs[c].bn);
+            const double share = std::min(1.0, nwg / (256.0 * cfgs[c].per_cu));
+            static const double expo = [] { const char* e = getenv("FERN_TUNE_SHARE_EXP"); return e ? atof(e) : 0.75; }();      // A/B knob (tools/c5_exp_ab.sh: 0 = latency score 17.9-18.3 k queries/s on c5, 0.5 ... 1.5 all 19.2-19.5 k)
+            score *= (float)std::pow(share, expo);
+        }
+        if (score < best_ms) { best_ms = score; best = c; }
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(scratch);

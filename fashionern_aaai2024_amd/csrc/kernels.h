@@ -149,6 +149,8 @@ void gemm_bf16_tuner_export(std::string& out);
 // the reverse: lines of that format replace this process's choices for the listed shapes
 void gemm_tuner_import(const std::string& text);
 void gemm_bf16_tuner_import(const std::string& text);
+// reduced-precision families: score trials for a pipeline that keeps `n` batches in flight on separate streams (gemm_bf16.hip)
+void gemm_bf16_tuner_set_concurrency(int n);
 
 #ifdef __HIPCC__
 // 64-bit ranking keys: orderable(score) << 32 | ~index, so "score descending, index ascending" is one unsigned compare

@@ -458,5 +458,10 @@ class FernEngine:
         """Adopt another process's `tuner_export()` for the shapes it lists (all tile choices are bit-identical: speed only)."""
         _lib.check(self.lib.fern_tuner_import(text.encode()), "fern_tuner_import")
 
+    def tuner_set_concurrency(self, lanes: int) -> None:
+        """Tell the GEMM tuner how many batches are kept in flight on separate streams (include/fern.h:
+        fern_tuner_set_concurrency): shapes tuned afterwards are scored for pipeline throughput, not stand-alone latency."""
+        _lib.check(self.lib.fern_tuner_set_concurrency(int(lanes)), "fern_tuner_set_concurrency")
+
     def sync(self) -> None:
         _lib.check(self.lib.fern_sync(self._h, _stream()), "fern_sync")

@@ -63,6 +63,7 @@ class ComposedQueryPipeline:
             raise ValueError("lanes must be >= 1")
         if engine.clip_cfg is None or engine.feature_dim is None:
             raise RuntimeError("the engine needs finalised CLIP and fusion weights")
+        engine.tuner_set_concurrency(lanes)      # shapes tuned from here on are scored for `lanes` batches in flight
         self.engines: List[FernEngine] = [engine] + [engine.fork() for _ in range(lanes - 1)]
         self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(lanes)]
         self._next = 0

@@ -328,6 +328,12 @@ FERN_API int64_t fern_tuner_export(char* buf, int64_t cap);
  * rank 0's export broadcast to all ranks of a job so that every rank runs the same kernels (the step time of a multi-GPU job is
  * the max over ranks).  Lines that do not parse or name an inapplicable configuration are skipped.  Never changes a result. */
 FERN_API int fern_tuner_import(const char* text);
+/* The number of batches the caller keeps in flight on separate streams (the query pipeline's lanes; process-wide, default 1).
+ * With more than one, the bf16 / fp8 / block-scaled GEMM families score a tile trial by duration x (share of the chip's
+ * workgroup slots the launch fills)^0.75 instead of duration alone: a launch that leaves CUs to the other streams' kernels is worth more
+ * to the pipeline than its own latency says.  Call before the first launch of a shape; tuned shapes keep their
+ * choice.  The fp32 family is not affected.  Never changes a result.  No reference counterpart. */
+FERN_API int fern_tuner_set_concurrency(int lanes);
 
 /* Workspace generation of a context: incremented each time the context frees workspace memory it had handed to kernels before
  * (it consolidates its arena at the start of the next call after one that had to grow it).  A hipGraph captured from calls on

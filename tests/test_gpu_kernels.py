@@ -495,6 +495,33 @@ def test_gemm_mx8(engine, m, n, k, epi, out_bf16):
 
 
 @pytest.mark.gpu
+def test_tuner_concurrency_score_never_changes_a_result(engine):
+    """fern_tuner_set_concurrency(3) makes the reduced-precision families score their tile trials for a 3-lane pipeline (other
+    tiles may win); a row's bits must not depend on that choice, nor on the batch it travels in."""
+    g = torch.Generator().manual_seed(7)
+    k, n = 768, 768
+    a = torch.randn(6400, k, generator=g)
+    w = torch.randn(n, k, generator=g) * k ** -0.5
+    b = torch.randn(n, generator=g)
+    a8, sa = engine.quantize_mx8(a)
+    w8, sw = engine.quantize_mx8(w)
+    ab, wb = engine.to_bf16(a.cuda()), engine.to_bf16(w.cuda())
+    try:
+        engine.tuner_set_concurrency(1)
+        ref_mx = engine.gemm_mx8(a8[:6272], sa[:, :6272].contiguous(), w8, sw, b, epilogue=0, out_bf16=True)
+        ref_bf = engine.gemm_bf16(ab[:6272], wb, b, epilogue=0, out_bf16=True)
+        engine.tuner_set_concurrency(3)
+        got_mx = engine.gemm_mx8(a8, sa, w8, sw, b, epilogue=0, out_bf16=True)           # new shape key: tuned under the new score
+        got_bf = engine.gemm_bf16(ab, wb, b, epilogue=0, out_bf16=True)
+    finally:
+        engine.tuner_set_concurrency(1)                                                   # process-wide setting
+    assert torch.equal(got_mx[:6272].view(torch.int16), ref_mx.view(torch.int16))
+    assert torch.equal(got_bf[:6272].view(torch.int16), ref_bf.view(torch.int16))
+    with pytest.raises(RuntimeError):
+        engine.tuner_set_concurrency(0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("var,cfg", [("FERN_GEMM_BF16_CFG", c) for c in range(7)] + [("FERN_GEMM_FP8_CFG", c) for c in range(6)] +
                          [("FERN_GEMM_MX8_CFG", c) for c in range(11)])
 def test_every_reduced_precision_gemm_tile_variant(var, cfg):

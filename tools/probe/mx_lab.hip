@@ -352,8 +352,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void mx8q_kernel(
         if (op < PPW) {
             const int piece = wave + NW * op;
             const char* base = (piece * RPP < BM ? Abase : Wbase) + (long)kt * RB;          // wave-uniform
+#ifdef LAB_SADDR
+            // scalar base + 32-bit lane offset form of the same instruction (the builtin selects the 64-bit vector address form)
+            const unsigned ldsa = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + buf * TILE + piece * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(ldsa), "v"(src[op]), "s"(base) : "memory");
+#else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + src[op]),
                                              (__attribute__((address_space(3))) void*)(smem + buf * TILE + piece * 1024), 16, 0, 0);
+#endif
         } else {
             const int j = op - PPW;
             const int sp = (wave + NW * j) % SP;
