@@ -653,9 +653,13 @@ static const TileCfg kCfgs[] = {
     {64, 64, 16, 0.86f},     // 11
     {256, 128, 16, 1.00f},   // 12: 8 waves, 256x128 macro-tile (0.75x the L2->LDS bytes per flop of 128x128), 2 workgroups per CU
     {128, 256, 16, 1.00f},   // 13
+    // column counts that are not multiples of 64 (the ModifiedResNet's 80 / 160 / 320-channel layers: a 64- or 128-wide tile spends
+    // 37.5 % / 17 % of its MFMAs on padding columns): four waves stacked over the rows, each 32 rows x the whole tile width
+    {128, 96, 16, 1.00f},    // 14: wave tile 32x96
+    {128, 160, 16, 1.00f},   // 15: wave tile 32x160
 };
 constexpr int kNumAuto = 4;      // configs the heuristic may pick
-constexpr int kNumCfgs = 14;
+constexpr int kNumCfgs = 16;
 
 static int forced_cfg() {
     static int v = [] {
@@ -712,6 +716,8 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
             case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
             case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
             case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 14: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 96, 32, 96, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 15: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 160, 32, 160, 16, 3, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -728,6 +734,8 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
         case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
         case 12: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
         case 13: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 256, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
+        case 14: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 96, 32, 96, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 15: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 160, 32, 160, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -952,7 +960,7 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
         (void)hipEventElapsedTime(&ms, e0, e1);
         return ms;
     };
-    static const int cands[] = {0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13};
+    static const int cands[] = {0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13, 14, 15};
     // {bulk cfg, remainder cfg, tiles per round}: the bulk covers the rows whose tiles fill whole rounds of the chip -- 256 = one tile
     // per CU; the 8-wave macro-tiles keep two workgroups per CU, so a round of 512 gives every CU an even number of them
     static const int pairs[][3] = {{8, 11, 256}, {8, 9, 256}, {9, 11, 256}, {10, 11, 256}, {12, 8, 256}, {12, 8, 512}, {12, 11, 256}, {12, 11, 512},
@@ -968,7 +976,11 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
         for (int i = 0; i < NC; ++i) {
             const int c = cands[i];
             if (c == 6 && !skinny_ok(p)) continue;
-            if (c >= 12 && (p.epi == EPI_TOPK_FILTER || p.aload != ALOAD_PLAIN || p.M < 2048)) continue;      // macro-tiles: plain loader, stored outputs, deep matrices
+            if ((c == 12 || c == 13) && (p.epi == EPI_TOPK_FILTER || p.aload != ALOAD_PLAIN || p.M < 2048)) continue;      // macro-tiles: plain loader, stored outputs, deep matrices
+            if (c >= 14) {      // odd-width tiles: only where they pad fewer columns than the 64-wide tiles do (N = 80: 96 < 128) or as many with a wider tile (N = 160, 320)
+                const int pad64 = (p.N + 63) / 64 * 64, padc = (p.N + kCfgs[c].bn - 1) / kCfgs[c].bn * kCfgs[c].bn;
+                if (p.epi == EPI_TOPK_FILTER || epi_is_reduce(p.epi) || p.M < 1024 || (c == 14 ? padc >= pad64 : padc > pad64)) continue;
+            }
             if (c < 8 && p.epi == EPI_TOPK_FILTER) continue;
             if (c >= 8 && p.aload == ALOAD_IM2COL) continue;
             if (c < 8 && p.aload == ALOAD_CONV3) continue;
@@ -1140,7 +1152,8 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     }
     if (c == 6 && !skinny_ok(p)) c = (p.K & 31) ? best_of(p.M, p.N, 8, 12) : best_of(p.M, p.N, 0, kNumAuto);   // forced but not applicable
     if (c != 6 && forced_cfg() < 0 && !tunable && p.M <= 64 && p.N >= 256 && skinny_ok(p)) c = 6;     // untuned small-M GEMMs
-    if ((p.aload == ALOAD_CONV3 || p.epi == EPI_TOPK_FILTER) && (c < 8 || c > 11)) c = 8 + (c & 3);     // 3x3 window / filtered sweep: LDS-DMA family only
+    if (p.epi == EPI_TOPK_FILTER && (c < 8 || c > 11)) c = 8 + (c & 3);     // filtered sweep: the four LDS-DMA tiles only
+    if (p.aload == ALOAD_CONV3 && (c < 8 || c == 12 || c == 13)) c = 8 + (c & 3);     // 3x3 window: LDS-DMA family without the macro-tiles
     if (c >= 8 && p.aload == ALOAD_IM2COL) c &= 3;                        // patch loader: register-staged family only
     return launch_cfg(c, p, s);
 }

@@ -216,7 +216,7 @@ def test_topk_large_gallery_many_segments(engine):
     assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13, 14, 15])
 def test_every_gemm_tile_variant_passes_the_shape_suite(cfg):
     """The launcher autotunes the tile per shape, so each variant is also forced (FERN_GEMM_CFG, read once per process) over
     the whole GEMM shape / epilogue suite, incl. the integer-exactness test: all variants must agree bit for bit."""
@@ -556,6 +556,26 @@ def test_reduced_precision_gemms_are_batch_invariant(engine):
         assert torch.equal(engine.gemm_mx8(am[lo:hi].contiguous(), sam[:, lo:hi].contiguous(), wq, swm, b, epilogue=0).cpu(), fullm[lo:hi])
         assert torch.equal(engine.gemm_bf16(ab[lo:hi].contiguous(), wb, b, epilogue=1, out_bf16=True).cpu(), full[lo:hi])
         assert torch.equal(engine.gemm_fp8(a8[lo:hi].contiguous(), sa[lo:hi].contiguous(), w8, sw, b, epilogue=0).cpu(), full8[lo:hi])
+
+
+@pytest.mark.gpu
+def test_resnet_tower_is_bit_identical_on_every_lds_dma_tile(tmp_path):
+    """The ModifiedResNet's convolutions (3x3-window loader and 1x1, 80 / 160 / 320 / ... output channels) through the 128x128 tile
+    and through the odd-width tiles built for those channel counts (configs 14: 128x96, 15: 128x160): identical features."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for cfg in ("8", "14", "15"):
+        path = str(tmp_path / f"rn_{cfg}.npy")
+        env = dict(os.environ, FERN_GEMM_CFG=cfg)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_resnet_dump.py"), path], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    for other in outs[1:]:
+        assert np.array_equal(outs[0].view(np.uint32), other.view(np.uint32))
 
 
 @pytest.mark.gpu
