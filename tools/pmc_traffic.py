@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Turn two `rocprofv3 --pmc` passes of `bench.py --pmc-mode` (one with FETCH_SIZE, one with WRITE_SIZE) into
 profiles/pmc_traffic.json: HBM-side bytes per launch for the fp32 GEMM family and per call for the ranking stage
-(sample GEMM + bound + filtered sweep + candidate select + the gated retry pair).
+(sample GEMM + bound + filtered sweep + candidate select + the gated exact pass).
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE reports exactly 1/2 of
 the bytes of a wide coalesced streaming read (TCC_EA0_RDREQ x 64 B with 128-B requests tallied at 64 B) -> doubled;
@@ -25,8 +25,8 @@ def per_dispatch(path, counter):
     return rows[marker + 1:]
 
 
-def is_filter_gemm(name):      # gemm_f32_glds_kernel<BM, BN, WM, WN, BKT, MINW, CONV, SYNC, FILT = true>
-    return "gemm_f32_glds_kernel" in name and re.search(r",\s*true>", name) is not None
+def is_filter_gemm(name):      # gemm_f32_glds_kernel<BM, BN, WM, WN, BKT, MINW, CONV, SYNC, FILT = true, SPLIT>
+    return re.search(r"gemm_f32_glds_kernel<(\d+,\s*){6}(true|false),\s*\d+,\s*true\b", name) is not None
 
 
 def summarise(rows, scale):
@@ -38,7 +38,7 @@ def summarise(rows, scale):
                 rank_ids.add(rows[i - 1][0])                      # the sample pass: the GEMM right before the bound kernel
             seen = 0
             for nxt in rows[i + 1:i + 6]:                          # filtered sweep, select, gated sweep, gated select
-                if is_filter_gemm(nxt[1]) or "topk_candidates_kernel" in nxt[1]:
+                if is_filter_gemm(nxt[1]) or "topk_candidates_kernel" in nxt[1] or "rank_exact_kernel" in nxt[1]:
                     rank_ids.add(nxt[0])
                     if is_filter_gemm(nxt[1]) and seen == 0:
                         sweep_ids.add(nxt[0])
@@ -66,7 +66,7 @@ def main():
                   "stage_write_bytes_per_call": write["rank_bytes"] / max(1, write["rank_calls"]),
                   "sweep_kernel_fetch_bytes": fetch["sweep_bytes"] / calls,
                   "sweep_kernel_write_bytes": write["sweep_bytes"] / max(1, write["rank_calls"]),
-                  "note": "stage = sample GEMM + bound + filtered sweep + candidate select + gated retry pair of one fern_sim_topk call; the "
+                  "note": "stage = sample GEMM + bound + filtered sweep + candidate select + gated exact pass of one fern_sim_topk call; the "
                           "[B, N] score matrix (B*N*4 bytes) is never written: the stage's writes are the sample scores, the surviving "
                           "candidates and the [B, K] result"},
         "note": "FETCH_SIZE counts L2->fabric read requests (Infinity-Cache hits included), i.e. the sum over the 8 private XCD L2s: every XCD "

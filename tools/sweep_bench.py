@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Ranking-stage roofline: fused sweep + top-K (sample pass, bound, filtered sweep, selection, gated retry pair) against
+"""Ranking-stage roofline: fused sweep + top-K (sample pass, bound, filtered sweep, selection, gated exact pass) against
 SURVEY 8d's algorithmic bytes N*D*s_g + B*D*4 + B*K*8, for an fp32 gallery (MFMA-bound at B = 64) and a bf16 gallery
 (HBM-bound), per gallery size.  Whole-call time from HIP events on the stream; the sweep kernel alone from libfern's profiler."""
 import os
@@ -40,5 +40,5 @@ for B in (64, 128):
             sel_us = st["topk_ms"] / 10 * 1e3
             alg = n * D * sg + B * D * 4 + B * K * 8
             print(f"B={B:4d} N={n:8d} {name}: call {call_us:8.1f} us = {alg / call_us / 1e3:6.0f} GB/s algorithmic ({alg / call_us / 1e3 / 8000:.3f} of 8 TB/s) | "
-                  f"sweep kernel(s) {sweep_us:8.1f} us x{nsweep:.0f}, sample + bound + select + retry pair {sel_us:7.1f} us (instrumented)", flush=True)
+                  f"sweep kernel(s) {sweep_us:8.1f} us x{nsweep:.0f}, sample + bound + select + exact pass {sel_us:7.1f} us (instrumented)", flush=True)
         del g, gb
