@@ -356,23 +356,38 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(AttnParams p) {
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st, 0, 0, 0);
             }
             float mt = -INFINITY;
+            if (CAUSAL || (t + 1) * 32 > p.s_k) {            // only the last key tile (or a causal one) has keys to mask: wave-uniform
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const bool ok = key < p.s_k && (!CAUSAL || key <= qi);
-                st[r] = ok ? st[r] * p.scale : -INFINITY;
-                mt = fmaxf(mt, st[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const bool ok = key < p.s_k && (!CAUSAL || key <= qi);
+                    st[r] = ok ? st[r] * p.scale : -INFINITY;
+                    mt = fmaxf(mt, st[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[r] *= p.scale;
+                    mt = fmaxf(mt, st[r]);
+                }
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float m_new = fmaxf(m, mt);
             const float alpha = __expf(m - m_new);
             float ps = 0.0f;
             bf16x8 pf[2];
+            {
+                unsigned pw[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __expf(st[r] - m_new);
-                ps += e;                                   // the normaliser sums the un-rounded weights
-                pf[r >> 3][r & 7] = (short)f32_to_bf16_bits(e);
+                for (int r = 0; r < 16; r += 2) {
+                    const float e0 = __expf(st[r] - m_new), e1 = __expf(st[r + 1] - m_new);
+                    ps += e0;                              // the normaliser sums the un-rounded weights (same order as one by one)
+                    ps += e1;
+                    pw[r >> 1] = f32x2_to_bf16x2_bits(e0, e1);
+                }
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                pf[0] = __builtin_bit_cast(bf16x8, u32x4_t{pw[0], pw[1], pw[2], pw[3]});
+                pf[1] = __builtin_bit_cast(bf16x8, u32x4_t{pw[4], pw[5], pw[6], pw[7]});
             }
             sum = sum * alpha + ps;
             m = m_new;

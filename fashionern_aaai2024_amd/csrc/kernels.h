@@ -222,10 +222,13 @@ __device__ __forceinline__ unsigned mx_scale_byte(float amax) {
     return (unsigned)min(max(e, 1), 253);
 }
 __device__ __forceinline__ float mx_inv_scale(unsigned e) { return __uint_as_float((254u - e) << 23); }
-__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {   // round to nearest even (finite inputs)
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+// fp32 -> bf16, round to nearest even: v_cvt_pk_bf16_f32 (one instruction per PAIR of values on gfx950; the integer form
+// u += 0x7fff + ((u >> 16) & 1) it replaces is three per value and gives the same bits for every finite input)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned f32x2_to_bf16x2_bits(float lo, float hi) {      // lo in bits 0-15
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 #endif
 

@@ -25,11 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
-__device__ __forceinline__ u16 f32_to_bf16_rne(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);      // round to nearest even (inputs are finite cosine features)
-    return (u16)(u >> 16);
-}
+__device__ __forceinline__ u16 f32_to_bf16_rne(float f) { return f32_to_bf16_bits(f); }      // round to nearest even (kernels.h)
 
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* x, u16* y, long n4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
