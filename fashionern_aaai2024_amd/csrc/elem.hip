@@ -561,6 +561,61 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* img, const 
     *reinterpret_cast<f32x4*>(out + pix * cout + c4 * 4) = acc;
 }
 
+// The same convolution with one thread = one output pixel x ALL output channels (C4N groups of 4): the 27 image taps are loaded once
+// per pixel instead of once per channel group, the weights come from an LDS image laid out [tap][channel] (one broadcast
+// ds_read_b128 per tap and channel group), and a thread stores its pixel's whole channel vector contiguously.  Each output is the
+// same fma chain (bias, then taps in (c, ky, kx) order): bit-identical to the kernel above.
+template <int C4N>
+__global__ __launch_bounds__(256) void stem_conv_px_kernel(const float* img, const float* w, const float* bias, float* out, int B, int S) {
+    constexpr int COUT = 4 * C4N;
+    __shared__ f32x4 ws[27][C4N];
+    for (int i = threadIdx.x; i < 27 * COUT; i += 256) {
+        const int k = i / COUT, co = i % COUT;
+        reinterpret_cast<float*>(&ws[0][0])[i] = w[co * 27 + k];
+    }
+    __syncthreads();
+    const int So = S / 2;
+    const long total = (long)B * So * So;
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= total) return;
+    const int x = (int)(pix % So), y = (int)((pix / So) % So), b = (int)(pix / ((long)So * So));
+    f32x4 acc[C4N];
+#pragma unroll
+    for (int c4 = 0; c4 < C4N; ++c4) acc[c4] = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
+    float v[27];      // the pixel's taps, all requested before the first is used
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = 2 * y + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = 2 * x + kx - 1;
+                float t = 0.f;
+                if (yy >= 0 && yy < S && xx >= 0 && xx < S) t = img[(((long)b * 3 + c) * S + yy) * S + xx];
+                v[(c * 3 + ky) * 3 + kx] = t;
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+#pragma unroll
+        for (int c4 = 0; c4 < C4N; ++c4) {
+            const f32x4 wv = ws[k][c4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c4][e] = fmaf(v[k], wv[e], acc[c4][e]);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one tap's weight reads at a time (unfenced, all 270 are hoisted and spill)
+    }
+    float* o = out + pix * COUT;
+#pragma unroll
+    for (int c4 = 0; c4 < C4N; ++c4) {
+        f32x4 r = acc[c4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+        *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const float* x, float* y, int B, int H, int W, int C, int k) {
     const int Ho = H / k, Wo = W / k, c4n = C / 4;
     const long total = (long)B * Ho * Wo * c4n;
@@ -748,6 +803,11 @@ hipError_t launch_sr_finalize(const float* partial, int nb, const float* bc, con
 hipError_t launch_stem_conv(const float* img, const float* w, const float* bias, float* out, int B, int S, int cout_pad, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if ((S & 1) || (cout_pad & 3)) return hipErrorInvalidValue;
+    if (cout_pad == 48) {      // RN50x4's stem width (40 channels, padded to the next conv's k granularity): all channels of a pixel in one thread
+        const long npix = (long)B * (S / 2) * (S / 2);
+        hipLaunchKernelGGL(stem_conv_px_kernel<12>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, img, w, bias, out, B, S);
+        return hipGetLastError();
+    }
     const long total = (long)B * (S / 2) * (S / 2) * (cout_pad / 4);
     hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, w, bias, out, B, S, cout_pad);
     return hipGetLastError();
