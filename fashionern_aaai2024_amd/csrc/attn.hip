@@ -93,12 +93,17 @@ __global__ __launch_bounds__(NW * 64) void attn_f32_kernel(AttnParams p) {
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[kk][e], st, 0, 0, 0);
             }
             float mt = -INFINITY;
+            if (CAUSAL || (t + 1) * 32 > p.s_k) {            // only the last key tile (or a causal one) has keys to mask: wave-uniform
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const bool ok = key < p.s_k && (!CAUSAL || key <= qi);
-                st[r] = ok ? st[r] : -INFINITY;
-                mt = fmaxf(mt, st[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const bool ok = key < p.s_k && (!CAUSAL || key <= qi);
+                    st[r] = ok ? st[r] : -INFINITY;
+                    mt = fmaxf(mt, st[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[r]);
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float m_new = fmaxf(m, mt);      // finite from tile 0 on: key 0 is valid for every query
@@ -233,11 +238,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_f32_chunked_kernel(AttnParams
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[kk][e], st, 0, 0, 0);
             }
             float mt = -INFINITY;
+            if ((c * CT + t + 1) * 32 > p.s_k) {             // only the last key tile has keys to mask: wave-uniform
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = (c * CT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                st[r] = key < p.s_k ? st[r] : -INFINITY;
-                mt = fmaxf(mt, st[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = (c * CT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    st[r] = key < p.s_k ? st[r] : -INFINITY;
+                    mt = fmaxf(mt, st[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[r]);
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float m_new = fmaxf(m, mt);
