@@ -426,17 +426,24 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* text, co
     row_store(r, X + row * d, d, lane);
 }
 
-// eot[b] = first position of the maximum token id (torch.argmax semantics on the reference's EOT pooling)
-__global__ void text_eot_kernel(const int64_t* text, int* eot, int B, int T) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// eot[b] = first position of the maximum token id (torch.argmax semantics on the reference's EOT pooling).  One wave per caption:
+// a single thread walking the 77 tokens is a chain of 77 dependent memory round trips (20 us for a kernel that moves 40 KB).
+__global__ __launch_bounds__(256) void text_eot_kernel(const int64_t* text, int* eot, int B, int T) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
-    long best = text[(long)b * T];
-    int pos = 0;
-    for (int s = 1; s < T; ++s) {
-        const long v = text[(long)b * T + s];
+    long long best = -0x7fffffffffffffffLL - 1;
+    int pos = 0x7fffffff;
+    for (int s = lane; s < T; s += 64) {      // ascending positions per lane: a lane keeps its first maximum
+        const long long v = text[(long)b * T + s];
         if (v > best) { best = v; pos = s; }
     }
-    eot[b] = pos;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const long long ob = __shfl_xor(best, off);
+        const int op = __shfl_xor(pos, off);
+        if (ob > best || (ob == best && op < pos)) { best = ob; pos = op; }
+    }
+    if (lane == 0) eot[b] = pos;
 }
 
 __global__ __launch_bounds__(256) void vit_cls_kernel(const float* cls, const float* pos, float* X, int B, int tokens, int d) {
@@ -778,7 +785,7 @@ hipError_t launch_text_embed(const int64_t* text, const float* tok_emb, const fl
     if (B <= 0) return hipSuccess;
     if (bad_width(d)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(text_embed_kernel, row_grid((long)B * T), dim3(256), 0, s, text, tok_emb, pos_emb, X, B, T, d, vocab, bad_flag);
-    hipLaunchKernelGGL(text_eot_kernel, dim3((B + 63) / 64), dim3(64), 0, s, text, eot, B, T);
+    hipLaunchKernelGGL(text_eot_kernel, dim3((B + 3) / 4), dim3(256), 0, s, text, eot, B, T);
     return hipGetLastError();
 }
 hipError_t launch_vit_cls(const float* cls, const float* pos, float* X, int B, int tokens, int d, hipStream_t s) {
