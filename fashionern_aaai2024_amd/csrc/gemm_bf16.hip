@@ -327,7 +327,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
     if (!p.out_mx8) {
-        gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N, true>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
+        gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N, true, 2, false>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
         return;
     }
     // Quantising epilogue: bias (+ GELU) in the accumulator layout (lane = column), then each 32x32 tile is turned through a
@@ -350,9 +350,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 f32x2 v2 = {acc[i][j][r] + bia, acc[i][j][r + 1] + bia};
-                if (p.epi == EPI_BIAS_GELU) v2 = gelu_fast2(v2);
+                if (p.epi == EPI_BIAS_GELU) v2 = gelu_tanh2(v2);      // the family's GELU (gemm_epilogue.h): same values as the stored epilogues
                 patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PS + l31] = v2[0];
                 patch[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh) * PS + l31] = v2[1];
+                __builtin_amdgcn_sched_barrier(0);      // one pair at a time (register budget of the 128-VGPR configurations)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the wave's own LDS writes, then its reads
             f32x4 v4[4];

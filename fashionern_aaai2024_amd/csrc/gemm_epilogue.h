@@ -58,11 +58,34 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
     return x * 0.5f * cdf2;
 }
 
+// GELU of the BLOCK-SCALED fp8 GEMM family (outputs are e4m3 bytes, or feed operands that will be): the tanh form written as
+// x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3) -- one exp2 and one reciprocal per element, ~6.5 issue slots against ~12.5 for
+// gelu_fast2.  |gelu_tanh - exact| <= 4.8e-4 (at |x| ~ 2.2): far below the 2^-4 relative step of an e4m3 value, NOT below fp32 or bf16
+// rounding, so no other family uses it.  The c_fc launch of that mode is bound by its epilogue's vector instructions (tools/probe/
+// mx_lab.hip: 9.0 -> 6.8 us per 256x256 tile, the launch -10 %).  exp2 overflow (x << 0) gives 1/inf = 0 and underflow x * 1: both limits.
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
+    const f32x2 x2 = x * x;
+    const f32x2 t = x2 * (-2.0f * 0.7978845608f * 0.044715f * 1.4426950409f) + (-2.0f * 0.7978845608f * 1.4426950409f);
+    const f32x2 w = t * x;                                   // -2u log2(e)
+    const f32x2 e = {__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};
+    const f32x2 d = e + 1.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return x * r;
+}
+// FAST (template parameter of the epilogues below): 0 = gelu_erf2 (fp32 parity mode), 1 = gelu_fast2 (bf16 / per-row fp8 families),
+// 2 = gelu_tanh2 (block-scaled fp8 family)
+template <int FAST>
+__device__ __forceinline__ f32x2 gelu_of(f32x2 x) {
+    if (FAST == 2) return gelu_tanh2(x);
+    if (FAST == 1) return gelu_fast2(x);
+    return gelu_erf2(x);
+}
+
 // One 32x32 accumulator tile.  GUARD = false: the tile lies fully inside the matrix (wave-uniform test by the caller), so
 // there is no per-element predicate at all -- the 16 residual / scale loads issue back to back behind ONE wait, and so do
 // the 16 stores.  (With a predicate per element every load sits in its own exec-masked block and the compiler waits for
 // it -- and for every store before it -- on the spot: 16 serial memory round trips per tile.)
-template <int EPI, bool OUT_BF16, bool SCALED, bool GUARD, bool FAST = false>
+template <int EPI, bool OUT_BF16, bool SCALED, bool GUARD, int FAST = 0>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16& acc, int row0, int col0, int l31, int lrow, int loff) {
     constexpr bool resid = EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_RESIDUAL_RELU;
     const int col = col0 + l31;
@@ -112,9 +135,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16&
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const f32x2 v2 = {SCALED ? acc[r] * qs[r] + bia : acc[r] + bia, SCALED ? acc[r + 1] * qs[r + 1] + bia : acc[r + 1] + bia};
-            const f32x2 g2 = FAST ? gelu_fast2(v2) : gelu_erf2(v2);
+            const f32x2 g2 = gelu_of<FAST>(v2);
             emit(r, g2[0]);
             emit(r + 1, g2[1]);
+            if (FAST == 2) __builtin_amdgcn_sched_barrier(0);      // one pair at a time: interleaved pairs of the two-transcendental form spill at 128 VGPRs
         }
     } else {
 #pragma unroll
@@ -127,7 +151,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16&
 // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 // An element's address = (wave-uniform tile / register-row part, kept in SGPRs) + (lane part: 4 * half rows + column):
 // one 32-bit VGPR offset serves all 16 loads and stores of a tile (ldc < 2^24 on this path, so the lane part fits an int).
-template <int EPI, bool OUT_BF16, bool SCALED, bool FAST = false, int TM, int TN>
+template <int EPI, bool OUT_BF16, bool SCALED, int FAST = 0, int TM, int TN>
 __device__ __forceinline__ void plain_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int row_w, int col_w, int l31, int lh) {
     const int lrow = 4 * lh;
     const int loff = lrow * (int)p.ldc + l31;
@@ -171,33 +195,34 @@ __device__ __forceinline__ void filter_epilogue(const GemmParams& p, f32x16 (&ac
 }
 
 // Shared epilogue of the fp32 and bf16 GEMM kernels (ALLOW_BF16_OUT: only the bf16 kernel stores bf16 outputs).
-template <int BM, int BN, int WM, int WN, int TM, int TN, int WAVES_N, bool ALLOW_BF16_OUT = false>
+template <int BM, int BN, int WM, int WN, int TM, int TN, int WAVES_N, bool ALLOW_BF16_OUT = false, int RGELU = 1 /* GELU of the reduced-precision families: 1 fast, 2 tanh */,
+          bool ALLOW_SCALED = true /* per-row / per-channel fp8 scales folded back here (p.scale_a); the block-scaled family has none and leaves the code out */>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int bm, int bn, int nbn,
                                               int wm, int wn, int l31, int lh, int tid) {
     const int row_w = bm * BM + wm * WM;
     const int col_w = bn * BN + wn * WN;
     if (!epi_is_reduce(p.epi)) {
-        if (ALLOW_BF16_OUT && p.scale_a) {      // fp8 operands: scales folded back here; bias / GELU / residual forms
+        if (ALLOW_BF16_OUT && ALLOW_SCALED && p.scale_a) {      // fp8 operands: scales folded back here; bias / GELU / residual forms
             if (p.out_bf16) {
-                if (p.epi == EPI_BIAS_GELU) plain_epilogue<EPI_BIAS_GELU, true, true, true>(p, acc, row_w, col_w, l31, lh);
+                if (p.epi == EPI_BIAS_GELU) plain_epilogue<EPI_BIAS_GELU, true, true, RGELU>(p, acc, row_w, col_w, l31, lh);
                 else plain_epilogue<EPI_BIAS, true, true>(p, acc, row_w, col_w, l31, lh);
             } else {
                 if (p.epi == EPI_BIAS_RESIDUAL) plain_epilogue<EPI_BIAS_RESIDUAL, false, true>(p, acc, row_w, col_w, l31, lh);
-                else if (p.epi == EPI_BIAS_GELU) plain_epilogue<EPI_BIAS_GELU, false, true, true>(p, acc, row_w, col_w, l31, lh);
+                else if (p.epi == EPI_BIAS_GELU) plain_epilogue<EPI_BIAS_GELU, false, true, RGELU>(p, acc, row_w, col_w, l31, lh);
                 else plain_epilogue<EPI_BIAS, false, true>(p, acc, row_w, col_w, l31, lh);
             }
             return;
         }
         if (ALLOW_BF16_OUT && p.out_bf16) {
             switch (p.epi) {      // bf16 outputs feed the next bf16 GEMM: bias (+ GELU / ReLU) only
-                case EPI_BIAS_GELU: plain_epilogue<EPI_BIAS_GELU, true, false, true>(p, acc, row_w, col_w, l31, lh); break;
+                case EPI_BIAS_GELU: plain_epilogue<EPI_BIAS_GELU, true, false, RGELU>(p, acc, row_w, col_w, l31, lh); break;
                 case EPI_BIAS_RELU: plain_epilogue<EPI_BIAS_RELU, true, false>(p, acc, row_w, col_w, l31, lh); break;
                 default: plain_epilogue<EPI_BIAS, true, false>(p, acc, row_w, col_w, l31, lh); break;
             }
             return;
         }
         switch (p.epi) {
-            case EPI_BIAS_GELU: plain_epilogue<EPI_BIAS_GELU, false, false, ALLOW_BF16_OUT>(p, acc, row_w, col_w, l31, lh); break;
+            case EPI_BIAS_GELU: plain_epilogue<EPI_BIAS_GELU, false, false, ALLOW_BF16_OUT ? RGELU : 0>(p, acc, row_w, col_w, l31, lh); break;
             case EPI_BIAS_RELU: plain_epilogue<EPI_BIAS_RELU, false, false>(p, acc, row_w, col_w, l31, lh); break;
             case EPI_BIAS_RESIDUAL: plain_epilogue<EPI_BIAS_RESIDUAL, false, false>(p, acc, row_w, col_w, l31, lh); break;
             case EPI_BIAS_RESIDUAL_RELU: plain_epilogue<EPI_BIAS_RESIDUAL_RELU, false, false>(p, acc, row_w, col_w, l31, lh); break;

@@ -257,7 +257,7 @@ def test_builtin_clip_bpe_tokenizer_on_a_synthetic_merge_table(tmp_path, monkeyp
 
 def test_gelu_approximations_meet_their_documented_bounds():
     """csrc/gemm_epilogue.h evaluates GELU's erf by Abramowitz & Stegun 7.1.26 (fp32 parity mode: gelu_erf2) and 7.1.28 (reduced-precision
-    GEMM family: gelu_fast2).  Both formulas restated in numpy float32, operation for operation, against exact erf: the header's
+    GEMM family: gelu_fast2); the block-scaled fp8 family uses the tanh form (gelu_tanh2).  The formulas restated in numpy float32, operation for operation, against exact erf: the header's
     bounds (|error| of GELU <= 5e-7 resp. 8.2e-7 on [-12, 12]) hold, tails included (no cancellation for x << 0)."""
     from scipy.special import erf
     f = np.float32
@@ -283,6 +283,13 @@ def test_gelu_approximations_meet_their_documented_bounds():
     r = f(1) / p
     g28 = x * f(0.5) * np.where(z >= 0, f(2) - r, r)
     assert np.abs(g28 - ref).max() < 8.2e-7
+    # block-scaled fp8 family (gelu_tanh2): x * sigmoid(2u) by one exp2 and one reciprocal; its error only has to stay far below the
+    # 2^-4 relative step of the e4m3 values it is rounded to
+    w = (x * x * f(-2.0 * 0.7978845608 * 0.044715 * 1.4426950409) + f(-2.0 * 0.7978845608 * 1.4426950409)) * x
+    with np.errstate(over="ignore"):
+        gt = x * (f(1) / (np.exp2(w) + f(1)))
+    assert np.abs(gt - ref).max() < 4.8e-4 and np.isfinite(gt).all()
+    assert gt[0] == 0 and gt[-1] == x[-1]           # the limits: exp2 overflow -> 1/inf = 0, underflow -> x
     tail = x < -3                                   # the negative tail keeps relative accuracy where GELU is still above 1e-5
     big = tail & (np.abs(ref) > 1e-5)
     assert (np.abs(g26 - ref)[big] / np.abs(ref)[big]).max() < 1e-2 and (np.abs(g28 - ref)[big] / np.abs(ref)[big]).max() < 6e-2

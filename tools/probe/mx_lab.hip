@@ -21,6 +21,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TRACE_SLOTS = 128;
 
+#ifdef LAB_FASTGELU      // the family's GELU before round 3 (A&S 7.1.28)
+#define LAB_GELU gelu_fast2
+#else
+#define LAB_GELU gelu_tanh2
+#endif
+
 // QT: accumulators hold the TRANSPOSED 32x32 tile (lane = output row, registers = 16 columns) -- quantising epilogue only
 template <int BM, int BN, int WM, int WN, int RB, int STAGES, int MINW, bool QT>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void mx8p_kernel(GemmParams p, long long* trace, int dbg) {
@@ -234,7 +240,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void mx8p_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         f32x2 v2 = {acc[i][j][r] + bia[j][r], acc[i][j][r + 1] + bia[j][r + 1]};
-                        if (p.epi == EPI_BIAS_GELU) v2 = gelu_fast2(v2);
+                        if (p.epi == EPI_BIAS_GELU) v2 = LAB_GELU(v2);
                         v[r] = v2[0]; v[r + 1] = v2[1];
                         am = fmaxf(am, fmaxf(fabsf(v2[0]), fabsf(v2[1])));
                     }
@@ -520,7 +526,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void mx8q_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         f32x2 v2 = {acc[i][j][r] + bia[j][r], acc[i][j][r + 1] + bia[j][r + 1]};
-                        if (p.epi == EPI_BIAS_GELU) v2 = gelu_fast2(v2);
+                        if (p.epi == EPI_BIAS_GELU) v2 = LAB_GELU(v2);
                         v[r] = v2[0]; v[r + 1] = v2[1];
                         am = fmaxf(am, fmaxf(fabsf(v2[0]), fabsf(v2[1])));
                     }
@@ -567,7 +573,7 @@ __global__ void mx_ref_kernel(GemmParams p, float* out) {
         tot += (double)s * exp2((double)(ea - 127)) * exp2((double)(ew - 127));
     }
     float v = (float)tot + (p.bias ? p.bias[n] : 0.f);
-    if (p.epi == EPI_BIAS_GELU) { f32x2 g = gelu_fast2(f32x2{v, v}); v = g[0]; }
+    if (p.epi == EPI_BIAS_GELU) { f32x2 g = LAB_GELU(f32x2{v, v}); v = g[0]; }
     if (p.epi == EPI_BIAS_RESIDUAL) v += p.R[(long)m * p.N + n];
     out[idx] = v;
 }
