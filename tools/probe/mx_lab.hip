@@ -3,7 +3,8 @@
 // (operands swapped in the MFMA, so a lane holds 16 columns of ONE row; the two lane halves trade dwords with v_permlane32_swap).
 // Stand-alone (does not link the library): random e4m3 bytes + E8M0 scales, a naive device reference for correctness, hipEvent
 // timing and per-workgroup phase stamps (100 MHz realtime counter).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probe/mx_lab.hip -o tools/probe/mx_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DLAB_Q: pipelined variants 2, 3 only | -DLAB_ALL: + variants 4-9 (sweep 1 of profiles/r03_mx_lab.txt
+//   numbered them 1-7)] [-DLAB_FASTGELU: the family's GELU before round 3] tools/probe/mx_lab.hip -o tools/probe/mx_lab
 //   tools/probe/mx_lab M N K variant epi quant grid     (epi 0 bias, 1 bias+GELU, 3 bias+residual; quant 1 = fp8 + scales out)
 #include "../../fashionern_aaai2024_amd/csrc/gemm_epilogue.h"
 
@@ -597,12 +598,12 @@ static const Variant kV[] = {
     VQ(256, 256, 128, 64, 4, 1, 1),        // 2: pipelined, 8 waves of 128x64
     VQ(256, 128, 128, 64, 3, 2, 2),        // 3: pipelined, 4 waves of 128x64, two workgroups per CU
 #ifdef LAB_ALL
-    V(256, 128, 64, 64, 64, 3, 2, 2),      // 2: config 9 shape
-    V(256, 256, 64, 64, 128, 2, 1, 1),     // 3: config 7 shape (16 waves)
-    V(256, 128, 128, 64, 64, 3, 2, 2),     // 4: 4 waves of 128x64, 2 per CU
-    V(256, 256, 128, 64, 64, 3, 1, 1),     // 5
-    V(128, 256, 64, 64, 64, 3, 2, 2),      // 6: 8 waves of 64x64, wide
-    V(256, 256, 128, 64, 128, 2, 1, 1),    // 7
+    V(256, 128, 64, 64, 64, 3, 2, 2),      // 4: config 9 shape
+    V(256, 256, 64, 64, 128, 2, 1, 1),     // 5: config 7 shape (16 waves)
+    V(256, 128, 128, 64, 64, 3, 2, 2),     // 6: 4 waves of 128x64, 2 per CU
+    V(256, 256, 128, 64, 64, 3, 1, 1),     // 7
+    V(128, 256, 64, 64, 64, 3, 2, 2),      // 8: 8 waves of 64x64, wide
+    V(256, 256, 128, 64, 128, 2, 1, 1),    // 9
 #endif
 };
 
