@@ -112,7 +112,9 @@ def other_config_lines(steps: int) -> dict:
             j = json.loads(line)
             rec = {k: j.get(k) for k in keep}
             rec["workload"] = j["config"]["workload"]
-            rec["roofline"] = {k: j["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "gemm_ms_per_step")}
+            rec["roofline"] = {k: j["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "gemm_ms_per_step", "step_level")}
+            rec["roofline"]["regime"] = "serial_passes (instrumented one-stream passes; `step_level` = same flops / the timed multi-lane ms_per_step)"
+            rec["latency_ms_per_batch"] = j.get("latency_ms_per_batch")
             if j.get("roofline_sim_sweep"):
                 rec["rank_stage_us"] = j["roofline_sim_sweep"].get("stage_us")
                 rec["rank_stage_frac_of_hbm"] = j["roofline_sim_sweep"].get("frac")
@@ -270,6 +272,11 @@ def main():
     clip.load_state_dict(clip_sd)
     model = ERN(clip, D, device, engine=clip.engine).load_state_dict(fusion_sd)
     eng = model.engine
+    # The gallery store is allocated NOW, like a serving process allocates its gallery at start-up (the all-gather below writes
+    # straight into it): a 1 GB buffer allocated after a minute of other work (workspaces of three lanes, tuner scratch, freed
+    # sources) sits in small physical fragments and the same sweep kernel streams it ~20 % slower (209 vs 171 us on one box).
+    _s0, _s1, _per = fd.shard_rows(n_gal, rank, world)
+    gallery_store = torch.empty((world * _per, D), dtype=torch.bfloat16 if w["bf16_gallery"] else torch.float32, device=device)
     if not args.headline_only and args.config == "c2" and precision == "fp32":
         # the 1M-row bf16 gallery of the HBM-bound ranking leg is allocated NOW, like a serving process allocates its gallery at start-up:
         # allocated after a minute of other work (workspaces of three lanes, four precision modes, a freed 2 GB fp32 source) the same
@@ -300,7 +307,7 @@ def main():
         return block
 
     def gather(block):
-        return fd.all_gather_shards(block, n_gal)      # bytes on the wire; the gloo debug backend is staged through the host in there
+        return fd.all_gather_shards(block, n_gal, out=gallery_store)      # bytes on the wire; the gloo debug backend is staged through the host in there
 
     def barrier():
         torch.cuda.synchronize()
@@ -352,6 +359,8 @@ def main():
             eng.gather_scores(q, gallery, members)
         return out
 
+    last_latency = [None]
+
     def timed_loop(fn, steps):
         """`steps` calls of fn bracketed by barrier + synchronize; max over ranks.  Also the median gap between consecutive
         batches' completion events (hipEvents on the lanes' streams): a per-step figure that one slow step does not move."""
@@ -371,6 +380,13 @@ def main():
         nl = args.lanes
         for a, b in zip(evs[:-nl], evs[nl:]):
             gaps.append(a.elapsed_time(b) / nl)
+        # per-batch service latency: the batch's first kernel reaches the head of its lane -> its top-K is complete, with the
+        # other lanes' batches in flight beside it (throughput is quoted with `lanes` batches in flight; this is what one batch pays)
+        lat = sorted(o.start_event.elapsed_time(o.done_event) for o in outs if getattr(o, "start_event", None) is not None)
+        last_latency[0] = None if not lat else {"p50": lat[len(lat) // 2], "p99": lat[min(len(lat) - 1, int(0.99 * len(lat)))],
+                                                "max": lat[-1], "batches": len(lat), "batches_in_flight": nl,
+                                                "note": "hipEvent on the batch's lane in front of its first kernel -> event behind its last, "
+                                                        "other lanes busy; queueing behind earlier batches of the same lane is not included"}
         return el, outs[-1], (statistics.median(gaps) if gaps else None)
 
     for _ in range(max(args.warmup, args.lanes, n_batches)):      # every lane's workspace / every tuned shape exists before the timed region
@@ -393,6 +409,7 @@ def main():
         return
     elapsed, last, gap_median = timed_loop(step, args.steps)
     value = world * B * args.steps / elapsed
+    headline_latency = last_latency[0]
 
     # ---- c5 only: gallery-SHARDED ranking (SURVEY 8e alternative): all-gather the fused queries, sweep the local shard for all of
     # them, all-gather the candidates, merge -- every rank reads N/W gallery rows per batch instead of N
@@ -450,6 +467,7 @@ def main():
         tfl = sp[key + "_flops"] / (sp[key + "_ms"] * 1e-3) / 1e12 if sp[key + "_ms"] > 0 else 0.0
         overlap = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(ref_idx.cpu(), b_idx.cpu())) / ref_idx.numel()
         info = {"value": world * B * args.steps / el, "unit": "queries/sec", "ms_per_step": el / args.steps * 1e3,
+                "latency_ms_per_batch": last_latency[0],
                 "dtype": ("f32 data; plain GEMMs of >= 256 rows as three bf16 planes per operand, six bf16 MFMAs per fp32 pair, f32 accumulate "
                           "(fp32-accurate, not the bit-exact fma chain; attention, statistics and the ranking stage unchanged)") if prec == "f32x3" else
                          {"bf16": "bf16", "fp8": "fp8 e4m3fn (per-token / per-channel scales)",
@@ -574,7 +592,8 @@ def main():
             traffic = tr.get("gemm", {}).get("hbm_bytes_per_launch")
             alg_bytes = tr.get("gemm", {}).get("algorithmic_bytes_per_launch")
             sweep_traffic = tr.get("sweep", {}).get("hbm_bytes_per_launch")
-            traffic_src = ("STALE -- not measured in this run: read from profiles/pmc_traffic.json, produced by separate `rocprofv3 --pmc "
+            traffic_src = ("STALE -- not measured in this run: read from profiles/pmc_traffic.json (measured " + json.dumps(tr.get("measured")) +
+                           "), produced by separate `rocprofv3 --pmc "
                            "FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `bench.py --pmc-mode` (" + str(tr.get("source")) + ")")
         result = {
             "metric": "composed queries/sec", "value": value, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
@@ -586,6 +605,7 @@ def main():
                        "input_batches_rotated": n_batches,
                        "parallelism": f"dp{world} queries; gallery built sharded ({per} rows per rank, seed + rank), fused blocks all-gathered once"},
             "ms_per_step_event_median": gap_median,
+            "latency_ms_per_batch": headline_latency,
             "rccl_world": world if backend == "nccl" else (1 if world == 1 else f"{world} (debug backend {backend})"),
             "all_gather": {"ms": ag_ms if world > 1 else 0.0, "bytes_received_per_rank": ag_bytes,
                            "GBs_per_rank": (ag_bytes / (ag_ms * 1e-3) / 1e9) if world > 1 and ag_ms > 0 else None,
@@ -600,6 +620,14 @@ def main():
                                     "bf16": "gemm_bf16_glds_kernel (bf16 MFMA GEMM of the encoder blocks)",
                                     "fp8": "gemm_bf16_glds_kernel<FP8> (fp8 MFMA GEMM of the encoder blocks)",
                                     "mx8": "gemm_mx8_kernel (block-scaled fp8 GEMM of the encoder blocks, v_mfma_scale_f32_32x32x64_f8f6f4)"}[precision],
+                         "regime": "serial_passes: `achieved` = sum of 2MNK / sum of HIP-event durations around every launch of the family "
+                                   "in INSTRUMENTED ONE-STREAM passes of the step (run after the timed region); the timed region itself keeps "
+                                   f"{args.lanes} batches in flight, so `gemm_ms_per_step` may exceed `ms_per_step` -- `step_level` is the same "
+                                   "flop count over the timed wall clock",
+                         "step_level": {"achieved": st[gkey + "_flops"] / prof_steps / 1e12 / (elapsed / args.steps),
+                                        "frac": st[gkey + "_flops"] / prof_steps / 1e12 / (elapsed / args.steps) / gemm_peak,
+                                        "note": "family flops per step / timed ms_per_step (multi-lane regime): a LOWER bound of the family's "
+                                                "rate -- the wall clock also holds every other kernel of the step"},
                          "gemm_ms_per_step": st[gkey + "_ms"] / prof_steps, "gemm_gflop_per_step": st[gkey + "_flops"] / prof_steps / 1e9,
                          "gemm_launches_per_step": st[gkey + "_launches"] / prof_steps,
                          "gemm_dispatches_per_step": (st["gemm_dispatches"] / prof_steps) if precision == "fp32" else None,

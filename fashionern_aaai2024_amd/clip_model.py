@@ -95,20 +95,24 @@ class FernCLIP:
             raise IndexError(f"token id out of range [0, {self.cfg.vocab_size})")      # nn.Embedding's error in the reference
         # the reference calls encode_text twice on the same tokens (global, then seq: test_fiq.py:102-103); one tower pass
         # serves both.  "The same tokens" is decided WITHOUT a device sync: host tokens (what the reference's tokenizer yields)
-        # are compared on the host; device tokens by identity -- storage address, shape and torch's in-place version counter
-        # (round 2 compared device tensors with torch.equal: a host sync per call in the harness loop).
-        if text.is_cuda:
-            key, same = (text.data_ptr(), tuple(text.shape), text._version, text.dtype), None
-        else:
-            key, same = None, text
+        # are compared on the host; device tokens ONLY by object identity + torch's in-place version counter, with the cache
+        # holding a strong reference to the tensor (a freed block handed out again at the same address with version 0 and the
+        # same shape must not hit: ADVICE r3).  `visual_emb` is part of the key by identity as well.
         c = self._text_cache
-        if c is not None and ((key is not None and c[0] == key) or
-                              (same is not None and c[1] is not None and c[1].shape == same.shape and torch.equal(c[1], same))):
-            g, s = c[2], c[3]
+        hit = False
+        if c is not None and c["visual_emb"] is visual_emb:
+            if text.is_cuda:
+                hit = c["tensor"] is text and c["version"] == text._version
+            else:
+                h = c["host"]
+                hit = h is not None and h.shape == text.shape and h.dtype == text.dtype and torch.equal(h, text)
+        if hit:
+            g, s = c["global"], c["seq"]
         else:
             t = text.to(device=self.device, dtype=torch.int64)
             g, s = self.engine.encode_text(t, visual_emb=visual_emb)
-            self._text_cache = (key, None if same is None else same.clone(), g, s)
+            self._text_cache = {"tensor": text if text.is_cuda else None, "version": text._version,
+                                "host": None if text.is_cuda else text.clone(), "visual_emb": visual_emb, "global": g, "seq": s}
         return s if mode == "seq" else (g, s)
 
 

@@ -715,8 +715,8 @@ extern "C" int fern_set_precision(fern_ctx* c, int precision) {
     if (precision != FERN_PREC_FP32 && precision != FERN_PREC_BF16 && precision != FERN_PREC_FP8 && precision != FERN_PREC_MX8 &&
         precision != FERN_PREC_F32X3)
         return fail(FERN_ERR_ARG, "fern_set_precision: unknown precision");
-    c->f32x3 = precision == FERN_PREC_F32X3;
-    if (c->f32x3) precision = FERN_PREC_FP32;      // fp32 data flow; only the GEMM arithmetic changes
+    const bool split = precision == FERN_PREC_F32X3;
+    if (split) precision = FERN_PREC_FP32;         // fp32 data flow; only the GEMM arithmetic changes
     if (precision == FERN_PREC_MX8 && c->clip.ready) {
         for (const auto* blocks : {&c->clip.vblocks, &c->clip.tblocks})
             for (const auto& b : *blocks)
@@ -729,7 +729,8 @@ extern "C" int fern_set_precision(fern_ctx* c, int precision) {
                 if (!b.qkv.w8 || !b.out.w8 || !b.fc.w8 || !b.proj.w8)
                     return fail(FERN_ERR_ARG, "fern_set_precision: fp8 needs tower widths and MLP widths that are multiples of 64 (<= 4096)");
     }
-    c->precision = precision;
+    c->precision = precision;                      // both fields are committed together, after every check has passed
+    c->f32x3 = split;
     return FERN_OK;
 }
 extern "C" int fern_get_precision(fern_ctx* c) { return !c ? FERN_ERR_ARG : c->f32x3 ? FERN_PREC_F32X3 : c->precision; }

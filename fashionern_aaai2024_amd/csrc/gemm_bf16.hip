@@ -499,10 +499,15 @@ static void pin_tile_line_b(const char* line) {      // caller holds g_tuned_b_m
     char kind[16];
     int M, N, K, epi, ob, cfg;
     if (sscanf(line, "%15s %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &ob, &cfg) != 7) return;
-    const bool f8 = !strcmp(kind, "fp8"), mx = !strcmp(kind, "mx8");
-    if ((f8 || mx || !strcmp(kind, "bf16")) && cfg >= 0 && cfg < (mx ? kNumCfgsMx : f8 ? kNumCfgsF8 : kNumCfgsB) &&
-        (f8 || mx || K % kCfgsB[cfg].bk == 0))
-        g_tuned_b[ShapeKeyB{M, N, K, epi, ob}] = cfg;
+    // the LAUNCH family is selected by the `ob` bits of the key (bit 1: per-row fp8, bit 2: block-scaled fp8), so the family the
+    // configuration index is checked against comes from `ob`, and a line whose kind disagrees with it is dropped (an
+    // mx8 cfg pinned under a bf16 key would fail every launch of that shape)
+    const bool mx = (ob & 4) != 0, f8 = !mx && (ob & 2) != 0;
+    if (strcmp(kind, mx ? "mx8" : f8 ? "fp8" : "bf16") != 0) return;
+    if (cfg < 0 || cfg >= (mx ? kNumCfgsMx : f8 ? kNumCfgsF8 : kNumCfgsB) || M <= 0 || N <= 0 || K <= 0) return;
+    const int kq = mx ? 128 : f8 ? 64 : kCfgsB[cfg].bk;      // k granularity the family's kernels need (launch_gemm_bf16 checks the same)
+    if (K % kq) return;
+    g_tuned_b[ShapeKeyB{M, N, K, epi, ob}] = cfg;
 }
 static void load_pinned_tiles_b() {
     static std::once_flag once;

@@ -88,15 +88,22 @@ def build_gallery(engine, index_features: torch.Tensor, index_local: torch.Tenso
     return full[:n]
 
 
-def all_gather_shards(block: torch.Tensor, n_total: int) -> torch.Tensor:
+def all_gather_shards(block: torch.Tensor, n_total: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """ONE all_gather of equally sized per-rank blocks [per, ...] (``per = ceil(n_total / world)``, short shards zero-padded by
     the caller) -> the first ``n_total`` rows of their concatenation on every rank.  This is the path's only data-path
-    collective: one shard per xGMI link, nothing to bucket."""
+    collective: one shard per xGMI link, nothing to bucket.  ``out`` ([world * per, ...], same dtype / device): the gallery
+    store of a serving process, allocated when the process starts -- the collective writes straight into it (world 1: one copy)."""
     rank, world = world_info()
+    if out is not None and (tuple(out.shape) != (world * block.shape[0],) + tuple(block.shape[1:]) or out.dtype != block.dtype
+                            or out.device != block.device or not out.is_contiguous()):
+        raise ValueError(f"out must be a contiguous [{world * block.shape[0]}, ...] {block.dtype} tensor on {block.device}")
     if world == 1:
-        return block[:n_total]
+        if out is None:
+            return block[:n_total]
+        out.copy_(block)
+        return out[:n_total]
     block = block.contiguous()
-    full = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    full = out if out is not None else torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
     _all_gather_into(full, block)      # as bytes: a bf16 gallery (config 5) needs no bf16 support from the backend (gloo has none)
     return full[:n_total]
 

@@ -18,8 +18,16 @@ from .engine import FernEngine
 class QueryResult:
     """Top-K of one submitted batch; `scores` / `idx` are valid on the caller's stream after `wait()`."""
 
-    def __init__(self, scores: torch.Tensor, idx: torch.Tensor, fused: torch.Tensor, event: torch.cuda.Event, member_scores=None):
+    def __init__(self, scores: torch.Tensor, idx: torch.Tensor, fused: torch.Tensor, event: torch.cuda.Event, member_scores=None,
+                 start_event: Optional[torch.cuda.Event] = None):
         self.scores, self.idx, self.fused, self._event, self.member_scores = scores, idx, fused, event, member_scores
+        self._start = start_event
+
+    @property
+    def start_event(self) -> Optional[torch.cuda.Event]:
+        """``timing=True`` pipelines: recorded on the batch's lane in front of its first kernel, i.e. when the batch reaches the head
+        of its lane -- `start_event.elapsed_time(done_event)` is the batch's service latency with the other lanes' batches in flight."""
+        return self._start
 
     @property
     def done_event(self) -> torch.cuda.Event:
@@ -87,6 +95,10 @@ class ComposedQueryPipeline:
         stream.wait_stream(torch.cuda.current_stream())          # inputs produced on the caller's stream
         args = (images, tokens, local, exclude_idx, members, ref_feats)
         with torch.cuda.stream(stream):
+            ev0 = None
+            if self.timing:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record(stream)
             if self.graphs:
                 outs = self._replay(lane, eng, stream, args, gallery, k, idx_offset)
             else:
@@ -94,7 +106,7 @@ class ComposedQueryPipeline:
             ev = torch.cuda.Event(enable_timing=self.timing)
             ev.record(stream)
         fused, scores, idx, member_scores = outs
-        return QueryResult(scores, idx, fused, ev, member_scores)
+        return QueryResult(scores, idx, fused, ev, member_scores, ev0)
 
     @staticmethod
     def _step(eng, args, gallery, k, idx_offset):
@@ -148,3 +160,4 @@ class ComposedQueryPipeline:
         for e in self.engines[1:]:
             e.close()
         self.engines = self.engines[:1]
+        self.engines[0].tuner_set_concurrency(1)      # process-wide setting: shapes tuned after this pipeline are scored stand-alone again

@@ -2,11 +2,13 @@
 would be too slow (sortedness, idempotence, shard/merge == global, gather == top-K scores, batch invariance), plus a
 direct oracle comparison on a bounded slice.
 
-C1  RN50x4-shaped D=640, 1k gallery, B=32 (fusion + rank; the RN50x4 image tower itself is not built yet)
+C1  RN50x4-shaped D=640, 1k gallery, B=32 (fusion + rank; the RN50x4 image tower itself: tests/test_gpu_kernels.py, test_gpu_fusion.py)
 C2  ViT-B/16 D=512, B=64 vs 46k gallery
 C3  D=640, ~200k gallery sharded 8 ways, all-gather == unsharded
 C4  CIRR-style: B=1024 queries, K=51 with the reference removed, 6 group members per query
-C5  1M-row gallery (fp32 here; the fp8/bf16 mode of that config is not built)
+C5  1M-row gallery: fp32 sweep, bf16 sweep, and the whole config end to end -- ViT-B/16 towers in the per-row fp8 mode AND in the
+    block-scaled fp8 mode the bench times ("mx8") -> fusion -> 1M-row bf16 gallery sweep, ranking checked against the oracle on
+    the features the encoder produced
 """
 import numpy as np
 import pytest
@@ -307,26 +309,35 @@ def test_bf16_sweep_exact_ties_and_one_million_rows():
     assert (got - s_c[:4]).abs().max().item() < 2e-6
 
 
-def test_c5_fp8_encoder_with_bf16_similarity_end_to_end():
-    """BASELINE configs[4] as one path on one GPU's share: ViT-B/16 towers in fp8 mode -> fp32 fusion -> 1M-row bf16 gallery
-    sweep + top-50 (the 8-GPU form shards the gallery build and replicates this step; tests/test_distributed_cpu.py).
+@pytest.mark.parametrize("precision", ["fp8", "mx8"])
+def test_c5_fp8_encoder_with_bf16_similarity_end_to_end(precision):
+    """BASELINE configs[4] as one path on one GPU's share: ViT-B/16 towers in an fp8 mode -- "fp8" (per-row scales) and "mx8"
+    (block-scaled, the precision `bench.py --config c5` times: VERDICT r3 item 1b) -> fusion -> 1M-row bf16 gallery sweep + top-50
+    (the 8-GPU form shards the gallery build and replicates this step; tests/test_distributed_cpu.py).
     The ranking is checked exactly against the oracle ON THE FEATURES THE fp8 ENCODER PRODUCED (same bf16 rounding of both
-    operands); the encoder's own deviation is what test_clip_towers_fp8_precision bounds."""
+    operands); the encoder's own deviation is what test_clip_towers_{fp8,mx8}_precision bound (tests/test_gpu_fusion.py), and the
+    fused queries must stay within the mode's documented distance of the fp32 mode's (cosine >= 1 - 2e-2: a 3-bit mantissa)."""
     cfg = synth.CLIP_CONFIGS["ViT-B-16"]
     eng = FernEngine("cuda:0")
     eng.load_tensors(synth.clip_state_dict(cfg, seed=3))
     eng.finalize_clip(cfg)
     eng.load_tensors(synth.fusion_state_dict(512, seed=21))
     eng.finalize_fusion(512)
-    eng.set_precision("fp8")
     b = 8
     imgs = torch.from_numpy(synth.images(b, cfg, 5))
     toks = torch.from_numpy(synth.captions(b, cfg, 5))
     loc = torch.from_numpy(synth.local_feats(b, 512, 5))
+    ref32 = eng.encode_image(imgs)
+    tg32, ts32 = eng.encode_text(toks)
+    fused32 = eng.dvr_fuse(ref32, loc, tg32, ts32)
+    eng.set_precision(precision)
+    assert eng.precision == precision
     ref = eng.encode_image(imgs)
     tg, ts = eng.encode_text(toks)
     fused = eng.dvr_fuse(ref, loc, tg, ts)
     assert torch.isfinite(fused).all() and (fused.norm(dim=-1) - 1).abs().max().item() < 1e-5
+    assert not torch.equal(fused, fused32), "the mode was expected to change the towers' arithmetic"
+    assert (1 - F.cosine_similarity(fused, fused32, dim=-1)).max().item() < 2e-2
     n = 1_000_000
     g = torch.from_numpy(synth.unit_rows(125_000, 512, tag="c5e")).cuda().repeat(8, 1)
     g[125_000:] += torch.linspace(0, 1e-3, n - 125_000, device="cuda")[:, None]

@@ -200,6 +200,47 @@ def test_precision_option_of_the_clip_surface_and_oracle_bf16_restatement():
         clip.engine.set_precision("int4")
 
 
+def test_encode_text_cache_hits_only_on_identity_or_equal_host_tokens():
+    """the one-pass-serves-both-calls cache (test_fiq.py:102-103) must never serve another batch.  Host
+    tokens hit on equal contents; device tokens only when it is the SAME tensor object at the same in-place version (a new
+    tensor that the allocator placed at the freed address of the last one is a different object) and the same visual_emb."""
+    from fashionern_aaai2024_amd.clip_model import create_model
+    cfg = synth.CLIP_CONFIGS["tiny"]
+    eng = OracleEngine()
+    calls = []
+    inner = eng.encode_text
+    eng.encode_text = lambda t, **kw: (calls.append(1), inner(t, **kw))[1]
+    clip = create_model(cfg, device="cpu", seed=2, engine=eng)
+    a = torch.from_numpy(synth.captions(3, cfg, 3))
+    b = torch.from_numpy(synth.captions(3, cfg, 4))
+    g1, _ = clip.encode_text(a)
+    s1 = clip.encode_text(a.clone(), mode="seq")                    # equal host contents: served from the cache
+    assert len(calls) == 1 and torch.equal(s1[torch.arange(3), a.argmax(-1)], g1)
+    g2, _ = clip.encode_text(b)
+    assert len(calls) == 2 and not torch.equal(g1, g2)
+    ve = torch.zeros(13, 3, cfg.embed_dim)
+    clip.encode_text(b, visual_emb=ve)
+    assert len(calls) == 3                                           # another visual_emb object: re-encoded
+    clip.encode_text(b, mode="seq", visual_emb=ve)
+    assert len(calls) == 3
+
+    class DeviceTokens:                                              # a duck-typed "cuda" tensor: same address / shape / version every time
+        is_cuda, dtype, _version = True, torch.int64, 0
+        def __init__(self, t): self.t, self.shape = t, t.shape
+        def data_ptr(self): return 0xdead0000
+        def numel(self): return self.t.numel()
+        def to(self, **kw): return self.t
+    da, db = DeviceTokens(a), DeviceTokens(b)
+    ga, _ = clip.encode_text(da)
+    n = len(calls)
+    assert torch.equal(clip.encode_text(da, mode="seq")[torch.arange(3), a.argmax(-1)], ga) and len(calls) == n
+    gb, _ = clip.encode_text(db)                                     # same address, shape, version, dtype -- different object
+    assert len(calls) == n + 1 and torch.equal(gb, g2) and not torch.equal(gb, ga)
+    db._version = 1                                                  # modified in place
+    clip.encode_text(db)
+    assert len(calls) == n + 2
+
+
 def test_builtin_clip_bpe_tokenizer_on_a_synthetic_merge_table(tmp_path, monkeypatch):
     """ClipBpeTokenizer restates the published CLIP byte-level BPE (vocabulary file not available offline: parity unpinned);
     its algorithmic behaviour is checked on a small merge table: rank order, every-occurrence merging, end-of-word marks,

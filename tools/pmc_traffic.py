@@ -10,7 +10,9 @@ WRITE_SIZE is exact for 16-B-per-lane streaming stores (the GEMM epilogues store
 Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> [out.json]
 """
 import csv
+import datetime
 import json
+import os
 import re
 import sys
 
@@ -55,7 +57,10 @@ def main():
     write = summarise(per_dispatch(sys.argv[2], "WRITE_SIZE"), 1.0)
     steps = int(sys.argv[3])
     calls = max(1, fetch["rank_calls"])
+    # when / at which tree the counters were collected: bench.py quotes the figure as STALE (it cannot collect PMC counters inside
+    # the driver's run) and repeats this stamp.  FERN_HEAD: `git rev-parse --short HEAD` of the dev container (no .git on the GPU box).
     out = {
+        "measured": {"date": datetime.date.today().isoformat(), "head": os.environ.get("FERN_HEAD", "unknown")},
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --pmc-mode`; FETCH_SIZE x2 (gfx950), KiB -> B",
         "steps": steps,
         "gemm": {"launches_per_step": fetch["gemm_launches"] / steps,

@@ -4,10 +4,24 @@
 # rocprofv3 needs the program itself after `--` (python3 ...), TMPDIR on /tmp, and --pmc in passes of its own; every profiled
 # command runs under `timeout` (a profiler hang must not eat the GPU budget).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh
 mkdir -p $O
+# The probe executables are git-ignored build products (they travel from the dev container with the gpurun snapshot): build any that
+# is missing or older than its source -- hipcc is on the GPU box too -- and stop if one cannot be built, instead of filling the
+# artefacts with "No such file" (ADVICE r3).
+build_probe() {   # output, extra flags..., source is tools/probe/<first word of output's basename without _phases>.hip
+    local out=$1 src=$2; shift 2
+    if [ ! -x $R/$out ] || [ $R/$src -nt $R/$out ] || [ $R/fashionern_aaai2024_amd/csrc/gemm.hip -nt $R/$out ]; then
+        (cd $R && hipcc --offload-arch=gfx950 -O3 -std=c++17 "$@" $src -o $out) || { echo "refresh_profiles: cannot build $out" >&2; exit 1; }
+    fi
+}
+build_probe tools/probe/gemm_timeline tools/probe/gemm_timeline.hip -DFERN_GEMM_TRACE
+build_probe tools/probe/gemm_timeline_phases tools/probe/gemm_timeline.hip -DFERN_GEMM_TRACE -DFERN_GEMM_TRACE_PHASES
+build_probe tools/probe/mfma_issue_probe tools/probe/mfma_issue_probe.hip
+for b in gemm_timeline gemm_timeline_phases mfma_issue_probe; do [ -x $R/tools/probe/$b ] || { echo "refresh_profiles: tools/probe/$b missing" >&2; exit 1; }; done
+export FERN_HEAD=${FERN_HEAD:-$(cat $R/.fern_head 2>/dev/null || echo unknown)}      # stamped into pmc_traffic.json (no .git on the GPU box)
 cd /tmp && export TMPDIR=/tmp
 run_stats() {   # name, bench args...
     local name=$1; shift
