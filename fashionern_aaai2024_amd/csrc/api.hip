@@ -1118,12 +1118,15 @@ static int clip_block_fp8(fern_ctx* c, const ClipBlockW& Bk, float* X, unsigned 
 // MX block (FERN_PREC_MX8): clip_block_fp8 with block-scaled operands -- one E8M0 scale per (token, 32 channels) and per (output
 // channel, 32 inputs), applied inside v_mfma_scale_f32_32x32x64_f8f6f4 (twice the MFMA rate of the plain fp8 form, and an outlier
 // channel costs its own 32-block precision, not the whole token row).  SM: the activation scales of the operand in flight.
-static int clip_block_mx8(fern_ctx* c, const ClipBlockW& Bk, float* X, unsigned char* XN8, unsigned char* SM, unsigned short* QKVb,
+// The residual stream of this mode is BF16 (Xb, round 4): the two residual GEMMs of a block read and write it in place
+// (C = bf16(acc + bias + Xb): one rounding per residual add) and the LayerNorms read it -- out-proj / c_proj were HBM-bound on their
+// 2 x 39 MB of fp32 residual traffic per launch (M = 12608), the LayerNorm + quantise passes on their 39 MB reads.
+static int clip_block_mx8(fern_ctx* c, const ClipBlockW& Bk, unsigned short* Xb, unsigned char* XN8, unsigned char* SM, unsigned short* QKVb,
                           unsigned short* ATTb, unsigned char* ATT8, unsigned char* H8, int batch, int S, int width,
                           int heads, int causal, hipStream_t s) {
     const long R = (long)batch * S;
     const int hd = width / heads, mlp = Bk.fc.out;
-    HIP_TRY(launch_layernorm_mx8(X, Bk.ln1.g, Bk.ln1.b, XN8, SM, R, R, width, width, width, 1e-5f, s));
+    HIP_TRY(launch_layernorm_mx8(nullptr, Bk.ln1.g, Bk.ln1.b, XN8, SM, R, R, width, width, width, 1e-5f, s, Xb));
     FERN_TRY(run_gemm_b(c, gemm_desc_mx(XN8, SM, R, width, Bk.qkv, QKVb, 3 * width, (int)R, EPI_BIAS, true), s));
     AttnParams a{nullptr, nullptr, nullptr, nullptr, 3L * width, 3L * width, 3L * width, (long)width,
                  batch, heads, hd, S, S, causal, 1.0f / std::sqrt((float)hd), ATTb, QKVb, QKVb + width, QKVb + 2 * width};
@@ -1134,17 +1137,17 @@ static int clip_block_mx8(fern_ctx* c, const ClipBlockW& Bk, float* X, unsigned 
         FERN_TRY(run_attention(c, a, s));
         HIP_TRY(launch_quantize_mx8(ATTb, nullptr, width, ATT8, width, SM, R, R, width, s));
     }
-    GemmParams po = gemm_desc_mx(ATT8, SM, R, width, Bk.out, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
-    po.R = X;
+    GemmParams po = gemm_desc_mx(ATT8, SM, R, width, Bk.out, Xb, width, (int)R, EPI_BIAS_RESIDUAL, true);
+    po.Rb = Xb;
     FERN_TRY(run_gemm_b(c, po, s));
-    HIP_TRY(launch_layernorm_mx8(X, Bk.ln2.g, Bk.ln2.b, XN8, SM, R, R, width, width, width, 1e-5f, s));
+    HIP_TRY(launch_layernorm_mx8(nullptr, Bk.ln2.g, Bk.ln2.b, XN8, SM, R, R, width, width, width, 1e-5f, s, Xb));
     // c_fc quantises its GELU output where it is produced (fp32 values -> e4m3fn + block scales): no bf16 round trip, no extra pass
     unsigned char* SH = SM + ((size_t)R * (width / 32) + 255) / 256 * 256;      // H's scales, behind the LayerNorm output's
     GemmParams pf = gemm_desc_mx(XN8, SM, R, width, Bk.fc, H8, mlp, (int)R, EPI_BIAS_GELU, false);
     pf.out_mx8 = 1; pf.mxc = SH; pf.mxc_rows = R;
     FERN_TRY(run_gemm_b(c, pf, s));
-    GemmParams p2 = gemm_desc_mx(H8, SH, R, mlp, Bk.proj, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
-    p2.R = X;
+    GemmParams p2 = gemm_desc_mx(H8, SH, R, mlp, Bk.proj, Xb, width, (int)R, EPI_BIAS_RESIDUAL, true);
+    p2.Rb = Xb;
     return run_gemm_b(c, p2, s);
 }
 
@@ -1237,11 +1240,18 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
     FERN_TRY(run_gemm(c, pe, s));
     }
     HIP_TRY(launch_vit_cls(W.cls, W.vpos, X, b, S, vw, s));
-    HIP_TRY(launch_layernorm(X, nullptr, W.ln_pre.g, W.ln_pre.b, X, R, vw, vw, vw, 1e-5f, s));
+    unsigned short* Xb = nullptr;              // FERN_PREC_MX8: the bf16 residual stream of the full blocks
+    const bool mx_stream = c->precision == FERN_PREC_MX8 && cf.v_layers > 1;
+    if (mx_stream) {
+        FERN_TRY(ws_get(c, (size_t)R * vw, &Xb));
+        HIP_TRY(launch_layernorm_bf16(X, W.ln_pre.g, W.ln_pre.b, Xb, R, vw, vw, vw, 1e-5f, s));      // ln_pre writes the stream (rounded once)
+    } else {
+        HIP_TRY(launch_layernorm(X, nullptr, W.ln_pre.g, W.ln_pre.b, X, R, vw, vw, vw, 1e-5f, s));
+    }
     for (int l = 0; l + 1 < cf.v_layers; ++l) {
         if (c->precision == FERN_PREC_MX8) {    // same buffer plan as fp8 below; the scale area holds E8M0 bytes
             unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
-            FERN_TRY(clip_block_mx8(c, W.vblocks[l], X, XN8, reinterpret_cast<unsigned char*>(XN + ((size_t)R * vw / 4 + 63) / 64 * 64),
+            FERN_TRY(clip_block_mx8(c, W.vblocks[l], Xb, XN8, reinterpret_cast<unsigned char*>(XN + ((size_t)R * vw / 4 + 63) / 64 * 64),
                                     reinterpret_cast<unsigned short*>(QKV), reinterpret_cast<unsigned short*>(ATT),
                                     reinterpret_cast<unsigned char*>(ATT) + (size_t)R * vw * 2, reinterpret_cast<unsigned char*>(H),
                                     b, S, vw, cf.v_heads, 0, s));
@@ -1258,6 +1268,7 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
         else
             FERN_TRY(clip_block(c, W.vblocks[l], X, XN, QKV, ATT, H, b, S, vw, cf.v_heads, 0, s));
     }
+    if (mx_stream) HIP_TRY(launch_bf16_to_f32(Xb, X, R * vw, s));      // the class-row chain of the last block is fp32 (exact widening)
     // ATT / H are free after the last full block: reuse their heads as the [b, width] / [b, mlp] temporaries
     FERN_TRY(clip_block_cls_only(c, W.vblocks[cf.v_layers - 1], X, XN, QKV, CLS, ATT, ATT + (size_t)b * vw, H, b, S, vw, cf.v_heads, s));
     HIP_TRY(launch_layernorm(CLS, nullptr, W.ln_post.g, W.ln_post.b, CLS, b, vw, vw, vw, 1e-5f, s));
@@ -1378,10 +1389,15 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
     FERN_TRY(ws_get(c, (size_t)R * cf.t_mlp, &H));
     FERN_TRY(ws_get(c, (size_t)B, &eot));
     HIP_TRY(launch_text_embed(tokens, W.tok_emb, W.tpos, X, eot, B, T, tw, cf.vocab_size, c->tok_flag, s));
+    unsigned short* Xb = nullptr;              // FERN_PREC_MX8: the bf16 residual stream of the blocks (clip_block_mx8)
+    if (c->precision == FERN_PREC_MX8) {
+        FERN_TRY(ws_get(c, (size_t)R * tw, &Xb));
+        HIP_TRY(launch_f32_to_bf16(X, Xb, R * tw, s));
+    }
     for (int l = 0; l < cf.t_layers; ++l) {
         if (c->precision == FERN_PREC_MX8) {
             unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
-            FERN_TRY(clip_block_mx8(c, W.tblocks[l], X, XN8, reinterpret_cast<unsigned char*>(XN + ((size_t)R * tw / 4 + 63) / 64 * 64),
+            FERN_TRY(clip_block_mx8(c, W.tblocks[l], Xb, XN8, reinterpret_cast<unsigned char*>(XN + ((size_t)R * tw / 4 + 63) / 64 * 64),
                                     reinterpret_cast<unsigned short*>(QKV), reinterpret_cast<unsigned short*>(ATT),
                                     reinterpret_cast<unsigned char*>(ATT) + (size_t)R * tw * 2, reinterpret_cast<unsigned char*>(H),
                                     B, T, tw, cf.t_heads, 1, s));
@@ -1398,6 +1414,7 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
         else
             FERN_TRY(clip_block(c, W.tblocks[l], X, XN, QKV, ATT, H, B, T, tw, cf.t_heads, 1, s));
     }
+    if (Xb) HIP_TRY(launch_bf16_to_f32(Xb, X, R * tw, s));
     HIP_TRY(launch_layernorm(X, nullptr, W.ln_final.g, W.ln_final.b, XN, R, tw, tw, tw, 1e-5f, s));
     LinearW proj{W.tproj_t, nullptr, E, tw};
     if (out_seq) {
@@ -1715,7 +1732,7 @@ extern "C" int fern_gemm_mx8(fern_ctx* c, const uint8_t* A, int64_t lda, const u
     if (!A || !W || !C || !scales_a || !scales_w) return fail(FERN_ERR_ARG, "fern_gemm_mx8: NULL argument");
     if (epilogue != FERN_EPI_BIAS && epilogue != FERN_EPI_BIAS_GELU && epilogue != FERN_EPI_BIAS_RESIDUAL)
         return fail(FERN_ERR_ARG, "fern_gemm_mx8: epilogue must be BIAS, BIAS_GELU or BIAS_RESIDUAL");
-    if (epilogue == FERN_EPI_BIAS_RESIDUAL && (!residual || out_bf16)) return fail(FERN_ERR_ARG, "fern_gemm_mx8: the residual epilogue needs a residual and fp32 output");
+    if (epilogue == FERN_EPI_BIAS_RESIDUAL && !residual) return fail(FERN_ERR_ARG, "fern_gemm_mx8: the residual epilogue needs a residual");
     if (K % 128 || lda % 16 || ldw % 16 || scale_rows_a < M || scale_rows_w < N)
         return fail(FERN_ERR_ARG, "fern_gemm_mx8: K % 128, lda % 16 and ldw % 16 must be 0, scale_rows >= rows");
     HIP_TRY(hipSetDevice(c->device));
@@ -1723,6 +1740,7 @@ extern "C" int fern_gemm_mx8(fern_ctx* c, const uint8_t* A, int64_t lda, const u
     p.Ab = reinterpret_cast<const unsigned short*>(A); p.lda = lda; p.Wb = reinterpret_cast<const unsigned short*>(W); p.ldw = ldw;
     p.bias = bias; p.R = residual; p.C = reinterpret_cast<float*>(C); p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epilogue;
     p.aload = ALOAD_PLAIN; p.out_bf16 = out_bf16 ? 1 : 0; p.fp8 = 2; p.mxa = scales_a; p.mxa_rows = scale_rows_a; p.mxw = scales_w; p.mxw_rows = scale_rows_w;
+    if (out_bf16 && epilogue == FERN_EPI_BIAS_RESIDUAL) { p.Rb = reinterpret_cast<const unsigned short*>(residual); p.R = nullptr; }      // bf16 residual stream
     return run_gemm_b(c, p, (hipStream_t)stream);
 }
 

@@ -212,14 +212,30 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const unsigned s
 // v_mfma_scale_f32_32x32x64_f8f6f4 (gemm_bf16.hip: gemm_mx8_kernel).  e = the smallest power of two that brings the block's
 // maximum to <= 448, read off the maximum's exponent / mantissa bits (448 = 1.75 * 2^8); the scaling x * 2^(127-e) is exact.
 
-// LayerNorm fused with the MX quantiser (a lane holds 4 consecutive elements: a 32-block is 8 lanes)
-__global__ __launch_bounds__(256) void layernorm_mx8_kernel(const float* x, const float* gamma, const float* beta, unsigned char* y,
+// LayerNorm fused with the MX quantiser (a lane holds 4 consecutive elements: a 32-block is 8 lanes).  XB: the rows are bf16 (the
+// block-scaled mode's residual stream), 8-byte loads of the same 4 elements per lane.
+__device__ __forceinline__ void row_load_bf16(RowRegs& r, const unsigned short* x, int d, int lane) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (c < d) {
+            const uint2 w = *reinterpret_cast<const uint2*>(x + c);
+            t[0] = __uint_as_float(w.x << 16); t[1] = __uint_as_float(w.x & 0xffff0000u);
+            t[2] = __uint_as_float(w.y << 16); t[3] = __uint_as_float(w.y & 0xffff0000u);
+        }
+        r.v[i] = t;
+    }
+}
+template <bool XB>
+__global__ __launch_bounds__(256) void layernorm_mx8_kernel(const float* x, const unsigned short* xb, const float* gamma, const float* beta, unsigned char* y,
                                                             unsigned char* scales, long srows, long rows, int d, long ldx, long ldy, float eps) {
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     RowRegs r;
-    row_load(r, x + row * ldx, d, lane);
+    if (XB) row_load_bf16(r, xb + row * ldx, d, lane);
+    else row_load(r, x + row * ldx, d, lane);
     row_layernorm(r, gamma, beta, d, lane, eps);
     unsigned char* yr = y + row * ldy;
 #pragma unroll
@@ -690,10 +706,11 @@ hipError_t launch_layernorm_fp8(const float* x, const float* gamma, const float*
     return hipGetLastError();
 }
 hipError_t launch_layernorm_mx8(const float* x, const float* gamma, const float* beta, unsigned char* y, unsigned char* scales, long srows,
-                                long rows, int d, long ldx, long ldy, float eps, hipStream_t s) {
+                                long rows, int d, long ldx, long ldy, float eps, hipStream_t s, const unsigned short* x_bf16) {
     if (rows <= 0) return hipSuccess;
     if (d <= 0 || d % 128 || d > 256 * MAXV || (ldx & 3) || (ldy & 3) || srows < rows) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_mx8_kernel, row_grid(rows), dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps);
+    if (x_bf16) hipLaunchKernelGGL(layernorm_mx8_kernel<true>, row_grid(rows), dim3(256), 0, s, x, x_bf16, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps);
+    else hipLaunchKernelGGL(layernorm_mx8_kernel<false>, row_grid(rows), dim3(256), 0, s, x, x_bf16, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps);
     return hipGetLastError();
 }
 hipError_t launch_im2col_mx8(const float* images, unsigned char* y, unsigned char* scales, long srows, int b, int img, int patch, int grid,

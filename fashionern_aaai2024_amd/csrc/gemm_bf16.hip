@@ -627,6 +627,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     if (p.fp8 == 2) {
         if (!p.mxa || !p.mxw || p.scale_a || ((uintptr_t)p.mxa & 3) || ((uintptr_t)p.mxw & 3) || p.mxa_rows < p.M || p.mxw_rows < p.N)
             return hipErrorInvalidValue;
+        if (p.epi == EPI_BIAS_RESIDUAL && (p.out_bf16 ? !p.Rb : !p.R)) return hipErrorInvalidValue;
         if (p.out_mx8 && (!p.mxc || p.mxc_rows < p.M || (p.N & 31) || (p.ldc & 15) || ((uintptr_t)p.C & 15) || (p.epi != EPI_BIAS && p.epi != EPI_BIAS_GELU)))
             return hipErrorInvalidValue;
         static int forced = [] { const char* e = getenv("FERN_GEMM_MX8_CFG"); return e ? atoi(e) : -1; }();

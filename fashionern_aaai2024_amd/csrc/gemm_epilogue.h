@@ -109,13 +109,15 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16&
     }
     // The residual stream is updated in place (R == C): the compiler keeps every load behind the preceding store, so the
     // memory addends of a tile are fetched together BEFORE its first store.
-    const float* Rt = resid ? p.R + (long)row0 * p.ldc + col0 : nullptr;
+    const float* Rt = resid && !OUT_BF16 ? p.R + (long)row0 * p.ldc + col0 : nullptr;
+    const unsigned short* Rbt = resid && OUT_BF16 ? p.Rb + (long)row0 * p.ldc + col0 : nullptr;      // bf16 residual stream (block-scaled family)
     float add[16], qs[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ru = (r & 3) + 8 * (r >> 2);
         const bool ok = !GUARD || row0 + ru + lrow < p.M;
-        if (resid) add[r] = ok ? Rt[(long)ru * p.ldc + loff] : 0.0f;
+        if (resid && OUT_BF16) add[r] = ok ? bf16_bits_to_f32(Rbt[(long)ru * p.ldc + loff]) : 0.0f;
+        else if (resid) add[r] = ok ? Rt[(long)ru * p.ldc + loff] : 0.0f;
         if (SCALED) qs[r] = ok ? qa[ru + lrow] * qw : 0.0f;
     }
     float* Ct = OUT_BF16 ? nullptr : p.C + (long)row0 * p.ldc + col0;
@@ -214,6 +216,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             return;
         }
         if (ALLOW_BF16_OUT && p.out_bf16) {
+            if (!ALLOW_SCALED && p.epi == EPI_BIAS_RESIDUAL) {      // block-scaled family: bf16 residual stream, updated in place
+                plain_epilogue<EPI_BIAS_RESIDUAL, true, false>(p, acc, row_w, col_w, l31, lh);
+                return;
+            }
             switch (p.epi) {      // bf16 outputs feed the next bf16 GEMM: bias (+ GELU / ReLU) only
                 case EPI_BIAS_GELU: plain_epilogue<EPI_BIAS_GELU, true, false, RGELU>(p, acc, row_w, col_w, l31, lh); break;
                 case EPI_BIAS_RELU: plain_epilogue<EPI_BIAS_RELU, true, false>(p, acc, row_w, col_w, l31, lh); break;

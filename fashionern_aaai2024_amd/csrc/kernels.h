@@ -101,6 +101,9 @@ struct GemmParams {
     const unsigned short* Ab;
     const unsigned short* Wb;
     int out_bf16;                 // plain epilogues: store C as bf16 (ldc in elements) instead of fp32
+    // block-scaled family, EPI_BIAS_RESIDUAL with out_bf16: the residual stream itself is bf16 (Rb [M, ldc] bf16 in, C bf16 out,
+    // may alias): C = bf16(acc + bias + float(Rb)) -- one rounding per residual add (FERN_PREC_MX8's token stream, api.hip)
+    const unsigned short* Rb;
     // fp8 (OCP e4m3fn) operand form: Ab / Wb point at fp8 bytes (strides in elements = bytes), K % 64 == 0; the quantisation
     // scales are folded back in the epilogue: C = acc * scale_a[row] * scale_w[col] (+ bias ...)
     int fp8;
@@ -268,7 +271,7 @@ hipError_t launch_quantize_rows_fp8(const unsigned short* x_bf16, const float* x
 // max|block| * 2^-(e-127) <= 448 (clamped to [1, 253]; an all-zero block gets 1), y = fp8(x * 2^(127-e)) (exact scaling, RNE cast).
 // Scales in the mx_scale_offset layout with `srows` rows.  d % 128 == 0, d <= 4096.  LayerNorm-fused, bf16-row and fp32-row forms.
 hipError_t launch_layernorm_mx8(const float* x, const float* gamma, const float* beta, unsigned char* y, unsigned char* scales, long srows,
-                                long rows, int d, long ldx, long ldy, float eps, hipStream_t s);
+                                long rows, int d, long ldx, long ldy, float eps, hipStream_t s, const unsigned short* x_bf16 = nullptr /* when set: the rows are bf16 (x unused) */);
 hipError_t launch_quantize_mx8(const unsigned short* x_bf16, const float* x_f32, long ldx, unsigned char* y, long ldy, unsigned char* scales,
                                long srows, long rows, int d, hipStream_t s);
 // patch rows [b * grid * grid, 3 * patch * patch] of an image batch ((channel, y, x) order = conv1's weight layout), MX-quantised
@@ -326,6 +329,7 @@ hipError_t launch_u8_to_chw(const unsigned char* src, long src_ld, int x0, int y
 
 // ---- bf16 gallery sweep (sweep_bf16.hip) ---------------------------------------------------------------------------
 hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStream_t s);
+hipError_t launch_bf16_to_f32(const unsigned short* x, float* y, long n, hipStream_t s);      // exact (n % 4 == 0)
 // q < B <= 64 queries against a bf16 gallery [N, D] (D % 64 == 0), fp32 accumulation.
 // Sample form (filt == null): scores[q, c] = Q[q] . G[sample_row(c, R)] for c < S, row stride ld.
 // Filter form (filt != null): nothing is stored, survivors go to filt (gate as GemmParams.gate).

@@ -36,6 +36,14 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* x, u16* y
     reinterpret_cast<ushort4*>(y)[i] = o;
 }
 
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const u16* x, float* y, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const uint2 w = reinterpret_cast<const uint2*>(x)[i];
+    const f32x4 o = {__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
+    reinterpret_cast<f32x4*>(y)[i] = o;
+}
+
 constexpr int ROWS_T = 32;              // gallery rows per wave tile
 constexpr int KSTAGE = 64;              // k elements per ring stage (128 bytes per row)
 constexpr int STAGE_BYTES = ROWS_T * KSTAGE * 2;   // 4096
@@ -291,6 +299,13 @@ hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStre
     if (n <= 0) return hipSuccess;
     if (n & 3) return hipErrorInvalidValue;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, y, n / 4);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16_to_f32(const unsigned short* x, float* y, long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, y, n / 4);
     return hipGetLastError();
 }
 

@@ -455,32 +455,64 @@ __global__ __launch_bounds__(256) void topk_candidates_kernel(TopkFilter f, int 
 
 // ---- exact pass ---------------------------------------------------------------------------------------------------------------
 // Runs (gated on flags[0]) for the queries the select kernel sent here.  One launch of `groups` workgroups; workgroup g, wave w
-// owns the 32-row gallery tiles (4g + w) + j * 4 * groups.  A tile's scores come from the SAME MFMA sequence as the sweep kernels
-// -- fp32: v_mfma_f32_32x32x2_f32 per 8-group g8 and e = 0..3 with lane half h feeding k = 8 g8 + 4 h + e (gemm.hip); bf16:
+// owns the 32-row gallery tiles (4g + w) + j * 4 * groups.  The flagged queries are compacted (in query order) and taken 32 AT A
+// TIME as the 32 A rows of the tile MFMAs -- ONE gallery pass per 32 flagged queries (round 3 broadcast one query to all 32 rows:
+// a pass per query, 1/32 of the MFMA).  A tile's scores come from the SAME MFMA sequence as the sweep kernels -- fp32:
+// v_mfma_f32_32x32x2_f32 per 8-group g8 and e = 0..3 with lane half h feeding k = 8 g8 + 4 h + e (gemm.hip); bf16:
 // v_mfma_f32_32x32x16_bf16 per 16-k step with lane half h feeding k = 16 ks + 8 h .. + 7, the query rounded to bf16 like
-// sweep_bf16.hip does -- with the query broadcast to all 32 A rows, so lane n & 31 ends up with the bit-identical score of gallery
-// row n.  Keys that reach the query's (still valid) sampled bound are offered to the wave's sorted list; the four wave lists are
-// merged through LDS into partial[b][g], and the last workgroup to finish a query (a ticket in done[b]) merges the partial lists
-// and writes the ranking.  Nothing here has a capacity: whatever the gallery looks like, the result is the exact top-K.
+// sweep_bf16.hip does -- so register r of lane (n & 31) + 32 h holds the bit-identical score of gallery row n for query
+// (r & 3) + 8 (r >> 2) + 4 h of the chunk.  Keys that reach a query's (still valid) sampled bound are offered to that query's sorted
+// list of the wave (64 entries, one per lane, kept in LDS: lists[wave][query]); after the pass the four wave lists of a query are
+// merged into partial[b][g], and the last workgroup to finish a query (a ticket in done[b]) merges the partial lists and writes the
+// ranking.  Nothing here has a capacity: whatever the gallery looks like, the result is the exact top-K.
 typedef float f32x16e __attribute__((ext_vector_type(16)));
 typedef float f32x4e __attribute__((ext_vector_type(4)));
 typedef short bf16x8e __attribute__((ext_vector_type(8)));
+constexpr int EXACT_QB = 32;                    // flagged queries per gallery pass (the A rows of one MFMA tile)
 template <bool BF16>
 __global__ __launch_bounds__(256) void rank_exact_kernel(const float* q, const void* gallery, int B, long N, int D, int K, const int* state,
                                                          const u64* thr_key, const int* exclude, long exclude_off, long idx_offset,
                                                          u64* partial, int* done, float* out_scores, int* out_idx, const int* gate) {
     if (*gate == 0) return;
-    __shared__ u64 lists[4][64];
-    __shared__ int last;
+    __shared__ u64 lists[4][EXACT_QB][64];      // 64 KiB: every wave's sorted list of every query of the chunk
+    __shared__ int flagged[1024];               // the flagged queries in query order (a plan holds <= 1024 queries: api.hip kRankQueryChunk)
+    __shared__ u64 thr_s[EXACT_QB];
+    __shared__ long ex_s[EXACT_QB];
+    __shared__ int wtot[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int G = gridDim.x, g = blockIdx.x;
     const long ntiles = (N + 31) / 32;
-    for (int b = 0; b < B; ++b) {
-        if (state[b] == 0) continue;                               // uniform
-        const u64 thr = thr_key[b];
-        const long ex = exclude ? (long)exclude[b] - exclude_off : -1;
-        const float* qrow = q + (long)b * D;
-        u64 best = 0;
+    // compaction: thread t looks at queries 4t .. 4t + 3
+    int fl[4], cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int b = tid * 4 + u;
+        fl[u] = b < B && state[b] != 0;
+        cnt += fl[u];
+    }
+    const int incl = wave_inclusive_sum(cnt, lane);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = incl - cnt;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    const int nflag = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (fl[u]) flagged[base++] = tid * 4 + u;
+    __syncthreads();
+    for (int c0 = 0; c0 < nflag; c0 += EXACT_QB) {
+        const int nq = nflag - c0 < EXACT_QB ? nflag - c0 : EXACT_QB;       // queries of this chunk (uniform)
+        if (tid < EXACT_QB) {
+            const int b = flagged[c0 + (tid < nq ? tid : 0)];
+            thr_s[tid] = tid < nq ? thr_key[b] : ~0ull;
+            ex_s[tid] = (tid < nq && exclude) ? (long)exclude[b] - exclude_off : -1;
+        }
+        for (int i = tid; i < 4 * EXACT_QB * 64; i += 256) (&lists[0][0][0])[i] = 0;
+        __syncthreads();
+        const float* qrow = q + (long)flagged[c0 + (l31 < nq ? l31 : 0)] * D;      // this lane's A row
+        float bound[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bound[r] = filter_bound(thr_s[(r & 3) + 8 * (r >> 2) + 4 * lh]);      // +inf for the unused rows
         for (long t = (long)g * 4 + wave; t < ntiles; t += (long)G * 4) {
             const long n = t * 32 + l31;
             const long nc = n < N ? n : N - 1;
@@ -507,46 +539,66 @@ __global__ __launch_bounds__(256) void rank_exact_kernel(const float* q, const v
                     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
                 }
             }
-            u64 cand = 0;                                          // every A row is the query: acc[0] of lane n & 31 is row n's score
-            if (lane < 32 && n < N && n != ex) {
-                const u64 key = make_key(acc[0], (unsigned)n);
-                cand = key >= thr ? key : 0;
+            // which queries of the chunk have a score at or above their bound in this tile (wave-uniform bit mask)
+            unsigned qmask = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const u64 m = __ballot(n < N && !(acc[r] < bound[r]));
+                const int qa = (r & 3) + 8 * (r >> 2);
+                qmask |= ((unsigned)m != 0u ? 1u : 0u) << qa;
+                qmask |= ((unsigned)(m >> 32) != 0u ? 1u : 0u) << (qa + 4);
             }
-            wave_offer(best, cand, K, lane);
+            qmask &= nq >= 32 ? 0xFFFFFFFFu : ((1u << nq) - 1u);
+            while (qmask) {                                        // wave-uniform loop over the queries with survivors
+                const int qi = __builtin_ctz(qmask);
+                qmask &= qmask - 1;
+                const int rsel = (qi & 3) + 4 * (qi >> 3), hsel = (qi >> 2) & 1;
+                float v = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) v = rsel == r ? acc[r] : v;
+                u64 cand = 0;
+                if (lh == hsel && n < N && n != ex_s[qi]) {
+                    const u64 key = make_key(v, (unsigned)n);
+                    cand = key >= thr_s[qi] ? key : 0;
+                }
+                u64 best = lists[wave][qi][lane];
+                wave_offer(best, cand, K, lane);
+                lists[wave][qi][lane] = best;
+            }
         }
-        lists[wave][lane] = best;
         __syncthreads();
-        if (wave == 0) {
+        // wave w finishes queries w, w + 4, ...: merge the four wave lists, publish the partial list, take a ticket
+        for (int qi = wave; qi < nq; qi += 4) {
+            const int b = flagged[c0 + qi];
+            u64 best = lists[0][qi][lane];
 #pragma unroll 1
-            for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, lists[w][lane], lane);
+            for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, lists[w][qi][lane], lane);
             partial[((long)b * G + g) * 64 + lane] = best;
             __threadfence();
             int ticket = 0;
             if (lane == 0) ticket = atomicAdd(&done[b], 1);
             ticket = __builtin_amdgcn_readfirstlane(ticket);
-            if (lane == 0) last = ticket == G - 1;
-        }
-        __syncthreads();
-        if (last && wave == 0) {                                   // every other workgroup's partial list is visible (its fence precedes its ticket)
-            __threadfence();
-            u64 top = 0;
+            if (ticket == G - 1) {                                  // every other workgroup's partial list is visible (its fence precedes its ticket)
+                __threadfence();
+                u64 top = 0;
 #pragma unroll 1
-            for (int gg = 0; gg < G; ++gg) {
-                const u64 other = __hip_atomic_load(&partial[((long)b * G + gg) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                top = gg == 0 ? other : merge_sorted_desc(top, other, lane);
-            }
-            if (lane < K) {
-                float sc = -INFINITY;
-                int idx = -1;
-                if (top != 0) {
-                    sc = unorderable((unsigned)(top >> 32));
-                    idx = (int)((long)(0xFFFFFFFFu - (unsigned)top) + idx_offset);
+                for (int gg = 0; gg < G; ++gg) {
+                    const u64 other = __hip_atomic_load(&partial[((long)b * G + gg) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    top = gg == 0 ? other : merge_sorted_desc(top, other, lane);
                 }
-                out_scores[(long)b * K + lane] = sc;
-                out_idx[(long)b * K + lane] = idx;
+                if (lane < K) {
+                    float sc = -INFINITY;
+                    int idx = -1;
+                    if (top != 0) {
+                        sc = unorderable((unsigned)(top >> 32));
+                        idx = (int)((long)(0xFFFFFFFFu - (unsigned)top) + idx_offset);
+                    }
+                    out_scores[(long)b * K + lane] = sc;
+                    out_idx[(long)b * K + lane] = idx;
+                }
             }
         }
-        __syncthreads();
+        __syncthreads();                                            // the lists are re-zeroed for the next chunk
     }
 }
 
@@ -577,7 +629,7 @@ hipError_t launch_rank_exact(const float* q, const void* gallery, int gallery_bf
                              unsigned long long* partial, int groups, int* done, float* out_scores, int* out_idx, const int* gate,
                              hipStream_t s) {
     if (B <= 0 || N <= 0) return hipSuccess;
-    if (K < 1 || K > 64 || groups < 1 || D % (gallery_bf16 ? 16 : 8)) return hipErrorInvalidValue;
+    if (K < 1 || K > 64 || groups < 1 || B > 1024 || D % (gallery_bf16 ? 16 : 8)) return hipErrorInvalidValue;
     if (gallery_bf16)
         hipLaunchKernelGGL(rank_exact_kernel<true>, dim3(groups), dim3(256), 0, s, q, gallery, B, N, D, K, state, thr_key, exclude, exclude_off,
                            idx_offset, partial, done, out_scores, out_idx, gate);

@@ -377,7 +377,12 @@ class FernEngine:
         m, k = a8.shape
         n = w8.shape[0]
         bias = None if bias is None else self._f32(bias, (n,))
-        residual = None if residual is None else self._f32(residual, (m, n))
+        if residual is not None and out_bf16:      # the bf16 residual-stream form (include/fern.h: fern_gemm_mx8)
+            if residual.dtype != torch.bfloat16 or tuple(residual.shape) != (m, n):
+                raise ValueError("out_bf16 with a residual takes a bf16 [M, N] residual stream")
+            residual = residual.to(self.device).contiguous()
+        else:
+            residual = None if residual is None else self._f32(residual, (m, n))
         out = torch.empty(m, n, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=self.device)
         _lib.check(self.lib.fern_gemm_mx8(self._h, _ptr(a8), k, _ptr(sa), sa.shape[1], _ptr(w8), k, _ptr(sw), sw.shape[1], _ptr(bias),
                                           _ptr(residual), _ptr(out), n, m, n, k, int(epilogue), int(bool(out_bf16)), _stream()), "fern_gemm_mx8")

@@ -293,7 +293,9 @@ FERN_API int fern_gemm_fp8(fern_ctx* ctx, const uint8_t* A, int64_t lda, const f
  * an all-zero block gets 1), y = fp8(x * 2^(127-e)) -- the scaling is exact, the cast rounds to nearest even.
  * Scale layout (uint8, (d / 128) * scale_rows * 4 bytes): byte of (row r, block b = k / 32) at ((b / 4) * scale_rows + r) * 4 + b % 4,
  * scale_rows >= rows.  fern_gemm_mx8: C = sum over blocks of 2^(ea-127) 2^(ew-127) (A8 . W8) + bias (+ GELU | + residual), fp32
- * accumulation, scales applied inside the MFMA.  K % 128 == 0, d % 128 == 0, d <= 4096, lda / ldw % 16 == 0, ldx / ldy % 8 == 0. */
+ * accumulation, scales applied inside the MFMA.  K % 128 == 0, d % 128 == 0, d <= 4096, lda / ldw % 16 == 0, ldx / ldy % 8 == 0.
+ * FERN_EPI_BIAS_RESIDUAL with out_bf16 != 0 is the bf16 RESIDUAL-STREAM form (FERN_PREC_MX8's token stream): `residual` then points
+ * at bf16 [M, ldc] (may alias C) and C = bf16(sum + bias + float(residual)), one round-to-nearest-even per element. */
 FERN_API int fern_quantize_mx8(fern_ctx* ctx, const void* x, int x_is_bf16, int64_t ldx, uint8_t* y, int64_t ldy, uint8_t* scales,
                       int64_t scale_rows, int64_t rows, int d, void* stream);
 FERN_API int fern_gemm_mx8(fern_ctx* ctx, const uint8_t* A, int64_t lda, const uint8_t* scales_a, int64_t scale_rows_a, const uint8_t* W,

@@ -132,10 +132,12 @@ def _attention(sd, prefix, x, heads, causal, prec=None, q_rows=None):
 def _block(sd, prefix, x, heads, causal, prec=None):
     """Pre-LN residual block, modeling_clip.py:354-401; MLP :339-351 with exact GELU."""
     reduced = prec in ("bf16", "fp8", "mx8")
-    x = x + _attention(sd, prefix + ".attn", _ln(sd, prefix + ".ln_1", x), heads, causal, prec)
+    # the block-scaled mode keeps the residual stream itself in bf16 (csrc/api.hip: clip_block_mx8): one rounding per residual add
+    stream_bf16 = prec == "mx8"
+    x = _r(x + _attention(sd, prefix + ".attn", _ln(sd, prefix + ".ln_1", x), heads, causal, prec), stream_bf16)
     h = F.gelu(_linear(_ln(sd, prefix + ".ln_2", x), sd[prefix + ".mlp.c_fc.weight"], sd[prefix + ".mlp.c_fc.bias"], prec))
     # h is stored as bf16 -- except in the block-scaled mode, whose c_fc GEMM quantises its fp32 GELU output in the epilogue
-    return x + _linear(_r(h, reduced and prec != "mx8"), sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"], prec)
+    return _r(x + _linear(_r(h, reduced and prec != "mx8"), sd[prefix + ".mlp.c_proj.weight"], sd[prefix + ".mlp.c_proj.bias"], prec), stream_bf16)
 
 
 def _block_cls(sd, prefix, x, heads, prec):
@@ -215,6 +217,8 @@ def encode_image(sd, cfg, images, precision="fp32"):
     cls = sd["visual.class_embedding"].expand(x.shape[0], 1, -1)
     x = torch.cat((cls, x), dim=1) + sd["visual.positional_embedding"]  # :197-200
     x = _ln(sd, "visual.ln_pre", x)                                     # :839,866
+    if precision == "mx8" and cfg.v_layers > 1:
+        x = _r(x, True)                                                 # ln_pre writes the mode's bf16 residual stream
     for i in range(cfg.v_layers - (1 if bf16 else 0)):
         x = _block(sd, f"visual.transformer.resblocks.{i}", x, cfg.v_heads, causal=False, prec=prec)
     if bf16:
@@ -225,6 +229,8 @@ def encode_image(sd, cfg, images, precision="fp32"):
 
 def text_hidden(sd, cfg, text, precision="fp32"):
     x = sd["token_embedding.weight"][text] + sd["positional_embedding"][: text.shape[1]]   # :204-232
+    if precision == "mx8":
+        x = _r(x, True)                                                 # the block-scaled mode's bf16 residual stream
     for i in range(cfg.t_layers):
         x = _block(sd, f"transformer.resblocks.{i}", x, cfg.t_heads, causal=True, prec=None if precision == "fp32" else precision)
     return _ln(sd, "ln_final", x)                                       # :750

@@ -458,7 +458,7 @@ def test_quantize_mx8_is_bit_exact(engine, rows, d, bf16):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,n,k", [(64, 128, 128), (197, 384, 256), (1000, 520, 640), (4096, 768, 768), (333, 2304, 768)])
-@pytest.mark.parametrize("epi,out_bf16", [(0, False), (0, True), (1, True), (3, False)])
+@pytest.mark.parametrize("epi,out_bf16", [(0, False), (0, True), (1, True), (3, False), (3, True)])
 def test_gemm_mx8(engine, m, n, k, epi, out_bf16):
     """Block-scaled fp8 GEMM (v_mfma_scale_f32_32x32x64_f8f6f4) against fp64 math on the SAME quantised operands and scales."""
     from oracle.clip import mx8_dequantize
@@ -476,6 +476,22 @@ def test_gemm_mx8(engine, m, n, k, epi, out_bf16):
         ref = torch.nn.functional.gelu(ref)
     elif epi == 3:
         ref = ref + r.double()
+    if epi == 3 and out_bf16:
+        # the bf16 residual-stream form (FERN_PREC_MX8's token stream): bf16 residual in, C = bf16(acc + bias + residual) -- ONE rounding
+        rb = r.bfloat16()
+        ref = qa @ qw.T + b.double() + rb.double()
+        got = engine.gemm_mx8(a8, sa, w8, sw, b, residual=rb, epilogue=3, out_bf16=True)
+        f32 = engine.gemm_mx8(a8, sa, w8, sw, b, residual=rb.float(), epilogue=3, out_bf16=False)
+        assert got.dtype == torch.bfloat16 and torch.equal(got.cpu(), f32.cpu().bfloat16())      # exactly the fp32 epilogue's value, rounded once
+        assert torch.allclose(got.float().cpu().double(), ref, rtol=2 ** -7, atol=1e-3)
+        inplace = rb.cuda().clone()                                                                 # R == C: the stream is updated in place
+        from fashionern_aaai2024_amd import _lib
+        from fashionern_aaai2024_amd.engine import _ptr, _stream
+        bias_d = b.cuda()
+        _lib.check(engine.lib.fern_gemm_mx8(engine._h, _ptr(a8), k, _ptr(sa), sa.shape[1], _ptr(w8), k, _ptr(sw), sw.shape[1], _ptr(bias_d),
+                                            _ptr(inplace), _ptr(inplace), n, m, n, k, 3, 1, _stream()), "fern_gemm_mx8")
+        assert torch.equal(inplace.cpu(), got.cpu())
+        return
     got = engine.gemm_mx8(a8, sa, w8, sw, b, residual=r if epi == 3 else None, epilogue=epi, out_bf16=out_bf16)
     if out_bf16:
         assert got.dtype == torch.bfloat16 and torch.allclose(got.float().cpu().double(), ref, rtol=2 ** -7, atol=1e-3)

@@ -144,6 +144,11 @@ if mode == "cluster":
     gal[:4096] = torch.where(gal[:4096] * q[0] > 0, -gal[:4096], gal[:4096])       # sampled rows: never positive against query 0
     gal[4096:] = torch.sign(q[0]) / 8.0 * (torch.rand(904, 64, generator=g) < 0.9)  # the rest: strongly positive, all different
     k = 10
+elif mode == "many":
+    # 70 queries, tie-heavy scores, lists of ONE entry: (nearly) every query overflows -> the exact pass takes them 32 at a time as the
+    # A rows of its MFMA tiles (three chunks: 32 + 32 + 6), ragged last gallery tile (N % 32 != 0)
+    q, gal = unit(70, 64), unit(3001, 64)
+    k = 50
 else:
     # lists of ONE entry, all scores equal, K = 64: every list overflows for every query -- the case that used to end in NaN / -1
     # and an error at the next sync.  The exact pass must return rows 0..63 (ties -> lower index) with the common score.
@@ -165,7 +170,7 @@ print("OK")
 """
 
 
-@pytest.mark.parametrize("cap,mode", [("4", "cluster"), ("1", "all-equal")])
+@pytest.mark.parametrize("cap,mode", [("4", "cluster"), ("1", "all-equal"), ("1", "many")])
 def test_forced_tiny_lists_go_through_the_exact_pass(cap, mode):
     """FERN_RANK_CAP (test hook, read once per process) shrinks the candidate lists so that they overflow; the result must
     still be the oracle's, bit for bit (the stage is exact by construction, no NaN rows, no late error)."""
