@@ -124,6 +124,58 @@ def other_config_lines(steps: int) -> dict:
     return out
 
 
+def multi_gpu_preflight(torch, dist, fd, rank, world, local, device, backend):
+    """`--gpus N`, N > 1: before any model work, every rank reports where it runs and the job times the path's one collective
+    shape on the wire -- so that the first run on a real multi-GPU node is self-diagnosing: RCCL world size,
+    per-rank device (index, name, PCI bus id), two ranks on one device (refused unless the FERN_BENCH_SHARE_GPU debug layout), and
+    the all-gather rate of 64 MiB-per-rank bf16 blocks (the C5 shard is 128 MB) against 7 x 153 GB/s of xGMI.  Printed to stderr by
+    rank 0 and carried in the JSON line under `preflight`."""
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "local_rank": local, "device": device.index, "name": props.name, "host": socket.gethostname(),
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "hsa_ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    seen = {}
+    for e in everyone:
+        key = (e["host"], e["device"])
+        if key in seen and not os.environ.get("FERN_BENCH_SHARE_GPU"):
+            raise SystemExit(f"bench preflight: ranks {seen[key]} and {e['rank']} both run on {key}: one process per GPU is the layout "
+                             "(LOCAL_RANK -> cuda:LOCAL_RANK); set FERN_BENCH_SHARE_GPU=1 only for the one-GPU debug rehearsal")
+        seen[key] = e["rank"]
+    per = 64 << 20
+    block = torch.full((per // 2,), float(rank), dtype=torch.bfloat16, device=device)
+    out = torch.empty((world * (per // 2),), dtype=torch.bfloat16, device=device)
+    fd._all_gather_into(out, block)                      # connection set-up, workspaces
+    torch.cuda.synchronize()
+    dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    ev0.record()
+    for _ in range(reps):
+        fd._all_gather_into(out, block)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    ok = bool((out.view(world, -1)[:, 0].float().cpu() == torch.arange(world, dtype=torch.float32)).all())
+    t = torch.tensor([ms], dtype=torch.float64, device=device)
+    if backend == "gloo":
+        th = t.cpu()
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        ms = th.item()
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = t.item()
+    recv = (world - 1) * per
+    info = {"rccl_world": world if backend == "nccl" else f"{world} (debug backend {backend})", "backend": backend, "ranks": everyone,
+            "all_gather_64MiB_per_rank": {"ms": ms, "bytes_received_per_rank": recv, "GBs_per_rank": recv / (ms * 1e-3) / 1e9,
+                                          "frac_of_xgmi": recv / (ms * 1e-3) / 1e9 / XGMI_PEAK_GBS, "payload_ok": ok}}
+    if rank == 0:
+        print("[bench preflight] " + json.dumps(info), file=sys.stderr, flush=True)
+    if not ok:
+        raise SystemExit("bench preflight: the all-gather returned the wrong blocks")
+    return info
+
+
 def _timed(fn):
     t0 = time.perf_counter()
     fn()
@@ -249,6 +301,7 @@ def main():
     D, B, K, n_gal = w["d"], w["batch"], w["k"], w["gallery"]
     backend = dist.get_backend() if world > 1 else None
     gloo = backend == "gloo"
+    preflight = multi_gpu_preflight(torch, dist, fd, rank, world, local, device, backend) if world > 1 else None
 
     def dev_randn(shape, seed):
         g = torch.Generator(device=device)
@@ -607,6 +660,7 @@ def main():
             "ms_per_step_event_median": gap_median,
             "latency_ms_per_batch": headline_latency,
             "rccl_world": world if backend == "nccl" else (1 if world == 1 else f"{world} (debug backend {backend})"),
+            "preflight": preflight,
             "all_gather": {"ms": ag_ms if world > 1 else 0.0, "bytes_received_per_rank": ag_bytes,
                            "GBs_per_rank": (ag_bytes / (ag_ms * 1e-3) / 1e9) if world > 1 and ag_ms > 0 else None,
                            "xgmi_peak_GBs_per_gpu": XGMI_PEAK_GBS,

@@ -37,3 +37,26 @@ def test_bench_line_has_the_contract_keys(config):
     roof = d["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and "traffic" in roof
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_preflight_and_latency_keys():
+    """`bench.py --gpus 2` (two ranks sharing this box's one GPU over gloo: the debug layout; on a multi-GPU node the same command is
+    one rank per GPU over RCCL): the pre-flight block reports every rank's device and the all-gather rate, two ranks on one device
+    are refused without the debug switch, and the line carries the per-batch latency and the roofline regime label."""
+    env = dict(os.environ, FERN_DIST_BACKEND="gloo", FERN_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c4", "--steps", "2", "--warmup", "1", "--headline-only",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "[bench preflight]" in r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    pf = d["preflight"]
+    assert d["n_gpus"] == 2 and len(pf["ranks"]) == 2 and {e["rank"] for e in pf["ranks"]} == {0, 1}
+    assert pf["all_gather_64MiB_per_rank"]["payload_ok"] and pf["all_gather_64MiB_per_rank"]["bytes_received_per_rank"] == 64 << 20
+    lat = d["latency_ms_per_batch"]
+    assert lat["p50"] > 0 and lat["p99"] >= lat["p50"] and lat["batches"] == 2
+    assert d["roofline"]["regime"].startswith("serial_passes") and d["roofline"]["step_level"]["frac"] <= 1.0
+    env.pop("FERN_BENCH_SHARE_GPU")
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r2.returncode != 0      # one GPU here: rank 1 has no cuda:1 (on a node where two ranks name one device the pre-flight refuses)

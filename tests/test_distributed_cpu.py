@@ -159,3 +159,79 @@ def test_harness_under_torch_distributed_reproduces_reference_recalls(tmp_path, 
         for kind in ("fiq", "cirr", "200k", "shoes", "val"):
             assert got[kind] == meta["recalls"][kind], (r, kind, got[kind], meta["recalls"][kind])
         assert np.abs(np.array(got["fiq_pred"], dtype=np.float32) - gold["fiq_predicted"]).max() < 1e-6
+
+
+class _TunerStub:
+    """The two tuner entry points `share_gemm_tiles` uses (engine.tuner_export / tuner_import), without a GPU."""
+
+    def __init__(self, text):
+        self.text = text
+
+    def tuner_export(self):
+        return self.text
+
+    def tuner_import(self, text):
+        self.text = text
+
+
+def _world8_worker(rank, world, port, out_dir):
+    """every collective helper of the path at WORLD = 8 over gloo with the block types the GPU job moves --
+    bf16 gallery shards and int32 index blocks as BYTE views (no dtype support needed from the backend: the RCCL call sees uint8
+    too), fp32 score blocks, ragged gathers with objects, the tuner-plan broadcast, and the sharded ranking's candidate gathers."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from oracle_engine import OracleEngine
+    from fashionern_aaai2024_amd import distributed as fd
+    from fashionern_aaai2024_amd import synth
+    r, w, _ = fd.init_from_env("gloo")
+    assert (r, w) == (rank, world) and fd.world_info() == (rank, world)
+    n, d, k = 1003, 64, 9                                              # ragged: the last shard is short
+    start, stop, per = fd.shard_rows(n, rank, world)
+    full = torch.from_numpy(synth.unit_rows(n, d, tag="w8"))
+    # (1) bf16 shards through _all_gather_into / all_gather_shards, also into a pre-allocated store (`out=`, bench.py's gallery store)
+    blk = torch.zeros((per, d), dtype=torch.bfloat16)
+    blk[: stop - start] = full[start:stop].bfloat16()
+    assert torch.equal(fd.all_gather_shards(blk, n), full.bfloat16())
+    store = torch.empty((world * per, d), dtype=torch.bfloat16)
+    view = fd.all_gather_shards(blk, n, out=store)
+    assert view.data_ptr() == store.data_ptr() and torch.equal(view, full.bfloat16())
+    with pytest.raises(ValueError):
+        fd.all_gather_shards(blk, n, out=torch.empty((world * per, d), dtype=torch.float32))
+    # (2) int32 and fp32 blocks through _all_gather_into directly (the [B, K] candidate blocks of the sharded ranking)
+    idx = (torch.arange(5 * k, dtype=torch.int32).view(5, k) + 1000 * rank)
+    out_i = torch.empty((world * 5, k), dtype=torch.int32)
+    fd._all_gather_into(out_i, idx)
+    assert torch.equal(out_i, torch.cat([torch.arange(5 * k, dtype=torch.int32).view(5, k) + 1000 * q for q in range(world)]))
+    sc = torch.full((5, k), float(rank) + 0.5)
+    out_s = torch.empty((world * 5, k))
+    fd._all_gather_into(out_s, sc)
+    assert torch.equal(out_s.view(world, 5, k)[:, 0, 0], torch.arange(world, dtype=torch.float32) + 0.5)
+    # (3) gather_rows / gather_ragged (different row counts per rank, objects travel with the rows)
+    assert torch.equal(fd.gather_rows(idx), out_i)
+    mine = full[start:stop]
+    names = [f"row{j}" for j in range(start, stop)]
+    allx, allnames = fd.gather_ragged(mine, names)
+    assert torch.equal(allx, full) and allnames == [f"row{j}" for j in range(n)]
+    assert torch.equal(fd.gather_ragged(mine[: rank % 3]), torch.cat([full[fd.shard_rows(n, q, world)[0]:][: q % 3] for q in range(world)]))
+    # (4) the tuner-plan broadcast: every rank adopts rank 0's text
+    stub = _TunerStub(f"f32 12608 2304 768 0 0 {20 + rank % 2} 10880 12608\nmx8 12608 768 768 3 4 {rank}\n")
+    fd.share_gemm_tiles(stub)
+    assert stub.text == "f32 12608 2304 768 0 0 20 10880 12608\nmx8 12608 768 768 3 4 0\n"
+    # (5) sharded ranking == replicated ranking (candidate all-gathers + merge at world 8), with an excluded row per query
+    eng = OracleEngine()
+    q = torch.from_numpy(synth.unit_rows(6, d, tag="w8q"))
+    ex = torch.tensor([3, -1, n - 1, 0, 500, -1], dtype=torch.int32)
+    s_sh, i_sh = fd.rank_sharded(eng, q, full[start:stop], start, k, exclude_idx=ex)
+    s_re, i_re = fd.rank_replicated(eng, q, full, k, exclude_idx=ex)
+    assert torch.equal(i_sh, i_re) and torch.equal(s_sh, s_re)
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_collectives_move_bf16_and_int32_blocks_as_bytes(tmp_path):
+    port = _free_port()
+    mp.spawn(_world8_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(8)]
