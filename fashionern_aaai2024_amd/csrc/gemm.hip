@@ -777,7 +777,7 @@ static bool mixed_plan_ok(const Plan& pl, int M) {
 static std::map<ShapeKey, Plan> g_tuned;
 static std::mutex g_tuned_mu;
 static std::map<ShapeKey, Plan>& tuned_split_map();     // the f32x3 family's choices (defined with that family below)
-constexpr int kNumCfgsS = 6;                             // ... and its number of single configurations
+constexpr int kNumCfgsS = 7;                             // ... and its number of single configurations
 
 // FERN_GEMM_TILES=<file>: pin the per-shape choices (lines "f32 M N K epi aload cfg [rows_a cfg_b]", as written by gemm_tuner_export /
 // fern_tuner_export): listed shapes are never timed again, so a run's kernels -- and its HBM / L2 traffic -- are reproducible
@@ -1026,7 +1026,12 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
 // The planes of a wave tile are 12 VGPRs per 32-row fragment, so the configurations trade occupancy for room: the 128x128 tile at
 // <= 170 VGPRs (three workgroups per CU), the macro-tiles on four fat waves (wave tile 128x64 / 64x128, two workgroups per CU),
 // and the small tiles at the usual 128.  All bit-identical to each other; tuned per shape like the fp32 family.
-static const TileCfg kCfgsS[kNumCfgsS] = {{128, 128, 16, 1.f}, {256, 128, 16, 1.f}, {128, 256, 16, 1.f}, {64, 128, 16, 1.f}, {128, 64, 16, 1.f}, {64, 64, 16, 1.f}};
+// 6 (round 4): 256x256 on EIGHT fat waves (wave tile 128x64, one workgroup per CU).  The bf16 MFMAs of this family retire an fp32 k pair
+// in 6 x 32 cycles instead of 2 x 64, so the tile's L2 -> LDS bytes are due 2.67x sooner than in the fp32 kernel: the 256x128 tile on
+// four fat waves needs 32 B/clk per workgroup (two per CU: 64) of a path that delivers ~33 B/clk per CU -- copy-bound at about half the
+// MFMA rate, which is the 1.5x the family measured.  256x256 stages 32 KiB per 3 072 MFMA cycles per SIMD: 10.7 B/clk.
+static const TileCfg kCfgsS[kNumCfgsS] = {{128, 128, 16, 1.f}, {256, 128, 16, 1.f}, {128, 256, 16, 1.f}, {64, 128, 16, 1.f}, {128, 64, 16, 1.f}, {64, 64, 16, 1.f},
+                                          {256, 256, 16, 1.f}};
 static bool split_family_ok(const GemmParams& p) {
     return p.split == 3 && split_ok(p) && p.M >= 256 && p.K % 16 == 0;
 }
@@ -1039,6 +1044,7 @@ static hipError_t launch_cfg_split(int c, const GemmParams& p, hipStream_t s) {
         case 3: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
         case 4: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
         case 5: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 6: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 256, 128, 64, 16, 2, false, 0, false, 3>), dim3(nb), dim3(512), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1,6 +1,7 @@
 """Kernel-level parity through the C ABI (fern_gemm / fern_layernorm / fern_attention / rank ops)
 against plain torch fp32/fp64 CPU references of the same op."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -85,7 +86,8 @@ ATTN_CASES = [  # batch, heads, hd, s_q, s_k, causal
     (2, 12, 64, 197, 197, False), (3, 8, 64, 77, 77, True), (2, 8, 64, 91, 91, False), (2, 8, 80, 91, 91, False),
     (3, 8, 16, 91, 91, False), (2, 8, 64, 13, 13, False), (2, 8, 80, 13, 13, False), (2, 4, 32, 17, 17, False),
     (2, 3, 64, 10, 10, False), (2, 4, 32, 77, 77, True), (1, 2, 64, 77, 77, True), (2, 10, 64, 77, 77, True),
-    (1, 1, 32, 33, 33, True), (2, 2, 16, 5, 40, False), (1, 12, 64, 224, 224, False), (2, 8, 16, 13, 13, False)]
+    (1, 1, 32, 33, 33, True), (2, 2, 16, 5, 40, False), (1, 12, 64, 224, 224, False), (2, 8, 16, 13, 13, False),
+    (1, 3, 64, 77, 77, True), (2, 2, 96, 70, 70, True), (2, 10, 80, 77, 77, True)]      # odd head count, head dims 96 / 80 on the causal 3-tile shape
 
 
 @pytest.mark.parametrize("b,heads,hd,sq,sk,causal", ATTN_CASES)

@@ -30,8 +30,10 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="per-row-scaled fp8 kernel (FERN_GEMM_FP8_CFG)")
     ap.add_argument("--mx8", action="store_true", help="block-scaled fp8 kernel (FERN_GEMM_MX8_CFG)")
     ap.add_argument("--mx8q", action="store_true", help="with --mx8: quantising epilogue (fp8 + block scales out) on the BIAS / GELU shapes")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f32x3"], help="fp32 family arithmetic (FERN_GEMM_SPLIT_CFG picks the f32x3 tile)")
     args = ap.parse_args()
     eng = FernEngine("cuda:0")
+    eng.set_precision(args.precision)
     groups = SHAPES if args.shapes == "all" else {args.shapes: SHAPES[args.shapes]}
     tot_ms = tot_fl = 0.0
     for gname, shapes in groups.items():
