@@ -102,7 +102,19 @@ struct ClipW {
 };
 
 enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_TOPK = 2, PROF_SWEEP = 3 };
-struct ProfRec { hipEvent_t a, b; int kind; double work; int m, n, k, tag; int dispatches; };
+struct ProfRec { hipEvent_t a, b; int kind; double work; int m, n, k, tag; int dispatches;
+                 std::vector<hipEvent_t> kev; /* kernel-precise (start, stop) pairs of the launch's dispatches (kernels.h: LaunchTimer); empty: a, b are stream events */ };
+
+namespace fern {
+thread_local LaunchTimer* g_launch_timer = nullptr;
+hipEvent_t launch_timer_event() {
+    LaunchTimer* t = g_launch_timer;
+    hipEvent_t e = nullptr;
+    if (t && t->pool && !t->pool->empty()) { e = t->pool->back(); t->pool->pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace fern
 
 struct fern_ctx {
     int device = 0;
@@ -134,6 +146,7 @@ struct fern_ctx {
     bool prof_on = false;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> ev_pool;
+    LaunchTimer timer;
 };
 
 static int ws_begin(fern_ctx* c, hipStream_t s) {
@@ -175,21 +188,37 @@ static int ws_get(fern_ctx* c, size_t count, T** out) {
 }
 
 // ---- profiling hooks ----------------------------------------------------------------------------
+// GEMM and attention launches (kinds whose roofline is a per-KERNEL figure): timed by the dispatches' own timestamps
+static bool prof_kernel_precise(int kind) { return kind == PROF_GEMM || kind == PROF_ATTN; }
 static int prof_open(fern_ctx* c, int kind, double work, hipStream_t s, int* slot, int m = 0, int n = 0, int k = 0, int tag = 0) {
     *slot = -1;
     if (!c->prof_on) return FERN_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (prof_kernel_precise(kind) && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+        c->recs.push_back({nullptr, nullptr, kind, work, m, n, k, tag, 1, {}});
+        *slot = (int)c->recs.size() - 1;
+        c->timer.events.clear();
+        c->timer.pool = &c->ev_pool;
+        g_launch_timer = &c->timer;      // armed: the launch's dispatches go through hipExtLaunchKernelGGL (kernels.h: FERN_LAUNCH)
+        return FERN_OK;
+    }
     hipEvent_t ev[2];
     for (int i = 0; i < 2; ++i) {
         if (!c->ev_pool.empty()) { ev[i] = c->ev_pool.back(); c->ev_pool.pop_back(); }
         else HIP_TRY(hipEventCreate(&ev[i]));
     }
     HIP_TRY(hipEventRecord(ev[0], s));
-    c->recs.push_back({ev[0], ev[1], kind, work, m, n, k, tag, 1});
+    c->recs.push_back({ev[0], ev[1], kind, work, m, n, k, tag, 1, {}});
     *slot = (int)c->recs.size() - 1;
     return FERN_OK;
 }
 static int prof_close(fern_ctx* c, int slot, hipStream_t s) {
     if (slot < 0) return FERN_OK;
+    if (!c->recs[slot].a) {              // kernel-precise record: collect the event pairs of its dispatches, disarm
+        g_launch_timer = nullptr;
+        c->recs[slot].kev.swap(c->timer.events);
+        return FERN_OK;
+    }
     HIP_TRY(hipEventRecord(c->recs[slot].b, s));
     return FERN_OK;
 }
@@ -197,12 +226,16 @@ static int prof_close(fern_ctx* c, int slot, hipStream_t s) {
 static int run_gemm(fern_ctx* c, const GemmParams& p, hipStream_t s, int kind = PROF_GEMM, double work = -1.0) {
     int slot;
     FERN_TRY(prof_open(c, kind, work >= 0 ? work : 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, p.epi));
+    hipError_t le;
     if (c->f32x3 && kind == PROF_GEMM && p.w_sample <= 1) {      // FERN_PREC_F32X3: never the ranking stage (PROF_SWEEP / sample pass)
         GemmParams q = p;
         q.split = 3;                                             // launch_gemm falls back to the fp32 kernels where the split family does not apply
-        HIP_TRY(launch_gemm(q, s));
-    } else
-    HIP_TRY(launch_gemm(p, s));
+        le = launch_gemm(q, s);
+    } else {
+        le = launch_gemm(p, s);
+    }
+    g_launch_timer = nullptr;                                    // (prof_close collects the events; a failed launch must not leave the timer armed)
+    HIP_TRY(le);
     if (slot >= 0) c->recs[slot].dispatches = gemm_last_dispatches();
     return prof_close(c, slot, s);
 }
@@ -240,13 +273,17 @@ static GemmParams gemm_desc_mx(const unsigned char* A8, const unsigned char* sa,
 static int run_gemm_b(fern_ctx* c, const GemmParams& p, hipStream_t s) {
     int slot;
     FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, (p.fp8 == 2 ? 300 : p.fp8 ? 200 : 100) + p.epi));
-    HIP_TRY(launch_gemm_bf16(p, s));
+    const hipError_t le = launch_gemm_bf16(p, s);
+    g_launch_timer = nullptr;
+    HIP_TRY(le);
     return prof_close(c, slot, s);
 }
 static int run_attention(fern_ctx* c, const AttnParams& a, hipStream_t s) {
     int slot;
     FERN_TRY(prof_open(c, PROF_ATTN, 4.0 * a.batch * a.heads * (double)a.s_q * a.s_k * a.hd, s, &slot, a.batch * a.heads, a.s_q, a.hd, a.causal));
-    HIP_TRY(launch_attention(a, s));
+    const hipError_t le = launch_attention(a, s);
+    g_launch_timer = nullptr;
+    HIP_TRY(le);
     return prof_close(c, slot, s);
 }
 
@@ -423,7 +460,10 @@ extern "C" int fern_ctx_destroy(fern_ctx* c) {
         for (void* p : grp) (void)hipFree(p);
     if (c->tok_flag) (void)hipHostFree(c->tok_flag);
     for (auto& b : c->blocks) (void)hipFree(b.p);
-    for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& r : c->recs) {
+        if (r.a) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (hipEvent_t e : r.kev) (void)hipEventDestroy(e);
+    }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
     return FERN_OK;
@@ -1681,7 +1721,9 @@ extern "C" int fern_gemm_bf16(fern_ctx* c, const uint16_t* A, int64_t lda, const
     p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.aload = ALOAD_PLAIN; p.out_bf16 = out_bf16 ? 1 : 0;
     int slot;
     FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * M * (double)N * K, (hipStream_t)stream, &slot, M, N, K, 100 + epilogue));
-    HIP_TRY(launch_gemm_bf16(p, (hipStream_t)stream));
+    const hipError_t le = launch_gemm_bf16(p, (hipStream_t)stream);
+    g_launch_timer = nullptr;
+    HIP_TRY(le);
     return prof_close(c, slot, (hipStream_t)stream);
 }
 
@@ -1843,6 +1885,15 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
     FILE* dump = dump_path ? std::fopen(dump_path, "a") : nullptr;
     for (auto& r : c->recs) {
         float ms = 0.f;
+        if (!r.a) {                      // kernel-precise: the sum of the dispatches' own durations
+            for (size_t i = 0; i + 1 < r.kev.size(); i += 2) {
+                float one = 0.f;
+                HIP_TRY(hipEventElapsedTime(&one, r.kev[i], r.kev[i + 1]));
+                ms += one;
+            }
+            for (hipEvent_t e : r.kev) c->ev_pool.push_back(e);
+            r.kev.clear();
+        } else
         HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
         if (dump) std::fprintf(dump, "%d,%d,%d,%d,%d,%.6f,%.0f\n", r.kind, r.m, r.n, r.k, r.tag, ms, r.work);
         switch (r.kind) {
@@ -1858,8 +1909,7 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
             case PROF_TOPK: out->topk_ms += ms; out->topk_launches++; break;
             default: out->sweep_ms += ms; out->sweep_bytes += r.work; out->sweep_launches++; break;
         }
-        c->ev_pool.push_back(r.a);
-        c->ev_pool.push_back(r.b);
+        if (r.a) { c->ev_pool.push_back(r.a); c->ev_pool.push_back(r.b); }
     }
     c->recs.clear();
     if (dump) std::fclose(dump);

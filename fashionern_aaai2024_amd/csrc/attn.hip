@@ -467,7 +467,7 @@ static hipError_t launch_inst_b(const AttnParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.batch * p.heads), dim3(NW * 64), lds, s, p);
+    FERN_LAUNCH(kern, dim3(p.batch * p.heads), dim3(NW * 64), lds, s, p);
     return hipGetLastError();
 }
 
@@ -497,7 +497,7 @@ static hipError_t launch_inst(const AttnParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.batch * p.heads), dim3(NW * 64), lds, s, p);
+    FERN_LAUNCH(kern, dim3(p.batch * p.heads), dim3(NW * 64), lds, s, p);
     return hipGetLastError();
 }
 
@@ -522,7 +522,7 @@ static hipError_t launch_hd(const AttnParams& p, hipStream_t s) {
                 if (e != hipSuccess) return e;
                 attr_set = true;
             }
-            hipLaunchKernelGGL(kern, dim3(p.batch * p.heads), dim3(8 * 64), lds, s, p);
+            FERN_LAUNCH(kern, dim3(p.batch * p.heads), dim3(8 * 64), lds, s, p);
             return hipGetLastError();
         }
         return launch_inst<HDP, 7, false>(p, s);

@@ -702,40 +702,40 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
     if (p.epi == EPI_TOPK_FILTER) {      // the filtered sweep: LDS-DMA family, own instantiations
         if (p.aload != ALOAD_PLAIN) return hipErrorInvalidValue;
         switch (c) {
-            case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
-            case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
-            case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
-            case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 8: FERN_LAUNCH((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 9: FERN_LAUNCH((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 10: FERN_LAUNCH((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 11: FERN_LAUNCH((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 2, false, 0, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
     }
     if (p.aload == ALOAD_CONV3) {      // 3x3 window loader exists for the LDS-DMA family only
         switch (c) {
-            case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
-            case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
-            case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
-            case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
-            case 14: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 96, 32, 96, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
-            case 15: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 160, 32, 160, 16, 3, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 8: FERN_LAUNCH((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 9: FERN_LAUNCH((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 10: FERN_LAUNCH((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 11: FERN_LAUNCH((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 14: FERN_LAUNCH((gemm_f32_glds_kernel<128, 96, 32, 96, 16, 4, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
+            case 15: FERN_LAUNCH((gemm_f32_glds_kernel<128, 160, 32, 160, 16, 3, true>), dim3(nb, ks), dim3(256), 0, s, p); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
     }
     switch (c) {
-        case 0: hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 64, 64, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_f32_kernel<64, 128, 32, 64, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_f32_kernel<128, 64, 64, 32, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, 32, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
-        case 6: hipLaunchKernelGGL((gemm_f32_skinny_kernel<5, 64>), dim3(nb, ks), dim3(256), 0, s, p); break;
-        case 8: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
-        case 9: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
-        case 10: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
-        case 11: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
-        case 12: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
-        case 13: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 256, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
-        case 14: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 96, 32, 96, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
-        case 15: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 160, 32, 160, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 0: FERN_LAUNCH((gemm_f32_kernel<128, 128, 64, 64, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 1: FERN_LAUNCH((gemm_f32_kernel<64, 128, 32, 64, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 2: FERN_LAUNCH((gemm_f32_kernel<128, 64, 64, 32, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 3: FERN_LAUNCH((gemm_f32_kernel<64, 64, 32, 32, 32, false>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 6: FERN_LAUNCH((gemm_f32_skinny_kernel<5, 64>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 8: FERN_LAUNCH((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 9: FERN_LAUNCH((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 10: FERN_LAUNCH((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 11: FERN_LAUNCH((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 12: FERN_LAUNCH((gemm_f32_glds_kernel<256, 128, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
+        case 13: FERN_LAUNCH((gemm_f32_glds_kernel<128, 256, 64, 64, 16, 4>), dim3(nb, ks), dim3(512), 0, s, p); break;
+        case 14: FERN_LAUNCH((gemm_f32_glds_kernel<128, 96, 32, 96, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
+        case 15: FERN_LAUNCH((gemm_f32_glds_kernel<128, 160, 32, 160, 16, 4>), dim3(nb, ks), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -879,10 +879,10 @@ static hipError_t launch_mixed(const Plan& pl, const GemmParams& p, hipStream_t 
     const int n_a8 = (n_a + 7) & ~7, n_b8 = (n_b + 7) & ~7;      // every band starts on a multiple of 8 blocks: block % 8 stays the XCD inside the band
     const int grid = n_c > 0 ? n_a8 + n_b8 + n_c : n_b > 0 ? n_a8 + n_b : n_a;
     if (p.split == 3) {
-        if (wide) hipLaunchKernelGGL((gemm_f32_mixed_kernel<true, 3>), dim3(grid), dim3(256), 0, s, p, ra, rb, n_a8, n_b8);
-        else hipLaunchKernelGGL((gemm_f32_mixed_kernel<false, 3>), dim3(grid), dim3(256), 0, s, p, ra, rb, n_a8, n_b8);
-    } else if (wide) hipLaunchKernelGGL(gemm_f32_mixed_kernel<true>, dim3(grid), dim3(512), 0, s, p, ra, rb, n_a8, n_b8);
-    else hipLaunchKernelGGL(gemm_f32_mixed_kernel<false>, dim3(grid), dim3(512), 0, s, p, ra, rb, n_a8, n_b8);
+        if (wide) FERN_LAUNCH((gemm_f32_mixed_kernel<true, 3>), dim3(grid), dim3(256), 0, s, p, ra, rb, n_a8, n_b8);
+        else FERN_LAUNCH((gemm_f32_mixed_kernel<false, 3>), dim3(grid), dim3(256), 0, s, p, ra, rb, n_a8, n_b8);
+    } else if (wide) FERN_LAUNCH(gemm_f32_mixed_kernel<true>, dim3(grid), dim3(512), 0, s, p, ra, rb, n_a8, n_b8);
+    else FERN_LAUNCH(gemm_f32_mixed_kernel<false>, dim3(grid), dim3(512), 0, s, p, ra, rb, n_a8, n_b8);
     return hipGetLastError();
 }
 
@@ -928,6 +928,7 @@ static hipError_t launch_plan(const Plan& pl, const GemmParams& p, hipStream_t s
 // `tuned` = false: nothing was timed (the stream is being captured, or no scratch memory) and the heuristic plan is returned --
 // the caller must NOT cache it, or the shape would stay on the untuned plan (and be exported as a tuned choice) for good.
 static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
+    LaunchTimerPause pause;
     const int fallback_cfg = choose_cfg(p.M, p.N, p.K);
     const Plan fallback{fallback_cfg, 0, fallback_cfg};
     tuned = false;
@@ -1038,13 +1039,13 @@ static bool split_family_ok(const GemmParams& p) {
 static hipError_t launch_cfg_split(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsS[c].bm - 1) / kCfgsS[c].bm) * ((p.N + kCfgsS[c].bn - 1) / kCfgsS[c].bn);
     switch (c) {
-        case 0: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 3, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 128, 128, 64, 16, 2, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 256, 64, 128, 16, 2, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 5: hipLaunchKernelGGL((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 6: hipLaunchKernelGGL((gemm_f32_glds_kernel<256, 256, 128, 64, 16, 2, false, 0, false, 3>), dim3(nb), dim3(512), 0, s, p); break;
+        case 0: FERN_LAUNCH((gemm_f32_glds_kernel<128, 128, 64, 64, 16, 3, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 1: FERN_LAUNCH((gemm_f32_glds_kernel<256, 128, 128, 64, 16, 2, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 2: FERN_LAUNCH((gemm_f32_glds_kernel<128, 256, 64, 128, 16, 2, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 3: FERN_LAUNCH((gemm_f32_glds_kernel<64, 128, 32, 64, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 4: FERN_LAUNCH((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 5: FERN_LAUNCH((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 6: FERN_LAUNCH((gemm_f32_glds_kernel<256, 256, 128, 64, 16, 2, false, 0, false, 3>), dim3(nb), dim3(512), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1063,6 +1064,7 @@ static hipError_t launch_plan_split(const Plan& pl, const GemmParams& p, hipStre
     return pl.cfg >= kCfgMixed ? launch_mixed(pl, p, s) : launch_cfg_split(pl.cfg, p, s);
 }
 static Plan tune_shape_split(const GemmParams& p, hipStream_t s, bool& tuned) {
+    LaunchTimerPause pause;
     tuned = false;
     const int fb = heuristic_split(p);
     const Plan fallback{fb, 0, fb};

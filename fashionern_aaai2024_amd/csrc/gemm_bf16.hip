@@ -398,13 +398,13 @@ constexpr int kNumCfgsB = 7;
 static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsB[c].bm - 1) / kCfgsB[c].bm) * ((p.N + kCfgsB[c].bn - 1) / kCfgsB[c].bn);
     switch (c) {
-        case 0: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 3, 2>), dim3(nb), dim3(512), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 64, 64, 32, 3, 1>), dim3(nb), dim3(1024), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 64, 64, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 5: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 64, 32, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 6: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
+        case 0: FERN_LAUNCH((gemm_bf16_glds_kernel<128, 128, 64, 64, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 1: FERN_LAUNCH((gemm_bf16_glds_kernel<256, 128, 64, 64, 32, 3, 2>), dim3(nb), dim3(512), 0, s, p); break;
+        case 2: FERN_LAUNCH((gemm_bf16_glds_kernel<256, 256, 64, 64, 32, 3, 1>), dim3(nb), dim3(1024), 0, s, p); break;
+        case 3: FERN_LAUNCH((gemm_bf16_glds_kernel<64, 128, 32, 64, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 4: FERN_LAUNCH((gemm_bf16_glds_kernel<128, 64, 64, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 5: FERN_LAUNCH((gemm_bf16_glds_kernel<64, 64, 32, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 6: FERN_LAUNCH((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -416,12 +416,12 @@ constexpr int kNumCfgsF8 = 6;
 static hipError_t launch_cfg_f8(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsF8[c].bm - 1) / kCfgsF8[c].bm) * ((p.N + kCfgsF8[c].bn - 1) / kCfgsF8[c].bn);
     switch (c) {
-        case 0: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 128, 64, 64, 64, 3, 2, true>), dim3(nb), dim3(512), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_bf16_glds_kernel<256, 256, 64, 64, 64, 3, 1, true>), dim3(nb), dim3(1024), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 128, 32, 64, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((gemm_bf16_glds_kernel<128, 64, 64, 32, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
-        case 5: hipLaunchKernelGGL((gemm_bf16_glds_kernel<64, 64, 32, 32, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+        case 0: FERN_LAUNCH((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+        case 1: FERN_LAUNCH((gemm_bf16_glds_kernel<256, 128, 64, 64, 64, 3, 2, true>), dim3(nb), dim3(512), 0, s, p); break;
+        case 2: FERN_LAUNCH((gemm_bf16_glds_kernel<256, 256, 64, 64, 64, 3, 1, true>), dim3(nb), dim3(1024), 0, s, p); break;
+        case 3: FERN_LAUNCH((gemm_bf16_glds_kernel<64, 128, 32, 64, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+        case 4: FERN_LAUNCH((gemm_bf16_glds_kernel<128, 64, 64, 32, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
+        case 5: FERN_LAUNCH((gemm_bf16_glds_kernel<64, 64, 32, 32, 64, 2, 4, true>), dim3(nb), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -445,17 +445,17 @@ constexpr int kNumCfgsMx = 11;
 static hipError_t launch_cfg_mx(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsMx[c].bm - 1) / kCfgsMx[c].bm) * ((p.N + kCfgsMx[c].bn - 1) / kCfgsMx[c].bn);
     switch (c) {
-        case 0: hipLaunchKernelGGL((gemm_mx8_kernel<128, 128, 64, 64, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_mx8_kernel<256, 128, 64, 64, 2, 2>), dim3(nb), dim3(512), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((gemm_mx8_kernel<256, 128, 128, 64, 2, 1>), dim3(nb), dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((gemm_mx8_kernel<128, 128, 64, 64, 3, 1>), dim3(nb), dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((gemm_mx8_kernel<64, 128, 32, 64, 2, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 5: hipLaunchKernelGGL((gemm_mx8_kernel<128, 64, 64, 32, 2, 3>), dim3(nb), dim3(256), 0, s, p); break;
-        case 6: hipLaunchKernelGGL((gemm_mx8_kernel<64, 64, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
-        case 7: hipLaunchKernelGGL((gemm_mx8_kernel<256, 256, 64, 64, 2, 1>), dim3(nb), dim3(1024), 0, s, p); break;
-        case 8: hipLaunchKernelGGL((gemm_mx8_kernel<128, 128, 64, 64, 3, 3, 64>), dim3(nb), dim3(256), 0, s, p); break;
-        case 9: hipLaunchKernelGGL((gemm_mx8_kernel<256, 128, 64, 64, 3, 4, 64>), dim3(nb), dim3(512), 0, s, p); break;
-        case 10: hipLaunchKernelGGL((gemm_mx8_kernel<256, 256, 128, 64, 4, 2, 64>), dim3(nb), dim3(512), 0, s, p); break;
+        case 0: FERN_LAUNCH((gemm_mx8_kernel<128, 128, 64, 64, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
+        case 1: FERN_LAUNCH((gemm_mx8_kernel<256, 128, 64, 64, 2, 2>), dim3(nb), dim3(512), 0, s, p); break;
+        case 2: FERN_LAUNCH((gemm_mx8_kernel<256, 128, 128, 64, 2, 1>), dim3(nb), dim3(256), 0, s, p); break;
+        case 3: FERN_LAUNCH((gemm_mx8_kernel<128, 128, 64, 64, 3, 1>), dim3(nb), dim3(256), 0, s, p); break;
+        case 4: FERN_LAUNCH((gemm_mx8_kernel<64, 128, 32, 64, 2, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 5: FERN_LAUNCH((gemm_mx8_kernel<128, 64, 64, 32, 2, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 6: FERN_LAUNCH((gemm_mx8_kernel<64, 64, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
+        case 7: FERN_LAUNCH((gemm_mx8_kernel<256, 256, 64, 64, 2, 1>), dim3(nb), dim3(1024), 0, s, p); break;
+        case 8: FERN_LAUNCH((gemm_mx8_kernel<128, 128, 64, 64, 3, 3, 64>), dim3(nb), dim3(256), 0, s, p); break;
+        case 9: FERN_LAUNCH((gemm_mx8_kernel<256, 128, 64, 64, 3, 4, 64>), dim3(nb), dim3(512), 0, s, p); break;
+        case 10: FERN_LAUNCH((gemm_mx8_kernel<256, 256, 128, 64, 4, 2, 64>), dim3(nb), dim3(512), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -554,6 +554,7 @@ static int heuristic_b(int M, int N) {
 
 // `tuned` = false: nothing was timed (tuning off, stream capture, no scratch): the caller must not cache the fallback
 static int tune_shape_b(const GemmParams& p, hipStream_t s, bool& tuned) {
+    LaunchTimerPause pause;
     tuned = false;
     const bool f8 = p.fp8 != 0;
     auto launch = p.fp8 == 2 ? launch_cfg_mx : f8 ? launch_cfg_f8 : launch_cfg_b;

@@ -6,7 +6,43 @@
 
 #include <string>
 
+#ifdef __HIPCC__
+#include <hip/hip_ext.h>
+#endif
+#include <vector>
+
 namespace fern {
+
+// ---- kernel-precise launch timing (fern_prof_enable) ----------------------------------------------------------------------------
+// While a LaunchTimer is armed on the calling thread (api.hip arms one around every GEMM / attention launch of an instrumented pass),
+// FERN_LAUNCH dispatches through hipExtLaunchKernelGGL with a (start, stop) event pair: the events carry the DISPATCH's own begin /
+// end timestamps -- what rocprofv3's kernel trace reports -- instead of the stream-marker interval of hipEventRecord, which added
+// the marker packets and the dispatch latency (~3-5 us) to every launch (a fifth of a 25 us block-scaled GEMM).  Not armed: a plain
+// hipLaunchKernelGGL, nothing else.
+struct LaunchTimer {
+    std::vector<hipEvent_t> events;      // start, stop, start, stop ... of the dispatches since the timer was armed
+    std::vector<hipEvent_t>* pool;       // spare events (owned by the context)
+};
+extern thread_local LaunchTimer* g_launch_timer;
+struct LaunchTimerPause {                 // the tile tuners' trial launches are not part of the launch being timed
+    LaunchTimer* saved;
+    LaunchTimerPause() : saved(g_launch_timer) { g_launch_timer = nullptr; }
+    ~LaunchTimerPause() { g_launch_timer = saved; }
+};
+hipEvent_t launch_timer_event();         // an event from the armed timer's pool (created when the pool is empty)
+#ifdef __HIPCC__
+#define FERN_LAUNCH(kern, grid, block, shmem, stream, ...)                                                     \
+    do {                                                                                                       \
+        if (fern::g_launch_timer) {                                                                            \
+            hipEvent_t ev_a_ = fern::launch_timer_event(), ev_b_ = fern::launch_timer_event();                 \
+            hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, ev_a_, ev_b_, 0, __VA_ARGS__);             \
+            fern::g_launch_timer->events.push_back(ev_a_);                                                     \
+            fern::g_launch_timer->events.push_back(ev_b_);                                                     \
+        } else {                                                                                               \
+            hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);                                 \
+        }                                                                                                      \
+    } while (0)
+#endif
 
 // ---- fused similarity sweep + top-K selection (shared by the fp32 GEMM sweep and the bf16 sweep) ------------------
 // The sweep never stores the [B, N] score matrix.  A first, small pass scores a jittered 1-in-R row SAMPLE of the gallery
