@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const void* xin, co
             for (int e = 0; e < 4; ++e) { const float t = v[r][i][e] - mean[r]; q += t * t; }
         rstd[r] = rsqrtf(wave_sum(q) / (float)D + eps);
     }
+    unsigned e8s[RPW][NV];               // OUT == 1: the E8M0 byte of this lane's 32-block, per (row, chunk)
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const long row = row0 + r;
@@ -319,14 +320,42 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const void* xin, co
             } else {
                 float am = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
                 am = oct_max(am);
-                if (row < rows) {
-                    const unsigned e8 = mx_scale_byte(am);
-                    const float inv = mx_inv_scale(e8);
+                const unsigned e8 = mx_scale_byte(am);
+                const float inv = mx_inv_scale(e8);
+                e8s[r][i] = e8;
+                if (row < rows)
                     *reinterpret_cast<unsigned*>(static_cast<unsigned char*>(yout) + row * ldy + c) = pack4_fp8(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
-                    if ((lane & 7) == 0) scales[mx_scale_offset(row, c >> 5, srows)] = (unsigned char)e8;
-                }
             }
         }
+    }
+    if (OUT == 1) {
+        // Scales: the layout holds one dword per (128-k tile kt, row) = the bytes of blocks 4kt .. 4kt+3, i.e. of lanes 0, 8, 16, 24 (+ 32
+        // for the odd kt) of chunk kt / 2 -- gathered with v_readlane into ONE dword per (row, kt), and the RPW = 4 consecutive rows of the
+        // wave are 16 contiguous bytes per kt: one 16-byte store instead of 16 single-byte stores from 16 lanes of 4 instructions (a
+        // byte store is a write transaction of its own; 24 per row were as many transactions as all the data stores of the row).
+        static_assert(RPW == 4, "the scale gather writes the four rows of a wave as one uint4");
+        const bool whole = row0 + RPW <= rows && (srows & 3) == 0;      // row0 is a multiple of 4: the 16-byte stores are aligned
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                unsigned dw[RPW];
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int e = (int)e8s[r][i];
+                    dw[r] = (unsigned)__builtin_amdgcn_readlane(e, 32 * half) | ((unsigned)__builtin_amdgcn_readlane(e, 32 * half + 8) << 8) |
+                            ((unsigned)__builtin_amdgcn_readlane(e, 32 * half + 16) << 16) | ((unsigned)__builtin_amdgcn_readlane(e, 32 * half + 24) << 24);
+                }
+                const long kt = 2 * i + half;
+                unsigned* dst = reinterpret_cast<unsigned*>(scales + (kt * srows + row0) * 4);
+                if (lane == 0) {
+                    if (whole) *reinterpret_cast<uint4*>(dst) = uint4{dw[0], dw[1], dw[2], dw[3]};
+                    else
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r)
+                            if (row0 + r < rows) dst[r] = dw[r];
+                }
+            }
     }
 }
 constexpr int LN_RPW = 4;

@@ -52,9 +52,16 @@ cd $R
 for c in c2 c3 c4 c5; do      # the c2 line is the driver's default command: it carries cpu_baseline and the c3 / c4 / c5 child runs (other_configs)
     timeout 900 python3 bench.py --config $c $( [ $c = c2 ] || echo --no-cpu-baseline ) > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err
 done
-# world = 8 rehearsal: eight ranks share this box's one GPU over gloo (tools/r03_rehearsal.sh) -- every multi-rank path at its real shard sizes
-bash tools/r03_rehearsal.sh > $O/${TAG}_rehearsal.log 2>&1
-for c in c2 c3 c4 c5; do grep '^{' gpurun_out/r03_bench_${c}_8ranks_one_gpu_gloo.json | tail -1 > $O/${TAG}_bench_${c}_8ranks_one_gpu_gloo.json; done
+# one-stream kernel sequence of a c2 / c5 step (what DESIGN.md's per-block attributions quote)
+cd /tmp
+for c in c2 c5; do
+    rm -rf /tmp/tl_$c
+    timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$c -o p -- python3 $R/bench.py --pmc-mode --config $c --lanes 1 --steps 3 > /tmp/tl_$c.log 2>&1
+    python3 $R/tools/step_timeline.py /tmp/tl_$c 3 --list > $O/${TAG}_timeline_$c.txt 2>&1
+done
+cd $R
+# (the world = 8 one-GPU rehearsal of round 3, tools/r03_rehearsal.sh, is not repeated: its artefacts are profiles/r03_bench_c*_8ranks_one_gpu_gloo.json;
+#  round 4 covers the multi-rank paths with the world-8 gloo test and the bench pre-flight)
 # fp32 GEMM: per-wave timeline of the two dominant shapes + PMC view, MFMA issue-rate probe
 for shp in "12608 2304 768 8 0" "12608 2304 768 12 0" "12608 768 3072 12 3"; do set -- $shp; timeout 120 tools/probe/gemm_timeline $1 $2 $3 $4 $5 /tmp/tl.csv; python3 tools/gemm_timeline.py /tmp/tl.csv; done > $O/${TAG}_gemm_timeline.txt 2>&1
 timeout 60 tools/probe/mfma_issue_probe > $O/${TAG}_mfma_issue_probe.txt 2>&1
