@@ -107,6 +107,56 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const f32x16&
         }
         return;
     }
+    if constexpr (!GUARD) {
+        // Full tile (round 4): BUFFER addressing.  A tile's 16 accesses differ by a wave-uniform row offset only, so the address is
+        // (descriptor of the tile's first element, SGPRs) + (one lane offset, ONE VGPR for the whole kernel) + (row offset, an SGPR):
+        // no vector address arithmetic at all.  With flat global addressing hipcc kept a 64-bit address per element and advanced it
+        // with a v_lshl_add_u64 per access -- once for the residual loads and once more for the stores (R may alias C) -- a third of
+        // the epilogue's vector instructions and 32 live registers.  Same loads, same stores, same order, same values.
+        constexpr unsigned kRsrcFlags = 0x00020000u;      // gfx9 buffer descriptor DWORD3: 32-bit raw, no swizzle
+        constexpr int ES = OUT_BF16 ? 2 : 4;
+        const int voff = loff * ES;                                       // lane part: (4 lh) rows + column l31
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(p.C) + ((long)row0 * p.ldc + col0) * ES, 0, 0x7FFFFFFF, kRsrcFlags);
+        float add[16], qs[16];
+        if (resid) {
+            const char* rb = OUT_BF16 ? reinterpret_cast<const char*>(p.Rb) : reinterpret_cast<const char*>(p.R);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(rb) + ((long)row0 * p.ldc + col0) * ES, 0, 0x7FFFFFFF, kRsrcFlags);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {      // all sixteen addends before the first store (in place: R == C)
+                const int soff = ((r & 3) + 8 * (r >> 2)) * (int)p.ldc * ES;
+                if (OUT_BF16) add[r] = bf16_bits_to_f32(__builtin_amdgcn_raw_buffer_load_b16(rr, voff, soff, 0));
+                else add[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, voff, soff, 0));
+            }
+        }
+        if (SCALED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qs[r] = qa[(r & 3) + 8 * (r >> 2) + lrow] * qw;
+        }
+        auto put = [&](int r, float v) {
+            if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.0f);
+            else if (EPI == EPI_BIAS_RESIDUAL) v += add[r];
+            else if (EPI == EPI_BIAS_RESIDUAL_RELU) v = fmaxf(v + add[r], 0.0f);
+            else if (EPI == EPI_COLAFFINE_TANH) v = tanhf(v * sc + sh);
+            const int soff = ((r & 3) + 8 * (r >> 2)) * (int)p.ldc * ES;
+            if (OUT_BF16) __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16_bits(v), rc, voff, soff, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff, soff, 0);
+        };
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v2 = {SCALED ? acc[r] * qs[r] + bia : acc[r] + bia, SCALED ? acc[r + 1] * qs[r + 1] + bia : acc[r + 1] + bia};
+                const f32x2 g2 = gelu_of<FAST>(v2);
+                put(r, g2[0]);
+                put(r + 1, g2[1]);
+                if (FAST == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) put(r, SCALED ? acc[r] * qs[r] + bia : acc[r] + bia);
+        }
+        return;
+    }
     // The residual stream is updated in place (R == C): the compiler keeps every load behind the preceding store, so the
     // memory addends of a tile are fetched together BEFORE its first store.
     const float* Rt = resid && !OUT_BF16 ? p.R + (long)row0 * p.ldc + col0 : nullptr;
