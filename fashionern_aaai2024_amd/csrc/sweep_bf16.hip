@@ -325,7 +325,7 @@ static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, flo
     const long ntiles = ((FILTER ? N : S) + ROWS_T - 1) / ROWS_T;
     long blocks = (ntiles + 3) / 4;
     if (blocks > 256) blocks = 256;                                // one persistent workgroup per CU
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, q, g, scores, ld, B, N, D, S, R, filt, gate);
+    FERN_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, s, q, g, scores, ld, B, N, D, S, R, filt, gate);
     return hipGetLastError();
 }
 

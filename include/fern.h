@@ -135,9 +135,10 @@ typedef struct {
     double attn_ms;
     double attn_flops;
     int64_t attn_launches;
-    double topk_ms;        /* the rest of the ranking stage: sample pass, bound, candidate selection, gated exact pass */
+    double topk_ms;        /* the rest of the ranking stage: sample pass, bound, candidate selection, gated exact pass and every launch
+                              boundary of the stage = (one stream-marker interval around the whole stage) - sweep_ms */
     int64_t topk_launches;
-    double sweep_ms;       /* the filtered similarity sweep inside fern_sim_topk / fern_sim_topk_bf16 */
+    double sweep_ms;       /* the filtered similarity sweep inside fern_sim_topk / fern_sim_topk_bf16: the kernel's own duration */
     double sweep_bytes;    /* algorithmic bytes of those sweeps: N*D*s_g + B*D*4 + B*K*8 */
     int64_t sweep_launches;
     double gemm_fp8_ms;    /* fp8-operand GEMM launches (FERN_PREC_FP8, fern_gemm_fp8): not included in gemm_* / gemm_bf16_* */
