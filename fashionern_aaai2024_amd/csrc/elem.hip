@@ -374,6 +374,91 @@ static bool launch_ln_rows(const void* x, const float* gamma, const float* beta,
     return true;
 }
 
+// ---- bf16 rows in, MX fp8 out: half a wave per row (round 4, tools/probe/ln_lab.hip) ---------------------------------------------
+// The block-scaled mode's LayerNorm reads the bf16 residual stream the GEMM before it has just written (from other XCDs: nothing of
+// it is in this CU's L2) and is a single round of waves: its time is the latency of that round, not its 29 MB.  Measured in the chain
+// writer -> LayerNorm -> reader at 12608 x 768: the four-rows-per-wave kernel above 15.1 us, one row per wave 10.7, this form 9.1
+// (a byte-for-byte copy of the same shape: 8.7).  A lane holds 8 consecutive elements of each 256-column chunk of ITS half-wave's
+// row -- one 16-byte load and one 8-byte store per chunk, 512 contiguous bytes per half-wave -- and a 32-element MX block is 4 lanes.
+// The fp8 bytes leave with nt stores: the next kernel reads them from other XCDs anyway.  Statistics: the row's 32 lanes on the DPP
+// network, the two 16-lane rows of the half added in a fixed order; used for EVERY row count of a width it covers (batch-invariant).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_half_kernel(const unsigned short* x, const float* gamma, const float* beta, unsigned char* y, unsigned char* scales,
+                                                             long srows, long rows, long ldx, long ldy, float eps) {
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    const long rowp = ((long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * 2;
+    if (rowp >= rows) return;
+    const long row = rowp + lh;
+    const long rrow = row < rows ? row : rows - 1;             // an odd row count: the last wave's upper half re-reads the last row (not stored)
+    float v[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const uint4 w = *reinterpret_cast<const uint4*>(x + rrow * ldx + (i * 32 + l31) * 8);
+        const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][2 * e] = __uint_as_float(ww[e] << 16); v[i][2 * e + 1] = __uint_as_float(ww[e] & 0xffff0000u); }
+    }
+    float g[NV][8], bb[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 32 + l31) * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[i][e] = g0[e]; g[i][4 + e] = g1[e]; bb[i][e] = b0[e]; bb[i][4 + e] = b1[e]; }
+    }
+    auto half_sum = [&](float t) {      // over the 32 lanes of this lane's half
+        t += dpp_move<0xB1>(t);
+        t += dpp_move<0x4E>(t);
+        t += dpp_move<0x141>(t);
+        t += dpp_move<0x140>(t);
+        const float lo = lane_f(t, 0) + lane_f(t, 16), hi = lane_f(t, 32) + lane_f(t, 48);
+        return lh ? hi : lo;
+    };
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += v[i][e];
+    const float mean = half_sum(sum) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float t = v[i][e] - mean; q += t * t; }
+    const float rstd = rsqrtf(half_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float o[8];
+        float am = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[e] = (v[i][e] - mean) * rstd * g[i][e] + bb[i][e]; am = fmaxf(am, fabsf(o[e])); }
+        am = quad_max(am);
+        const unsigned e8 = mx_scale_byte(am);
+        const float inv = mx_inv_scale(e8);
+        if (row < rows) {
+            unsigned* dst = reinterpret_cast<unsigned*>(y + row * ldy + (i * 32 + l31) * 8);
+            __builtin_nontemporal_store(pack4_fp8(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv), dst);
+            __builtin_nontemporal_store(pack4_fp8(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv), dst + 1);
+            // blocks 8i .. 8i+7 of the row, 4 lanes each (mx_scale_offset: k tile = block / 4, byte = block % 4)
+            if ((l31 & 3) == 0) scales[mx_scale_offset(row, i * 8 + (l31 >> 2), srows)] = (unsigned char)e8;
+        }
+    }
+}
+static bool launch_ln_half(const unsigned short* x, const float* gamma, const float* beta, unsigned char* y, unsigned char* scales, long srows, long rows, int d,
+                           long ldx, long ldy, float eps, hipStream_t s) {
+    if (d % 256 || d > 1024 || (ldx & 7) || (ldy & 7) || ((uintptr_t)x & 15) || ((uintptr_t)y & 7) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) return false;
+    const dim3 grid((unsigned)((rows + ROWS_PER_BLOCK * 2 - 1) / (ROWS_PER_BLOCK * 2)));
+    switch (d / 256) {
+        case 1: hipLaunchKernelGGL((layernorm_half_kernel<1>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
+        case 2: hipLaunchKernelGGL((layernorm_half_kernel<2>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
+        case 3: hipLaunchKernelGGL((layernorm_half_kernel<3>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
+        default: hipLaunchKernelGGL((layernorm_half_kernel<4>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
+    }
+    return true;
+}
+
 // Patch rows of a [b, 3, img, img] image batch, block-scale quantised: row (image, gy, gx) = the 3 x patch x patch pixels of one
 // patch in (channel, y, x) order -- the k order of conv1's [width, 3 * patch * patch] weight -- so that the patch embedding of the
 // block-scaled mode is a plain MX GEMM.  One wave per patch; a lane holds 4 consecutive x of one (channel, y) per step.
@@ -832,6 +917,7 @@ hipError_t launch_layernorm_mx8(const float* x, const float* gamma, const float*
                                 long rows, int d, long ldx, long ldy, float eps, hipStream_t s, const unsigned short* x_bf16) {
     if (rows <= 0) return hipSuccess;
     if (d <= 0 || d % 128 || d > 256 * MAXV || (ldx & 3) || (ldy & 3) || srows < rows) return hipErrorInvalidValue;
+    if (x_bf16 && launch_ln_half(x_bf16, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps, s)) return hipGetLastError();
     if (x_bf16 ? launch_ln_rows<1, 1>(x_bf16, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps, s)
                : launch_ln_rows<0, 1>(x, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps, s))
         return hipGetLastError();
