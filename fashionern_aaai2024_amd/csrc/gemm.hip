@@ -23,6 +23,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <string>
 
 namespace fern {
@@ -443,6 +444,162 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_f32_gld
     glds_tile<BM, BN, WM, WN, BKT, CONV, SYNC, FILT, SPLIT>(p, blockIdx.x, smem);
 }
 
+// ---- f32x3 with the operands split ONCE per workgroup (round 4) ---------------------------------------------------------------
+// In the SPLIT = 3 form above every wave splits the fragments it reads: on the 256x256 tile an A row block is split by four waves
+// and a W row block by two, 216 split instructions per fat wave and 16-k tile, and the family is bound by the issue port, not by the
+// MFMA pipe or the copy (profiles/r04_experiments.txt section 1).  Here the fp32 tile goes global -> registers (two 16-byte loads per
+// (row, half) unit: chunks h and 2 + h, the 8 k values lane half h of that row feeds to one bf16 MFMA), is split by the thread that
+// loaded it -- the same split(), so the same plane bits -- and the three bf16 planes are written to LDS, 16 bytes per unit and plane;
+// every wave then reads ready fragments (ds_read_b128, conflict-free: a plane is [half][row][16 B]).  72 split instructions per wave
+// and tile instead of 216, 18 fragment reads instead of 12.  Planes are double buffered: tile kt + 1 is split and published while
+// the MFMAs of tile kt issue, tile kt + 2 is in flight in registers, one barrier per tile.  Same k -> slot map, same six products
+// in the same order as the SPLIT = 3 form: bit-identical to every other configuration of the family.
+// Wave tile 128x64 on (BM / 128) x (BN / 64) waves; two waves per SIMD of register budget.
+template <int BM, int BN>
+__global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void gemm_f32x3_shared_kernel(GemmParams p) {
+    constexpr int WM = 128, WN = 64, TM = 4, TN = 2;
+    constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N, NT = NW * 64;
+    constexpr int ROWS = BM + BN;                        // A rows then W rows
+    constexpr int UNITS = ROWS * 2;                      // (row, half) units of a 16-k tile
+    static_assert(UNITS % NT == 0, "units must divide over the threads");
+    constexpr int UPT = UNITS / NT;
+    constexpr int HALF = ROWS * 16 + 64;                 // bytes of one lane half of a plane (+ 64: the two halves of a row are written by neighbouring lanes -- different banks)
+    constexpr int PLANE = 2 * HALF;
+    constexpr int BUF = 3 * PLANE;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
+    if (p.gate && *p.gate == 0) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nwg = nbm * nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int bm = swz / nbn, bn = swz % nbn;
+
+    typedef short bf16x8s __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+    auto split = [&](const f32x4& g0, const f32x4& g1, bf16x8s (&pl)[3]) {      // glds_tile's split(), statement for statement
+        f32x2s x[4] = {{g0[0], g0[1]}, {g0[2], g0[3]}, {g1[0], g1[1]}, {g1[2], g1[3]}};
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) {
+            u32x4s packed;
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) packed[q2] = __builtin_amdgcn_perm(__float_as_uint(x[q2][1]), __float_as_uint(x[q2][0]), 0x07060302u);
+            pl[lv] = __builtin_bit_cast(bf16x8s, packed);
+            if (lv + 1 < 3) {
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2) {
+                    const u32x2s top = __builtin_bit_cast(u32x2s, x[q2]) & 0xFFFF0000u;
+                    x[q2] = x[q2] - __builtin_bit_cast(f32x2s, top);
+                }
+            }
+        }
+    };
+
+    const float* src[UPT];
+    int dst[UPT];
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+        const int unit = tid + NT * u;
+        const int trow = unit >> 1, h = unit & 1;
+        if (trow < BM) {
+            int row = bm * BM + trow;
+            row = row < p.M ? row : p.M - 1;
+            src[u] = p.A + (long)row * p.lda + h * 4;
+        } else {
+            int row = bn * BN + (trow - BM);
+            row = row < p.N ? row : p.N - 1;
+            src[u] = p.W + (long)row * p.ldw + h * 4;
+        }
+        dst[u] = h * HALF + trow * 16;
+    }
+    // two register sets: the tile published in step kt was requested two steps earlier (a step is ~1.5 us: an HBM miss has landed)
+    f32x4 g[2][UPT][2];
+    const int klast = p.K - 16;
+    auto load = [&](f32x4 (&gs)[UPT][2], int k0) {
+        k0 = k0 < klast ? k0 : klast;                      // past the end: re-read the last tile (published, never multiplied): no branch in the loop
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+            gs[u][0] = *reinterpret_cast<const f32x4*>(src[u] + k0);
+            gs[u][1] = *reinterpret_cast<const f32x4*>(src[u] + k0 + 8);
+        }
+    };
+    auto publish = [&](const f32x4 (&gs)[UPT][2], int buf) {
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+            bf16x8s pl[3];
+            split(gs[u][0], gs[u][1], pl);
+#pragma unroll
+            for (int lv = 0; lv < 3; ++lv) *reinterpret_cast<bf16x8s*>(smem + buf * BUF + lv * PLANE + dst[u]) = pl[lv];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int arow = lh * HALF + (wm * WM + l31) * 16, wrow = lh * HALF + (BM + wn * WN + l31) * 16;
+    auto compute = [&](int buf) {
+        const char* P = smem + buf * BUF;
+        bf16x8s ap[TM][3], bp[TN][3];
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ap[i][lv] = *reinterpret_cast<const bf16x8s*>(P + lv * PLANE + arow + i * 512);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bp[j][lv] = *reinterpret_cast<const bf16x8s*>(P + lv * PLANE + wrow + j * 512);
+        }
+#pragma unroll
+        for (int ord = 0; ord < 3; ++ord)
+#pragma unroll
+            for (int la = 0; la <= ord; ++la)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][la], bp[j][ord - la], acc[i][j], 0, 0, 0);
+    };
+
+    const int nk = p.K / 16;
+    load(g[0], 0);
+    publish(g[0], 0);
+    load(g[1], 16);
+    load(g[0], 32);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(2);
+    // step kt (parity P): MFMAs on plane buffer P; tile kt + 1 (register set P ^ 1) is split and published into buffer P ^ 1 -- free:
+    // every wave passed the last barrier -- and that register set is refilled with tile kt + 3.  Straight-line code: the split
+    // instructions interleave with the MFMAs.
+    auto step = [&](int kt, auto parity) {
+        constexpr int P = decltype(parity)::value;
+        compute(P);
+        publish(g[P ^ 1], P ^ 1);
+        load(g[P ^ 1], (kt + 3) * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my fragment reads and my plane writes are done
+        __builtin_amdgcn_s_barrier();
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        step(kt, std::integral_constant<int, 0>{});
+        step(kt + 1, std::integral_constant<int, 1>{});
+    }
+    if (kt < nk) step(kt, std::integral_constant<int, 0>{});
+    __builtin_amdgcn_s_setprio(0);
+    gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
+}
+
 // ---- mixed-geometry launch ------------------------------------------------------------------------------------------------
 // The 8-wave 256x128 (or 128x256) macro-tile has the best main loop of the family (0.75x the L2 -> LDS bytes per flop of the
 // 128x128 tile: 126-128 TFLOP/s against 121 on a shape both tile evenly, tools/probe/gemm_timeline.hip), but the encoder's GEMMs are
@@ -741,9 +898,10 @@ static hipError_t launch_cfg(int c, const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-static bool skinny_ok(const GemmParams& p) {      // shapes / forms the 16x16 small-M kernel covers
-    return p.M <= 128 && (p.K % 64) == 0 && p.aload == ALOAD_PLAIN && p.epi != EPI_SR_LOCAL && p.epi != EPI_PATCH_EMBED && p.epi != EPI_TOPK_FILTER;
+static bool skinny_form_ok(const GemmParams& p) {      // forms the 16x16 small-M kernel covers ...
+    return (p.K % 64) == 0 && p.aload == ALOAD_PLAIN && p.epi != EPI_SR_LOCAL && p.epi != EPI_PATCH_EMBED && p.epi != EPI_TOPK_FILTER;
 }
+static bool skinny_ok(const GemmParams& p) { return p.M <= 128 && skinny_form_ok(p); }      // ... and the shapes it is a candidate for on its own
 
 // ---- per-shape tile selection -------------------------------------------------------------------------------------
 // Every configuration accumulates each output element over k in the same order (k pairs (8g+e, 8g+4+e), g ascending),
@@ -777,7 +935,7 @@ static bool mixed_plan_ok(const Plan& pl, int M) {
 static std::map<ShapeKey, Plan> g_tuned;
 static std::mutex g_tuned_mu;
 static std::map<ShapeKey, Plan>& tuned_split_map();     // the f32x3 family's choices (defined with that family below)
-constexpr int kNumCfgsS = 7;                             // ... and its number of single configurations
+constexpr int kNumCfgsS = 8;                             // ... and its number of single configurations
 
 // FERN_GEMM_TILES=<file>: pin the per-shape choices (lines "f32 M N K epi aload cfg [rows_a cfg_b]", as written by gemm_tuner_export /
 // fern_tuner_export): listed shapes are never timed again, so a run's kernels -- and its HBM / L2 traffic -- are reproducible
@@ -917,6 +1075,7 @@ static int mixed_candidates(int M, int N, Plan (&out)[32]) {
 static hipError_t launch_plan(const Plan& pl, const GemmParams& p, hipStream_t s) {
     if (pl.cfg >= kCfgMixed) return launch_mixed(pl, p, s);
     if (pl.rows_a <= 0 || pl.rows_a >= p.M) return launch_cfg(pl.cfg, p, s);
+    if ((pl.cfg_b == 6 || pl.cfg == 6) && !skinny_form_ok(p)) return launch_cfg(pl.cfg == 6 ? 11 : pl.cfg, p, s);      // a pinned pair on a call the 16x16 kernel cannot serve
     g_last_dispatches = 2;
     GemmParams head = p;
     head.M = pl.rows_a;
@@ -1032,6 +1191,8 @@ static Plan tune_shape(const GemmParams& p, hipStream_t s, bool& tuned) {
 // four fat waves needs 32 B/clk per workgroup (two per CU: 64) of a path that delivers ~33 B/clk per CU -- copy-bound at about half the
 // MFMA rate, which is the 1.5x the family measured.  256x256 stages 32 KiB per 3 072 MFMA cycles per SIMD: 10.7 B/clk.
 static const TileCfg kCfgsS[kNumCfgsS] = {{128, 128, 16, 1.f}, {256, 128, 16, 1.f}, {128, 256, 16, 1.f}, {64, 128, 16, 1.f}, {128, 64, 16, 1.f}, {64, 64, 16, 1.f},
+                                          {256, 256, 16, 1.f},
+                                          // 7: operands split once per workgroup (gemm_f32x3_shared_kernel), 8 fat waves
                                           {256, 256, 16, 1.f}};
 static bool split_family_ok(const GemmParams& p) {
     return p.split == 3 && split_ok(p) && p.M >= 256 && p.K % 16 == 0;
@@ -1046,6 +1207,7 @@ static hipError_t launch_cfg_split(int c, const GemmParams& p, hipStream_t s) {
         case 4: FERN_LAUNCH((gemm_f32_glds_kernel<128, 64, 64, 32, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
         case 5: FERN_LAUNCH((gemm_f32_glds_kernel<64, 64, 32, 32, 16, 4, false, 0, false, 3>), dim3(nb), dim3(256), 0, s, p); break;
         case 6: FERN_LAUNCH((gemm_f32_glds_kernel<256, 256, 128, 64, 16, 2, false, 0, false, 3>), dim3(nb), dim3(512), 0, s, p); break;
+        case 7: FERN_LAUNCH((gemm_f32x3_shared_kernel<256, 256>), dim3(nb), dim3(512), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

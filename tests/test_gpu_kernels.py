@@ -241,6 +241,9 @@ def test_mixed_geometry_plans_are_bit_identical(engine, m, n, k):
     hi = (m // 256) * 256
     plans = [(20, hi, m), (20, hi, hi), (20, 1024, 1024 + ((m - 1024) // 128) * 128), (20, 256, 256), (20, 512, m),
              (21, (m // 128) * 128, m), (21, 1152, 2048), (21, 128, 128), (21, 2048, 2048 + 256)]
+    # bulk + remainder pairs (two launches): rows [0, ra) on `cfg`, the rest on `rb` -- incl. the 16x16-tile kernel (6) as the remainder
+    # of 64x64 / 64x128 / 128x64 bulks (k % 64 == 0), a ragged last row block included
+    plans += [(8, 1024, 11), (12, 2048, 8)] + ([(11, 2048, 6), (9, 1984, 6), (10, 1280, 6)] if k % 64 == 0 else [])
     for epi in (0, 1, 2, 3):
         run = lambda: engine.gemm(a, w, b, residual=r if epi == 3 else None, epilogue=epi).cpu()  # noqa: E731
         engine.tuner_import(f"f32 {m} {n} {k} {epi} 0 8 0 8\n")
@@ -270,7 +273,7 @@ def test_gemm_f32x3_is_fp32_accurate_and_configuration_independent(m, n, k):
         eng.set_precision("f32x3")
         assert eng.precision == "f32x3"
         outs = []
-        for cfg in range(6):
+        for cfg in range(8):
             eng.tuner_import(f"f32x3 {m} {n} {k} {epi} {cfg}\n")
             outs.append(run())
         if m >= 2048:      # one-launch mixed plans of the family (fat-wave macro-tiles + 128x128 + 64x128 bands)
