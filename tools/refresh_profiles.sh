@@ -33,6 +33,11 @@ run_stats() {   # name, bench args...
 rm -f /tmp/shapes.csv
 FERN_PROF_DUMP=/tmp/shapes.csv timeout 600 python3 $R/bench.py --no-cpu-baseline --headline-only --lanes 1 --steps 10 --save-tiles $O/${TAG}_gemm_tiles.txt > /dev/null 2>&1
 python3 $R/tools/prof_shapes.py /tmp/shapes.csv > $O/${TAG}_shapes.txt
+for c in c3 c5; do      # per-shape tables of the other workloads (not pinned: their own tuner choices)
+    rm -f /tmp/shapes_$c.csv
+    FERN_PROF_DUMP=/tmp/shapes_$c.csv timeout 600 python3 $R/bench.py --no-cpu-baseline --headline-only --lanes 1 --steps 10 --config $c > /dev/null 2>&1
+    python3 $R/tools/prof_shapes.py /tmp/shapes_$c.csv > $O/${TAG}_shapes_$c.txt
+done
 export FERN_GEMM_TILES=$O/${TAG}_gemm_tiles.txt
 run_stats ${TAG}_bench
 run_stats ${TAG}_bench_lanes1_headline_only --lanes 1 --headline-only
@@ -54,7 +59,7 @@ for c in c2 c3 c4 c5; do      # the c2 line is the driver's default command: it 
 done
 # one-stream kernel sequence of a c2 / c5 step (what DESIGN.md's per-block attributions quote)
 cd /tmp
-for c in c2 c5; do
+for c in c2 c3 c5; do
     rm -rf /tmp/tl_$c
     timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$c -o p -- python3 $R/bench.py --pmc-mode --config $c --lanes 1 --steps 3 > /tmp/tl_$c.log 2>&1
     python3 $R/tools/step_timeline.py /tmp/tl_$c 3 --list > $O/${TAG}_timeline_$c.txt 2>&1
