@@ -6,8 +6,10 @@
 ``ClipBpeTokenizer`` restates the published CLIP byte-level BPE (third party: openai/CLIP ``simple_tokenizer.py``, which
 open_clip 2.20.0 re-exports; neither is under /root/reference): printable-byte alphabet, merges applied in rank order on
 lower-cased, whitespace-collapsed text split by the CLIP pattern, ``<|startoftext|>`` / ``<|endoftext|>`` framing, zero padding
-and truncation to ``context_length`` with the end token kept.  PARITY UNPINNED: without the vocabulary file and without
-open_clip it can only be tested on synthetic merge tables (tests/test_host_cpu.py); ``ftfy`` text repair is not applied.
+and truncation to ``context_length`` with the end token kept.  PARITY of the merge TABLE is UNPINNED (no vocabulary file, no
+open_clip offline); how a table is APPLIED is pinned against an independent implementation, the `tokenizers` library's CLIP
+pipeline behind transformers' CLIPTokenizer, on a shared synthetic table (tests/test_host_cpu.py: 315 strings, identical ids).
+``ftfy`` text repair is not applied.
 """
 from __future__ import annotations
 

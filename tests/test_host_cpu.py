@@ -376,3 +376,67 @@ def test_builtin_tokenizer_reproduces_published_clip_token_ids():
     assert out.shape == (3, 77)
     for row, word in zip(out.tolist(), (22697, 1929, 2368)):
         assert row[:4] == [49406, 320, word, 49407] and not any(row[4:])
+
+
+def test_clip_bpe_algorithm_agrees_with_the_tokenizers_library_clip_pipeline():
+    """An independent statement of the CLIP tokenisation ALGORITHM is importable offline: transformers' CLIPTokenizer, i.e. the Rust
+    `tokenizers` pipeline (NFC + whitespace collapse + lower-case, the CLIP split pattern, byte-level alphabet, BPE with the `</w>`
+    end-of-word suffix, start / end framing).  Given the SAME vocabulary and merge table -- a table learned here by a 30-line BPE trainer
+    on a small caption corpus, since the released table is not available offline -- ClipBpeTokenizer must produce the same ids on
+    captions, contractions, punctuation runs, digits, accented and CJK text, emoji, whitespace noise, unseen words and random strings.
+    (The merge TABLE stays unpinned; this pins how a table is applied.)"""
+    import collections
+    import random
+    try:
+        from transformers.models.clip.tokenization_clip import CLIPTokenizer
+    except ImportError:
+        pytest.skip("transformers / tokenizers not importable")
+    from fashionern_aaai2024_amd.tokenizer import ClipBpeTokenizer, _byte_alphabet
+    corpus = ("a red dress with long sleeves and a floral print is shorter and has more buttons the blue shirt isn't as dark it's 100% "
+              "cotton, size 42 / xl! café naïve straße 日本語 emoji 😀 women's t-shirt that's striped; men's jeans i'd like; they've "
+              "we'll you're i'm is darker and more feminine has a v-neck and no sleeves").split()
+    alpha = _byte_alphabet()
+
+    def symbols(word):
+        s = "".join(alpha[b] for b in word.encode("utf-8"))
+        return tuple(list(s[:-1]) + [s[-1] + "</w>"])
+
+    words = collections.Counter(symbols(w) for w in corpus)
+    merges = []
+    for _ in range(200):                                   # plain BPE training: most frequent adjacent pair, ties by symbol order
+        pairs = collections.Counter()
+        for w, c in words.items():
+            for i in range(len(w) - 1):
+                pairs[(w[i], w[i + 1])] += c
+        if not pairs:
+            break
+        best = max(sorted(pairs), key=lambda p: pairs[p])
+        merges.append(best)
+        merged = collections.Counter()
+        for w, c in words.items():
+            out, i = [], 0
+            while i < len(w):
+                if i + 1 < len(w) and (w[i], w[i + 1]) == best:
+                    out.append(w[i] + w[i + 1])
+                    i += 2
+                else:
+                    out.append(w[i])
+                    i += 1
+            merged[tuple(out)] += c
+        words = merged
+    assert len(merges) > 100
+    mine = ClipBpeTokenizer(merges)
+    other = CLIPTokenizer(vocab=dict(mine.encoder), merges=[tuple(m) for m in merges])
+    texts = ["A red dress with long sleeves", "isn't it's 100% cotton, size 42 / XL!", "  multiple   spaces\tand\nnewlines ", "café naïve straße",
+             "日本語 😀 emoji", "women's t-shirt that's striped; men's jeans", "they've we'll you're I'm I'd", "unseenword zzzqqq 7777", "",
+             "a" * 200, "hello...world!!! (test) [x] {y} <z>", "dress", "Is DARKER and More Feminine", "v-neck,no sleeves;42xl", "it's's''s"]
+    rng = random.Random(0)
+    pool = "abcdefghijklmnopqrstuvwxyzABCDEFXYZ0123456789      '.,;:!?-_/()%&#é日😀ßñ"
+    texts += ["".join(rng.choice(pool) for _ in range(rng.randint(1, 60))) for _ in range(300)]
+    import html
+    for t in texts:
+        # open_clip's basic_clean() unescapes HTML entities twice before the shared pipeline (ClipBpeTokenizer does too); the
+        # transformers class does not, so it is handed the unescaped text
+        want = other(html.unescape(html.unescape(t)))["input_ids"]
+        got = [mine.sot] + mine.encode(t) + [mine.eot]
+        assert got == want, (t, got[:16], want[:16])
