@@ -157,7 +157,7 @@ def multi_gpu_preflight(torch, dist, fd, rank, world, local, device, backend):
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / reps
-    ok = bool((out.view(world, -1)[:, 0].float().cpu() == torch.arange(world, dtype=torch.float32)).all())
+    ok_here = bool((out.view(world, -1)[:, 0].float().cpu() == torch.arange(world, dtype=torch.float32)).all())
     t = torch.tensor([ms], dtype=torch.float64, device=device)
     if backend == "gloo":
         th = t.cpu()
@@ -166,6 +166,11 @@ def multi_gpu_preflight(torch, dist, fd, rank, world, local, device, backend):
     else:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = t.item()
+    # every rank learns of a bad payload on ANY rank and they all leave together -- a rank that exits alone leaves the others
+    # hanging in the gallery build's collectives until the process-group timeout
+    oks = [None] * world
+    dist.all_gather_object(oks, ok_here)
+    ok = all(oks)
     recv = (world - 1) * per
     info = {"rccl_world": world if backend == "nccl" else f"{world} (debug backend {backend})", "backend": backend, "ranks": everyone,
             "all_gather_64MiB_per_rank": {"ms": ms, "bytes_received_per_rank": recv, "GBs_per_rank": recv / (ms * 1e-3) / 1e9,
@@ -173,7 +178,7 @@ def multi_gpu_preflight(torch, dist, fd, rank, world, local, device, backend):
     if rank == 0:
         print("[bench preflight] " + json.dumps(info), file=sys.stderr, flush=True)
     if not ok:
-        raise SystemExit("bench preflight: the all-gather returned the wrong blocks")
+        raise SystemExit("bench preflight: the all-gather returned the wrong blocks on rank(s) " + str([r for r, o in enumerate(oks) if not o]))
     return info
 
 

@@ -57,6 +57,9 @@ SIGNATURES = {
                               c_void_p, c_void_p]),
     "fern_gallery_to_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "fern_sim_topk_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "fern_gallery_prepare": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
+    "fern_sim_topk_prefiltered": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_i64,
+                                          c_void_p, c_void_p]),
     "fern_gather_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fern_topk_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fern_gemm": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,

@@ -97,10 +97,14 @@ class FernCLIP:
         # serves both.  "The same tokens" is decided WITHOUT a device sync: host tokens (what the reference's tokenizer yields)
         # are compared on the host; device tokens ONLY by object identity + torch's in-place version counter, with the cache
         # holding a strong reference to the tensor (a freed block handed out again at the same address with version 0 and the
-        # same shape must not hit: ADVICE r3).  `visual_emb` is part of the key by identity as well.
+        # same shape must not hit: ADVICE r3).  `visual_emb` is part of the key as well
+        # (by identity AND in-place version -- a preallocated buffer refilled with `copy_` is a different argument: ADVICE r4).
+        # The entry is dropped once the "seq" call has been served: the pair of calls it exists for is over, and the cache must not
+        # keep the caller's device tensors (tokens, visual_emb, a [B,77,D] output) alive until some later miss.
         c = self._text_cache
         hit = False
-        if c is not None and c["visual_emb"] is visual_emb:
+        ve_version = None if visual_emb is None else visual_emb._version
+        if c is not None and c["visual_emb"] is visual_emb and c["ve_version"] == ve_version:
             if text.is_cuda:
                 hit = c["tensor"] is text and c["version"] == text._version
             else:
@@ -108,11 +112,14 @@ class FernCLIP:
                 hit = h is not None and h.shape == text.shape and h.dtype == text.dtype and torch.equal(h, text)
         if hit:
             g, s = c["global"], c["seq"]
+            if mode == "seq":
+                self._text_cache = None
         else:
             t = text.to(device=self.device, dtype=torch.int64)
             g, s = self.engine.encode_text(t, visual_emb=visual_emb)
-            self._text_cache = {"tensor": text if text.is_cuda else None, "version": text._version,
-                                "host": None if text.is_cuda else text.clone(), "visual_emb": visual_emb, "global": g, "seq": s}
+            self._text_cache = None if mode == "seq" else {
+                "tensor": text if text.is_cuda else None, "version": text._version, "host": None if text.is_cuda else text.clone(),
+                "visual_emb": visual_emb, "ve_version": ve_version, "global": g, "seq": s}
         return s if mode == "seq" else (g, s)
 
 

@@ -225,6 +225,26 @@ static int prof_close(fern_ctx* c, int slot, hipStream_t s) {
     return FERN_OK;
 }
 
+// A launch that failed after prof_open: disarm the timer, hand the events of the dispatches that did go out back to the pool and
+// drop the record -- left in place it would count as a 0 ms launch carrying its full flops.  Records are appended and
+// closed in order on one thread, so an open record is always the last one.
+static void prof_abort(fern_ctx* c, int slot) {
+    g_launch_timer = nullptr;
+    for (hipEvent_t e : c->timer.events) c->ev_pool.push_back(e);
+    c->timer.events.clear();
+    if (slot < 0 || slot != (int)c->recs.size() - 1) return;
+    ProfRec& r = c->recs[slot];
+    if (r.a) c->ev_pool.push_back(r.a);
+    if (r.b) c->ev_pool.push_back(r.b);
+    c->recs.pop_back();
+}
+#define HIP_TRY_PROF(le, c, slot)                  \
+    do {                                            \
+        const hipError_t le__ = (le);               \
+        if (le__ != hipSuccess) prof_abort(c, slot); \
+        HIP_TRY(le__);                              \
+    } while (0)
+
 static int run_gemm(fern_ctx* c, const GemmParams& p, hipStream_t s, int kind = PROF_GEMM, double work = -1.0) {
     int slot;
     FERN_TRY(prof_open(c, kind, work >= 0 ? work : 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, p.epi));
@@ -236,8 +256,7 @@ static int run_gemm(fern_ctx* c, const GemmParams& p, hipStream_t s, int kind = 
     } else {
         le = launch_gemm(p, s);
     }
-    g_launch_timer = nullptr;                                    // (prof_close collects the events; a failed launch must not leave the timer armed)
-    HIP_TRY(le);
+    HIP_TRY_PROF(le, c, slot);                                   // (a failed launch must not leave the timer armed, nor a 0 ms record behind)
     if (slot >= 0) c->recs[slot].dispatches = gemm_last_dispatches();
     return prof_close(c, slot, s);
 }
@@ -276,16 +295,14 @@ static int run_gemm_b(fern_ctx* c, const GemmParams& p, hipStream_t s) {
     int slot;
     FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * p.M * (double)p.N * p.K, s, &slot, p.M, p.N, p.K, (p.fp8 == 2 ? 300 : p.fp8 ? 200 : 100) + p.epi));
     const hipError_t le = launch_gemm_bf16(p, s);
-    g_launch_timer = nullptr;
-    HIP_TRY(le);
+    HIP_TRY_PROF(le, c, slot);
     return prof_close(c, slot, s);
 }
 static int run_attention(fern_ctx* c, const AttnParams& a, hipStream_t s) {
     int slot;
     FERN_TRY(prof_open(c, PROF_ATTN, 4.0 * a.batch * a.heads * (double)a.s_q * a.s_k * a.hd, s, &slot, a.batch * a.heads, a.s_q, a.hd, a.causal));
     const hipError_t le = launch_attention(a, s);
-    g_launch_timer = nullptr;
-    HIP_TRY(le);
+    HIP_TRY_PROF(le, c, slot);
     return prof_close(c, slot, s);
 }
 
@@ -1529,8 +1546,8 @@ struct RankPlan {
     unsigned long long* partial;
     TopkFilter filt;
 };
-static int rank_plan(fern_ctx* c, int m, int64_t N, int K, const int32_t* exclude, int64_t idx_offset, RankPlan* P) {
-    P->S = std::min<long>(std::max<long>(N / 64, std::min<long>(N, 4096)), 32768);      // the bound kernel holds a query's sample in registers
+static int rank_plan(fern_ctx* c, int m, int64_t N, int K, const int32_t* exclude, int64_t idx_offset, RankPlan* P, long sample_rows = 0) {
+    P->S = sample_rows > 0 ? sample_rows : std::min<long>(std::max<long>(N / 64, std::min<long>(N, 4096)), 32768);      // the bound kernel holds a query's sample in registers
     P->R = P->S > 0 ? (int)(N / P->S) : 1;
     // a list sees ~K * R / 256 survivors (<= 16 at K = R = 64; beyond N = 2M rows R grows past 64 and lists start to overflow:
     // those queries are then ranked by the exact pass -- still exact, a gallery pass slower); 64 entries is what one wave load of
@@ -1637,12 +1654,80 @@ extern "C" int fern_sim_topk_bf16(fern_ctx* c, const float* q, const uint16_t* g
             const TopkFilter f = block_filter(b0);
             FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + (double)mb * D * 4 + (double)mb * K * 8, s, &slot, mb, (int)N, D, 16));
             const hipError_t le = launch_sweep_bf16(q + (o + b0) * D, gallery, nullptr, 0, mb, N, D, 0, 1, &f, nullptr, s);
-            g_launch_timer = nullptr;
-            HIP_TRY(le);
+            HIP_TRY_PROF(le, c, slot);
             FERN_TRY(prof_close(c, slot, s));
         }
         HIP_TRY(launch_topk_candidates(P.filt, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, P.state, s));
         HIP_TRY(launch_rank_exact(q + o * D, gallery, 1, m, N, D, K, P.state, P.thr, ex, idx_offset, idx_offset, P.partial, P.groups, P.done,
+                                  out_scores + o * K, out_idx + o * K, P.flags, s));
+        FERN_TRY(prof_close(c, stage, s));
+    }
+    return FERN_OK;
+}
+
+// Certified bf16 pre-filter + exact fp32 rescoring (include/fern.h: fern_sim_topk_prefiltered).  Same plan buffers and kernels as the
+// bf16 sweep for steps 1-3; the bound is lowered by the certified margin, and the final kernel rescored the survivors with the exact
+// fp32 chain from the fp32 gallery.  Shapes the bf16 sweep does not cover run fern_sim_topk (same results by definition).
+extern "C" int fern_gallery_prepare(fern_ctx* c, const float* gallery, int64_t N, int D, uint16_t* out_bf16, float* out_meta, void* stream) {
+    if (!c || N < 0 || D <= 0 || !out_meta || (N && (!gallery || !out_bf16))) return fail(FERN_ERR_ARG, "fern_gallery_prepare: bad argument");
+    if (D % 4) return fail(FERN_ERR_ARG, "fern_gallery_prepare: D must be a multiple of 4");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_gallery_prepare(gallery, out_bf16, (long)N, D, out_meta, (hipStream_t)stream));
+    return FERN_OK;
+}
+
+static long prefilter_sample_rows(int64_t N) {
+    // a denser sample than the plain plan's (1 in 32 instead of 1 in 64 beyond 131k rows): the margin lowers the bound by ~0.1 sigma of the
+    // score distribution, a tighter sample bound pays that back; 32768 is what the bound kernel holds in registers
+    return std::min<long>(std::max<long>(N / 32, std::min<long>(N, 4096)), 32768);
+}
+
+extern "C" int fern_sim_topk_prefiltered(fern_ctx* c, const float* q, const float* gallery, const uint16_t* gallery_bf16, const float* meta, int B,
+                                         int64_t N, int D, int K, float* out_scores, int32_t* out_idx, int64_t idx_offset,
+                                         const int32_t* exclude_idx, void* stream) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_sim_topk_prefiltered: ctx is NULL");
+    if (B < 0 || N < 0 || K < 1 || K > 64 || D <= 0 || D % 32) return fail(FERN_ERR_ARG, "fern_sim_topk_prefiltered: need 1<=K<=64, D % 32 == 0");
+    if (B && (!q || !out_scores || !out_idx || (N && (!gallery || !gallery_bf16 || !meta)))) return fail(FERN_ERR_ARG, "fern_sim_topk_prefiltered: NULL argument");
+    if (N > 0x7FFFFFF0LL) return fail(FERN_ERR_ARG, "fern_sim_topk_prefiltered: N too large for int32 indices");
+    static const bool off = [] { const char* e = std::getenv("FERN_RANK_PREFILTER"); return e && e[0] == '0'; }();      // A/B switch
+    if (off || D % 64 || D > 768 || N == 0)       // outside the bf16 sweep's shapes (its LDS ring needs >= 3 stages): the plain fp32 stage (identical results)
+        return fern_sim_topk(c, q, gallery, B, N, D, K, out_scores, out_idx, idx_offset, exclude_idx, stream);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) return FERN_OK;
+    for (long o = 0; o < B; o += (long)kRankQueryChunk) {
+        const int m = (int)std::min<long>((long)kRankQueryChunk, B - o);
+        const int32_t* ex = exclude_idx ? exclude_idx + o : nullptr;
+        FERN_TRY(ws_begin(c, s));
+        RankPlan P;
+        FERN_TRY(rank_plan(c, m, N, K, ex, idx_offset, &P, prefilter_sample_rows(N)));
+        float* margin;
+        FERN_TRY(ws_get(c, (size_t)m, &margin));
+        const long QBLK = (D == 64 || D == 128 || D == 256 || D == 512) ? 128 : 64;
+        auto block_filter = [&](long b0) {
+            TopkFilter f = P.filt;
+            f.cand += b0 * RANK_SLOTS * P.cap; f.thr_key += b0; f.count += b0 * RANK_SLOTS;
+            if (f.exclude) f.exclude += b0;
+            return f;
+        };
+        int slot, stage;
+        FERN_TRY(prof_open(c, PROF_STAGE, 0, s, &stage));
+        for (long b0 = 0; b0 < m; b0 += QBLK)
+            HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery_bf16, P.sample + b0 * P.ld, P.ld, (int)std::min<long>(QBLK, m - b0), N, D, P.S, P.R,
+                                      nullptr, nullptr, s));
+        HIP_TRY(launch_topk_sample_bound(P.sample, P.ld, m, P.S, P.R, K, ex, idx_offset, P.thr, P.count, P.flags, P.state, s, q + o * D, D, meta, margin));
+        for (long b0 = 0; b0 < m; b0 += QBLK) {
+            const int mb = (int)std::min<long>(QBLK, m - b0);
+            const TopkFilter f = block_filter(b0);
+            // bytes this kernel streams: the bf16 copy once, the queries, nothing stored (the STAGE's algorithmic bytes -- SURVEY 8d, an fp32
+            // gallery: N D 4 -- are the caller's to quote against the stage time)
+            FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + (double)mb * D * 4 + (double)mb * K * 8, s, &slot, mb, (int)N, D, 16));
+            const hipError_t le = launch_sweep_bf16(q + (o + b0) * D, gallery_bf16, nullptr, 0, mb, N, D, 0, 1, &f, nullptr, s);
+            HIP_TRY_PROF(le, c, slot);
+            FERN_TRY(prof_close(c, slot, s));
+        }
+        HIP_TRY(launch_topk_rescore(P.filt, q + o * D, gallery, D, margin, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, P.state, s));
+        HIP_TRY(launch_rank_exact(q + o * D, gallery, 0, m, N, D, K, P.state, P.thr, ex, idx_offset, idx_offset, P.partial, P.groups, P.done,
                                   out_scores + o * K, out_idx + o * K, P.flags, s));
         FERN_TRY(prof_close(c, stage, s));
     }
@@ -1723,8 +1808,7 @@ extern "C" int fern_gemm_bf16(fern_ctx* c, const uint16_t* A, int64_t lda, const
     int slot;
     FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * M * (double)N * K, (hipStream_t)stream, &slot, M, N, K, 100 + epilogue));
     const hipError_t le = launch_gemm_bf16(p, (hipStream_t)stream);
-    g_launch_timer = nullptr;
-    HIP_TRY(le);
+    HIP_TRY_PROF(le, c, slot);
     return prof_close(c, slot, (hipStream_t)stream);
 }
 

@@ -364,6 +364,9 @@ template <int IN, int OUT>
 static bool launch_ln_rows(const void* x, const float* gamma, const float* beta, void* y, unsigned char* scales, long srows, long rows, int d,
                            long ldx, long ldy, float eps, hipStream_t s) {
     if (d % 256 || d > 1024) return false;
+    // gamma / beta are read as f32x4 and (OUT = 1) four rows' scale dwords leave as one 16-byte store: the public entry points accept
+    // any 4-byte-aligned view, so a pointer that is not 16-byte aligned takes the one-row kernel instead
+    if (((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || (OUT == 1 && ((uintptr_t)scales & 15))) return false;
     const dim3 grid((unsigned)((rows + ROWS_PER_BLOCK * LN_RPW - 1) / (ROWS_PER_BLOCK * LN_RPW)));
     switch (d / 256) {
         case 1: hipLaunchKernelGGL((layernorm_rows_kernel<1, LN_RPW, IN, OUT>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;

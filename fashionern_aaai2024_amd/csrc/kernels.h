@@ -366,6 +366,8 @@ hipError_t launch_u8_to_chw(const unsigned char* src, long src_ld, int x0, int y
 // ---- bf16 gallery sweep (sweep_bf16.hip) ---------------------------------------------------------------------------
 hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStream_t s);
 hipError_t launch_bf16_to_f32(const unsigned short* x, float* y, long n, hipStream_t s);      // exact (n % 4 == 0)
+// y = bf16(x) (RNE) and meta[0..2] = max over rows of ||x_n - y_n||, ||y_n||, ||x_n|| (meta[3] = 0): what certifies y as a pre-filter
+hipError_t launch_gallery_prepare(const float* x, unsigned short* y, long n, int d, float* meta, hipStream_t s);
 // q < B <= 64 queries against a bf16 gallery [N, D] (D % 64 == 0), fp32 accumulation.
 // Sample form (filt == null): scores[q, c] = Q[q] . G[sample_row(c, R)] for c < S, row stride ld.
 // Filter form (filt != null): nothing is stored, survivors go to filt (gate as GemmParams.gate).
@@ -376,8 +378,17 @@ hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* sco
 // Fused sweep, step 2: per query the K-th best key of the sample scores [B, ld] (S valid columns; column c is gallery row
 // sample_row(c, R)) -> thr_key[b] (0 when the sample holds fewer than K rows); also resets count[b][*] and flags[0..1].  A sample
 // row that is the query's excluded gallery index (exclude[b] - exclude_off, exclude may be null) does not count.
+// Pre-filter form (q != null; fern_sim_topk_prefiltered): the sample scores are bf16-sweep approximations of the exact fp32 scores; the
+// published bound is lowered by the certified margin 2 eps_b (topk.hip: BoundMargin; meta = launch_gallery_prepare's {E, G~, G}) and
+// margin_out[b] keeps the margin for launch_topk_rescore.
 hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S, int R, int K, const int* exclude, long exclude_off,
-                                    unsigned long long* thr_key, int* count, int* flags, int* state, hipStream_t s);
+                                    unsigned long long* thr_key, int* count, int* flags, int* state, hipStream_t s, const float* q = nullptr,
+                                    int D = 0, const float* meta = nullptr, float* margin_out = nullptr);
+// Final step of the certified pre-filter: T~ = K-th best approximate key of each query's lists, survivors = rows within `margin` of it,
+// exact fp32 fma-chain score (the sweep's k order) of every survivor from the fp32 gallery, exact top-K of those.  Queries without
+// room (list overflow, > 6144 candidates, > 1024 survivors) are flagged for launch_rank_exact.  D % 32 == 0, D <= 1024.
+hipError_t launch_topk_rescore(const TopkFilter& f, const float* q, const float* gallery, int D, const float* margin, int B, int K, long idx_offset,
+                               float* out_scores, int* out_idx, int* flags, int* state, hipStream_t s);
 // Fused sweep, final step: exact top-K of each query's candidate list -> out (idx = row + idx_offset; unfilled: -inf / -1).
 // A query with an overflowed list (a count > cap) is not written in the first pass: its bound is raised to the K-th best of the
 // stored candidates, its counts reset, flags[0] set, and the sweep + this kernel run again with pass = 1 (gated on

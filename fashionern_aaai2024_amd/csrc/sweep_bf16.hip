@@ -44,6 +44,35 @@ __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const u16* x, float* y
     reinterpret_cast<f32x4*>(y)[i] = o;
 }
 
+// fern_gallery_prepare: the bf16 copy of an fp32 gallery (round to nearest even, as f32_to_bf16_kernel) AND what certifies it as a
+// pre-filter of the exact fp32 ranking (api.hip: fern_sim_topk_prefiltered): meta[0] = max_n ||g_n - bf16(g_n)||, meta[1] = max_n
+// ||bf16(g_n)||, meta[2] = max_n ||g_n|| (2-norms, fp32; the row sums are added in a fixed lane order, so a row's value -- and so
+// the maxima -- do not depend on the launch).  g - bf16(g) is exact in fp32.  One wave per row, D % 4 == 0, any D.
+__global__ __launch_bounds__(256) void gallery_prepare_kernel(const float* x, u16* y, long n, int d, float* meta) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float e2 = 0.f, t2 = 0.f, g2 = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * d + c);
+        ushort4 o;
+        o.x = f32_to_bf16_rne(v[0]); o.y = f32_to_bf16_rne(v[1]); o.z = f32_to_bf16_rne(v[2]); o.w = f32_to_bf16_rne(v[3]);
+        *reinterpret_cast<ushort4*>(y + row * d + c) = o;
+        const float r0 = bf16_bits_to_f32(o.x), r1 = bf16_bits_to_f32(o.y), r2 = bf16_bits_to_f32(o.z), r3 = bf16_bits_to_f32(o.w);
+        const float d0 = v[0] - r0, d1 = v[1] - r1, d2 = v[2] - r2, d3 = v[3] - r3;
+        e2 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        t2 += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
+        g2 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { e2 += __shfl_xor(e2, m); t2 += __shfl_xor(t2, m); g2 += __shfl_xor(g2, m); }
+    if (lane == 0) {      // non-negative floats order like their bit patterns; NaN / inf rows poison the bound upwards (a NaN margin accepts every row)
+        atomicMax(reinterpret_cast<unsigned*>(meta + 0), __float_as_uint(sqrtf(e2)));
+        atomicMax(reinterpret_cast<unsigned*>(meta + 1), __float_as_uint(sqrtf(t2)));
+        atomicMax(reinterpret_cast<unsigned*>(meta + 2), __float_as_uint(sqrtf(g2)));
+    }
+}
+
 constexpr int ROWS_T = 32;              // gallery rows per wave tile
 constexpr int KSTAGE = 64;              // k elements per ring stage (128 bytes per row)
 constexpr int STAGE_BYTES = ROWS_T * KSTAGE * 2;   // 4096
@@ -302,6 +331,14 @@ hipError_t launch_f32_to_bf16(const float* x, unsigned short* y, long n, hipStre
     return hipGetLastError();
 }
 
+hipError_t launch_gallery_prepare(const float* x, unsigned short* y, long n, int d, float* meta, hipStream_t s) {
+    if (d <= 0 || (d & 3)) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(meta, 0, 4 * sizeof(float), s);
+    if (e != hipSuccess || n <= 0) return e;
+    hipLaunchKernelGGL(gallery_prepare_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, y, n, d, meta);
+    return hipGetLastError();
+}
+
 hipError_t launch_bf16_to_f32(const unsigned short* x, float* y, long n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (n & 3) return hipErrorInvalidValue;
@@ -348,6 +385,7 @@ static hipError_t launch_sweep_mode(const float* q, const unsigned short* g, flo
             case 128: return launch_sweep_inst<9, FILTER, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
             case 256: return launch_sweep_inst<9, FILTER, 4>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
             case 512: return launch_sweep_inst<9, FILTER, 8>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+            case 640: return launch_sweep_inst<9, FILTER, 10>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);      // RN50x4 (C3): 320 fragment VGPRs of the 512
             default: break;
         }
     }

@@ -262,23 +262,27 @@ __device__ __forceinline__ bool select_kth_fast(const unsigned (&h)[PER], LoOf l
 // k-th largest (k >= 1) of the workgroup's keys: thread-local hi words h[0..PER) (0 = empty slot) and lo words from lo_of(j).
 // Returns 0 when fewer than k keys exist.  Every thread of the workgroup (NW waves) must call it (barriers inside).  `ck`:
 // SELECT_CAPF keys of LDS for the fast path (null: bisection only); red: 4 * NW + 8 ints.
-template <int PER, int NW, class LoOf>
+// HAVE_K: the caller knows that at least k keys exist (skips the count and its barrier).
+template <int PER, int NW, bool HAVE_K = false, class LoOf>
 __device__ __forceinline__ u64 select_kth_largest(const unsigned (&h)[PER], LoOf lo_of, int k, int* red, u64* ck = nullptr) {
     WgReduce<NW> wg{red, 0};
-    int nv = 0;
-    unsigned mn = 0xFFFFFFFFu, mx = 0;
+    if (!HAVE_K) {
+        int nv = 0;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        nv += h[j] != 0;
-        mn = (h[j] != 0 && h[j] < mn) ? h[j] : mn;
-        mx = h[j] > mx ? h[j] : mx;
+        for (int j = 0; j < PER; ++j) nv += h[j] != 0;
+        if (wg.sum(nv) < k) return 0;
     }
-    if (wg.sum(nv) < k) return 0;
     if (ck) {
-        __syncthreads();                                                 // the reduction above is done with `red`
+        if (!HAVE_K) __syncthreads();                                    // the reduction above is done with `red`
         u64 fast;
         if (select_kth_fast<PER, NW>(h, lo_of, k, ck, red, fast)) return fast;
         wg.step = 0;
+    }
+    unsigned mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        mn = (h[j] != 0 && h[j] < mn) ? h[j] : mn;
+        mx = h[j] > mx ? h[j] : mx;
     }
     unsigned lo = wg.min(mn), hi = wg.max(mx);
     while (lo < hi) {                                     // largest v with count(h >= v) >= k
@@ -321,13 +325,57 @@ __device__ __forceinline__ u64 select_kth_largest(const unsigned (&h)[PER], LoOf
 // the real row.  Fewer than K sample rows -> bound 0 (accept all).  Also resets the query's list counters.
 // NT threads: 256 (four waves: a barrier among them is a fraction of the 16-wave one, and a bisection step is mostly barrier) for
 // samples of <= 4096 rows, 1024 for the larger ones (registers: PER keys per thread).
+// Pre-filter form (margin.q != null; api.hip: fern_sim_topk_prefiltered): the sample scores are the bf16 sweep's APPROXIMATIONS s~ of
+// the exact fp32 scores s.  With q~ = bf16(q), g~ = bf16(g):  s - s~ = q.(g - g~) + (q - q~).g~  (+ the two accumulations' rounding), so
+//     |s - s~| <= eps_b = ||q_b|| E + ||q_b - q~_b|| G~ + slack,   E = max_n ||g_n - g~_n||, G~ = max_n ||g~_n||   (Cauchy-Schwarz)
+// for EVERY gallery row -- E, G~, G = max ||g_n|| come from fern_gallery_prepare, the query's two norms are computed here.  If T~ is
+// the K-th best approximate score of the whole gallery, every row of the exact top-K has s~ >= T~ - 2 eps (K rows have s >= T~ - eps,
+// so the exact K-th best is >= T~ - eps, and a row at or above it has s~ >= s - eps).  The sample's K-th best is <= T~, so the bound
+// published for the sweep is (sample K-th best) - margin, margin = 2 eps_b, as a key with the lowest index part; margin_out[b] keeps
+// the margin for the rescoring kernel.  slack covers fp32 accumulation in both dot products (D 2^-21 ||q|| max(G, G~): four times
+// the textbook D u bound each, the MFMA's internal adder tree is not specified) and the rounding of the norms themselves.
+struct BoundMargin {
+    const float* q;          // [B, D] fp32 queries (null: no margin -- the sample scores ARE the ranking scores)
+    int D;
+    const float* meta;       // fern_gallery_prepare: {E, G~, G}
+    float* margin_out;       // [B]
+};
+template <int NT>
+__device__ __forceinline__ float bound_margin_of(const BoundMargin& m, int b, float* fred) {
+    const int tid = threadIdx.x;
+    float a = 0.f, e = 0.f;
+    for (int i = tid; i < m.D; i += NT) {
+        const float v = m.q[(long)b * m.D + i];
+        const float d = v - bf16_bits_to_f32(f32_to_bf16_bits(v));      // exact
+        a += v * v;
+        e += d * d;
+    }
+#pragma unroll
+    for (int x = 32; x >= 1; x >>= 1) { a += __shfl_xor(a, x); e += __shfl_xor(e, x); }
+    if ((tid & 63) == 0) { fred[tid >> 6] = a; fred[NT / 64 + (tid >> 6)] = e; }
+    __syncthreads();
+    a = 0.f; e = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { a += fred[w]; e += fred[NT / 64 + w]; }
+    __syncthreads();
+    const float nq = sqrtf(a), eq = sqrtf(e);
+    const float E = m.meta[0], Gt = m.meta[1], G = m.meta[2];
+    const float eps = (nq * E + eq * Gt) * 1.00390625f + (float)m.D * 4.76837158203125e-7f * nq * fmaxf(G, Gt);      // (1 + 2^-8); D 2^-21
+    return 2.0f * eps * 1.0009765625f;      // NaN (a NaN / inf row or query) makes every compare below accept: the exact pass sorts it out
+}
+
 template <int PER, int NT>
 __global__ __launch_bounds__(NT) void topk_sample_bound_kernel(const float* scores, long ld, long S, int R, int K, const int* exclude,
-                                                                long exclude_off, u64* thr_key, int* count, int* flags, int* state) {
+                                                                long exclude_off, u64* thr_key, int* count, int* flags, int* state, BoundMargin mg) {
     __shared__ int red[80];
     __shared__ u64 ck[SELECT_CAPF];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* row = scores + (long)b * ld;
+    float margin = 0.f;
+    if (mg.q) {
+        margin = bound_margin_of<NT>(mg, b, reinterpret_cast<float*>(red));
+        if (tid == 0) mg.margin_out[b] = margin;
+    }
     // sample column of the excluded gallery row (if it was sampled at all): it must not count towards the K rows of the bound
     long drop = -1;
     if (exclude) {
@@ -349,6 +397,10 @@ __global__ __launch_bounds__(NT) void topk_sample_bound_kernel(const float* scor
         if (kth != 0) {
             const long c = (long)(0xFFFFFFFFu - (unsigned)kth);
             out = (kth & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - (unsigned)sample_row(c, R));
+            if (mg.q) {      // certified pre-filter: lowered by the margin, index part = lowest (every row with that score passes)
+                const float lowered = unorderable((unsigned)(kth >> 32)) - margin;
+                out = lowered == lowered ? (u64)orderable(lowered) << 32 : 0ull;      // NaN margin: accept all
+            }
         }
         thr_key[b] = out;
         state[b] = 0;                      // 0: ranked by the select kernel; 1: lists overflowed -> exact pass; also its done-counter
@@ -453,6 +505,174 @@ __global__ __launch_bounds__(256) void topk_candidates_kernel(TopkFilter f, int 
     }
 }
 
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+// ---- certified pre-filter: select on the approximate keys, then rescore the survivors exactly ---------------------------------------
+// Final step of fern_sim_topk_prefiltered.  The candidate lists hold APPROXIMATE keys (bf16 sweep scores s~) of every row with
+// s~ >= (sample bound) - margin.  Per query (one workgroup): gather the lists as topk_candidates_kernel does, T~ = the K-th best
+// approximate score (exact, of the whole gallery: every row at or above the sample bound is in the lists), keep the rows with
+// s~ >= T~ - margin -- a superset of the exact top-K (topk_sample_bound_kernel's comment has the argument) -- and give each survivor
+// its EXACT fp32 score: one sequential v_fma_f32 chain per (query, row) in the k order of the fp32 MFMA kernels (8g, 8g+4, 8g+1, 8g+5,
+// ...: oracle/chain.c), i.e. bit for bit the score fern_sim_topk's sweep produces.  The exact keys are then ranked.  Output = the
+// exact top-K with the exact scores; the approximate scores decide nothing but which ~K + (rows within the margin) rows get rescored.
+// Rescoring loads are COALESCED: a wave takes 64 survivors at a time and walks D in 64-float chunks; 16 lanes fetch one row's 256-byte
+// chunk (4 rows per load instruction), the chunk tile [64 rows][64 k] is transposed through the wave's LDS tile and lane l then runs
+// survivor l's chain over its 64 k.  (One lane loading its own row touches 64 cache lines per instruction: 8x the address work.)
+// Anything without room -- a list overflow, more than CAND_MAX candidates, more than RESC_MAX survivors (galleries of near-ties) --
+// goes to the exact pass (rank_exact_kernel on the fp32 gallery), whose bound (sample bound - margin) is a valid lower bound of the
+// exact K-th best too.
+constexpr int RESC_MAX = 1024;                  // survivors per query that are rescored here
+constexpr int RESC_PER = RESC_MAX / 256;
+constexpr int RESC_CH = 32;                     // k per chunk of the transposing tile
+constexpr int RESC_TLD = RESC_CH + 4;           // floats per tile row (+ 4: lane l's ds_read_b128 of row l starts 4 banks after lane l-1's)
+static_assert(4 * 64 * RESC_TLD * 4 <= CAND_MAX * 8, "the four waves' tiles overlay the candidate keys");
+__global__ __launch_bounds__(256) void topk_rescore_kernel(TopkFilter f, const float* q, const float* gallery, int D, const float* margin_in, int K,
+                                                           long idx_offset, float* out_scores, int* out_idx, int* flags, int* state) {
+    __shared__ __attribute__((aligned(16))) u64 c_key[CAND_MAX];      // candidates (approximate keys); then select_kth_fast's compact list; then the waves' tiles
+    __shared__ u64 x_key[RESC_MAX];             // exact keys of the survivors
+    __shared__ unsigned surv[RESC_MAX];         // gallery rows of the survivors
+    __shared__ __attribute__((aligned(16))) float qrow[1024];
+    __shared__ int red[32];
+    __shared__ u64 lists[64];
+    __shared__ int wtotal[4], over[4], nsel, nsurv;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cnt_raw = f.count[(long)b * RANK_SLOTS + tid];      // thread t owns list t
+    const int cnt = cnt_raw < f.cap ? cnt_raw : f.cap;
+    const bool overflow_w = __any(cnt_raw > f.cap);
+    const int incl = wave_inclusive_sum(cnt, lane);
+    if (lane == 63) { wtotal[wave] = incl; over[wave] = overflow_w ? 1 : 0; }
+    if (tid == 0) { nsel = 0; nsurv = 0; }
+    for (int i = tid; i < D; i += 256) qrow[i] = q[(long)b * D + i];
+    __syncthreads();
+    const int total = wtotal[0] + wtotal[1] + wtotal[2] + wtotal[3];
+    if ((over[0] | over[1] | over[2] | over[3]) != 0 || total > CAND_MAX) {
+        if (tid == 0) { state[b] = 1; flags[0] = 1; }
+        return;
+    }
+    int base = incl - cnt;
+    for (int w = 0; w < wave; ++w) base += wtotal[w];
+    const u64* cand = f.cand + (long)b * RANK_SLOTS * f.cap;
+    {
+        int maxc = cnt;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(maxc, m); maxc = o > maxc ? o : maxc; }
+        const u64* mylist = cand + (long)tid * f.cap;
+#pragma unroll 1
+        for (int e0 = 0; e0 < maxc; e0 += 8) {
+            u64 key[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) key[u] = e0 + u < cnt ? mylist[e0 + u] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u < cnt) c_key[base + e0 + u] = key[u];
+        }
+    }
+    __syncthreads();
+    u64 mine[CAND_PER];
+    unsigned h[CAND_PER];
+#pragma unroll
+    for (int j = 0; j < CAND_PER; ++j) {
+        const int i = tid + 256 * j;
+        mine[j] = i < total ? c_key[i] : 0;
+        h[j] = (unsigned)(mine[j] >> 32);
+    }
+    const int want = total < K ? total : K;
+    u64 kth = 0;
+    __syncthreads();                                 // keys are in registers: c_key's head becomes the fast path's compact list
+    if (total > K) kth = select_kth_largest<CAND_PER, 4, true>(h, [&](int j) { return (unsigned)mine[j]; }, want, red, c_key);
+    // survivors: approximate score >= T~ - margin (total <= K: every candidate); a NaN on either side keeps the row
+    const float cut = kth != 0 ? unorderable((unsigned)(kth >> 32)) - margin_in[b] : -INFINITY;
+#pragma unroll
+    for (int j = 0; j < CAND_PER; ++j) {
+        if (mine[j] != 0 && !(unorderable(h[j]) < cut)) {
+            const int p = atomicAdd(&nsurv, 1);
+            if (p < RESC_MAX) surv[p] = 0xFFFFFFFFu - (unsigned)mine[j];
+        }
+    }
+    __syncthreads();                                 // also: nobody reads c_key as keys any more -- it becomes the tiles
+    const int ns = nsurv;
+    if (ns > RESC_MAX) {
+        if (tid == 0) { state[b] = 1; flags[0] = 1; }
+        return;
+    }
+    // exact rescoring, 64 survivors per wave and round
+    float* tl = reinterpret_cast<float*>(c_key) + wave * (64 * RESC_TLD);
+    const int lrow = lane >> 3, lcol = (lane & 7) * 4;       // loader role: row inside a group of 8, float offset inside the 32-float chunk
+    for (int s0 = wave * 64; s0 < ns; s0 += 256) {
+        const float* src[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = s0 + i * 8 + lrow;
+            src[i] = gallery + (long)surv[r < ns ? r : s0] * D + lcol;      // rows past the end redo survivor s0 (discarded)
+        }
+        f32x4e nxt[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) nxt[i] = *reinterpret_cast<const f32x4e*>(src[i]);
+        float acc = 0.0f;
+        for (int c0 = 0; c0 < D; c0 += RESC_CH) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4e*>(tl + (i * 8 + lrow) * RESC_TLD + lcol) = nxt[i];
+            if (c0 + RESC_CH < D) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) nxt[i] = *reinterpret_cast<const f32x4e*>(src[i] + c0 + RESC_CH);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own tile writes have landed (no other wave touches this tile)
+            const float* mrow = tl + lane * RESC_TLD;
+#pragma unroll
+            for (int g8 = 0; g8 < RESC_CH / 8; ++g8) {
+                const f32x4e g0 = *reinterpret_cast<const f32x4e*>(mrow + g8 * 8), g1 = *reinterpret_cast<const f32x4e*>(mrow + g8 * 8 + 4);
+                const f32x4e q0 = *reinterpret_cast<const f32x4e*>(qrow + c0 + g8 * 8), q1 = *reinterpret_cast<const f32x4e*>(qrow + c0 + g8 * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = __builtin_fmaf(q0[e], g0[e], acc);
+                    acc = __builtin_fmaf(q1[e], g1[e], acc);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile reads done before the next chunk overwrites it
+        }
+        if (s0 + lane < ns) x_key[s0 + lane] = make_key(acc, surv[s0 + lane]);
+    }
+    __syncthreads();
+    // rank the exact keys
+    u64 best = 0;
+    if (ns <= 64) {
+        if (wave != 0) return;
+        best = sort64_desc(lane < ns ? x_key[lane] : 0, lane);
+    } else {
+        u64 xm[RESC_PER];
+        unsigned xh[RESC_PER];
+#pragma unroll
+        for (int j = 0; j < RESC_PER; ++j) {
+            const int i = tid + 256 * j;
+            xm[j] = i < ns ? x_key[i] : 0;
+            xh[j] = (unsigned)(xm[j] >> 32);
+        }
+        const int want2 = ns < K ? ns : K;
+        __syncthreads();
+        const u64 kx = select_kth_largest<RESC_PER, 4, true>(xh, [&](int j) { return (unsigned)xm[j]; }, want2, red, c_key);
+#pragma unroll
+        for (int j = 0; j < RESC_PER; ++j) {
+            if (xm[j] != 0 && xm[j] >= kx) {
+                const int p = atomicAdd(&nsel, 1);
+                if (p < 64) lists[p] = xm[j];
+            }
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        const int n64 = nsel < 64 ? nsel : 64;
+        best = sort64_desc(lane < n64 ? lists[lane] : 0, lane);
+    }
+    if (lane < K) {
+        float sc = -INFINITY;
+        int idx = -1;
+        if (best != 0) {
+            sc = unorderable((unsigned)(best >> 32));
+            idx = (int)((long)(0xFFFFFFFFu - (unsigned)best) + idx_offset);
+        }
+        out_scores[(long)b * K + lane] = sc;
+        out_idx[(long)b * K + lane] = idx;
+    }
+}
+
 // ---- exact pass ---------------------------------------------------------------------------------------------------------------
 // Runs (gated on flags[0]) for the queries the select kernel sent here.  One launch of `groups` workgroups; workgroup g, wave w
 // owns the 32-row gallery tiles (4g + w) + j * 4 * groups.  The flagged queries are compacted (in query order) and taken 32 AT A
@@ -466,7 +686,6 @@ __global__ __launch_bounds__(256) void topk_candidates_kernel(TopkFilter f, int 
 // merged into partial[b][g], and the last workgroup to finish a query (a ticket in done[b]) merges the partial lists and writes the
 // ranking.  Nothing here has a capacity: whatever the gallery looks like, the result is the exact top-K.
 typedef float f32x16e __attribute__((ext_vector_type(16)));
-typedef float f32x4e __attribute__((ext_vector_type(4)));
 typedef short bf16x8e __attribute__((ext_vector_type(8)));
 constexpr int EXACT_QB = 32;                    // flagged queries per gallery pass (the A rows of one MFMA tile)
 template <bool BF16>
@@ -603,11 +822,13 @@ __global__ __launch_bounds__(256) void rank_exact_kernel(const float* q, const v
 }
 
 hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S, int R, int K, const int* exclude, long exclude_off,
-                                    u64* thr_key, int* count, int* flags, int* state, hipStream_t s) {
+                                    u64* thr_key, int* count, int* flags, int* state, hipStream_t s, const float* q, int D, const float* meta,
+                                    float* margin_out) {
     if (B <= 0) return hipSuccess;
-    if (K < 1 || K > 64 || S < 0 || R < 1) return hipErrorInvalidValue;
+    if (K < 1 || K > 64 || S < 0 || R < 1 || (q && (!meta || !margin_out || D <= 0))) return hipErrorInvalidValue;
+    const BoundMargin mg{q, D, meta, margin_out};
     // keys per thread of the bisection (registers): the plan caps S at 32768 (api.hip: rank_plan)
-    auto go = [&](auto kern, int nt) { hipLaunchKernelGGL(kern, dim3(B), dim3(nt), 0, s, scores, ld, S, R, K, exclude, exclude_off, thr_key, count, flags, state); };
+    auto go = [&](auto kern, int nt) { hipLaunchKernelGGL(kern, dim3(B), dim3(nt), 0, s, scores, ld, S, R, K, exclude, exclude_off, thr_key, count, flags, state, mg); };
     if (S <= 1024) go(topk_sample_bound_kernel<4, 256>, 256);
     else if (S <= 4096) go(topk_sample_bound_kernel<16, 256>, 256);
     else if (S <= 16 * 1024) go(topk_sample_bound_kernel<16, 1024>, 1024);
@@ -621,6 +842,14 @@ hipError_t launch_topk_candidates(const TopkFilter& f, int B, int K, long idx_of
     if (B <= 0) return hipSuccess;
     if (K < 1 || K > 64 || f.cap < 1 || f.cap > 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(topk_candidates_kernel, dim3(B), dim3(256), 0, s, f, K, idx_offset, out_scores, out_idx, flags, state);
+    return hipGetLastError();
+}
+
+hipError_t launch_topk_rescore(const TopkFilter& f, const float* q, const float* gallery, int D, const float* margin, int B, int K, long idx_offset,
+                               float* out_scores, int* out_idx, int* flags, int* state, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (K < 1 || K > 64 || f.cap < 1 || f.cap > 64 || D < 32 || D % 32 || D > 1024 || !margin) return hipErrorInvalidValue;
+    FERN_LAUNCH(topk_rescore_kernel, dim3(B), dim3(256), 0, s, f, q, gallery, D, margin, K, idx_offset, out_scores, out_idx, flags, state);
     return hipGetLastError();
 }
 

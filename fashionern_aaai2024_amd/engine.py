@@ -34,6 +34,30 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class PreparedGallery:
+    """An fp32 gallery [N, D] together with its certified bf16 pre-filter copy (include/fern.h: fern_gallery_prepare): what
+    `FernEngine.sim_topk` takes to run the ranking stage as one HBM-bound pass over the bf16 rows + exact fp32 rescoring of the few
+    rows that can still be in the top-K.  Results are those of the fp32 gallery, bit for bit.  Build it once per gallery
+    (`FernEngine.prepare_gallery`), like the reference builds its index once per evaluation (run/test/test_fiq.py:45-46); rebuild
+    it when the gallery's contents change."""
+
+    __slots__ = ("f32", "bf16", "meta")
+
+    def __init__(self, f32: torch.Tensor, bf16: torch.Tensor, meta: torch.Tensor):
+        self.f32, self.bf16, self.meta = f32, bf16, meta
+
+    @property
+    def shape(self):
+        return self.f32.shape
+
+    @property
+    def dtype(self):
+        return self.f32.dtype
+
+    def float(self):
+        return self.f32
+
+
 class FernEngine:
     """One native context on one GPU.  Not thread-safe (one per device per process)."""
 
@@ -248,7 +272,25 @@ class FernEngine:
         return out
 
     # ---- rank ---------------------------------------------------------------------------------
+    def prepare_gallery(self, gallery, out: Optional[PreparedGallery] = None) -> PreparedGallery:
+        """fp32 [N,D] -> PreparedGallery (the gallery itself, its bf16 copy, the three norms that certify the copy as a pre-filter).
+        `out`: a PreparedGallery of the same shape to refill in place (a serving process's store)."""
+        g = self._f32(gallery)
+        if g.dim() != 2 or g.shape[1] % 4:
+            raise ValueError(f"gallery must be [N,D] with D % 4 == 0, got {tuple(g.shape)}")
+        if out is not None and tuple(out.bf16.shape) == tuple(g.shape):
+            b16, meta = out.bf16, out.meta
+        else:
+            b16 = torch.empty(g.shape, dtype=torch.bfloat16, device=self.device)
+            meta = torch.zeros(4, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.fern_gallery_prepare(self._h, _ptr(g), g.shape[0], g.shape[1], _ptr(b16), _ptr(meta), _stream()), "fern_gallery_prepare")
+        return PreparedGallery(g, b16, meta)
+
     def sim_topk(self, q, gallery, k: int, idx_offset: int = 0, exclude_idx=None):
+        """Exact cosine top-K of q [B,D] against an fp32 gallery [N,D] (run/test/test_fiq.py:49-50).  `gallery` is a tensor -- the
+        fp32-MFMA sweep -- or a `PreparedGallery` -- bf16 pre-filter + exact rescoring, same scores and ordering bit for bit."""
+        if isinstance(gallery, PreparedGallery):
+            return self._sim_topk_prefiltered(q, gallery, k, idx_offset, exclude_idx)
         q, g = self._f32(q), self._f32(gallery)
         if q.dim() != 2 or g.dim() != 2 or q.shape[1] != g.shape[1]:
             raise ValueError(f"q [B,D] and gallery [N,D] must share D, got {tuple(q.shape)} and {tuple(g.shape)}")
@@ -262,6 +304,22 @@ class FernEngine:
                 raise ValueError("exclude_idx must be [B]")
         _lib.check(self.lib.fern_sim_topk(self._h, _ptr(q), _ptr(g), b, g.shape[0], q.shape[1], int(k), _ptr(scores), _ptr(idx),
                                           int(idx_offset), _ptr(ex), _stream()), "fern_sim_topk")
+        return scores, idx
+
+    def _sim_topk_prefiltered(self, q, pg: PreparedGallery, k: int, idx_offset: int = 0, exclude_idx=None):
+        q, g = self._f32(q), pg.f32
+        if q.dim() != 2 or q.shape[1] != g.shape[1]:
+            raise ValueError(f"q [B,D] and gallery [N,D] must share D, got {tuple(q.shape)} and {tuple(g.shape)}")
+        b = q.shape[0]
+        scores = self._empty(b, k)
+        idx = self._empty(b, k, dtype=torch.int32)
+        ex = None
+        if exclude_idx is not None:
+            ex = torch.as_tensor(exclude_idx).to(device=self.device, dtype=torch.int32).contiguous()
+            if tuple(ex.shape) != (b,):
+                raise ValueError("exclude_idx must be [B]")
+        _lib.check(self.lib.fern_sim_topk_prefiltered(self._h, _ptr(q), _ptr(g), _ptr(pg.bf16), _ptr(pg.meta), b, g.shape[0], q.shape[1], int(k),
+                                                      _ptr(scores), _ptr(idx), int(idx_offset), _ptr(ex), _stream()), "fern_sim_topk_prefiltered")
         return scores, idx
 
     def gallery_to_bf16(self, gallery) -> torch.Tensor:
@@ -287,7 +345,7 @@ class FernEngine:
         return scores, idx
 
     def gather_scores(self, q, gallery, idx):
-        q, g = self._f32(q), self._f32(gallery)
+        q, g = self._f32(q), self._f32(gallery.f32 if isinstance(gallery, PreparedGallery) else gallery)
         ix = torch.as_tensor(idx).to(device=self.device, dtype=torch.int32).contiguous()
         out = self._empty(*ix.shape)
         _lib.check(self.lib.fern_gather_scores(self._h, _ptr(q), _ptr(g), _ptr(ix), _ptr(out), ix.shape[0], ix.shape[1],

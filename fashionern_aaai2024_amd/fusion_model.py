@@ -29,11 +29,35 @@ class _FernModule:
         self.device = self.engine.device
         self._state = {}
 
+    # keys real checkpoints may or may not carry (model.py: ERN.load_state_dict documents both)
+    _optional = ("transformer_layer.cls_token", "transformer_layer.bert_encoder.bert_model.embeddings.position_ids")
+
     def load_state_dict(self, state_dict, strict=True):
+        """``strict`` follows ``nn.Module.load_state_dict`` (the reference loads with the default, run/test/test_fiq.py:149), the
+        same way ``ERN.load_state_dict`` does: strict -> a missing or unexpected key raises ``RuntimeError`` naming the keys before
+        anything reaches the native side; ``strict=False`` drops unexpected keys and keeps the previous load's value of a missing
+        one (an error if there was none).  Keys are the module's own, un-prefixed ones.  The two key lists of the last load stay in
+        ``self.missing_keys`` / ``self.unexpected_keys``."""
         sd = _np_state(state_dict)
-        self.engine.load_tensors(sd, prefix=self._prefix)
+        pre = self._prefix
+        expected = {k[len(pre):] for k in synth.fusion_state_shapes(self.feature_dim) if k.startswith(pre)}
+        optional = set(self._optional) | {k for k in sd if k.endswith("num_batches_tracked")}
+        missing = sorted(k for k in expected - optional if k not in sd)
+        unexpected = sorted(k for k in sd if k not in expected and k not in optional)
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: missing key(s): " + ", ".join(missing or ["-"]) +
+                               "; unexpected key(s): " + ", ".join(unexpected or ["-"]))
+        for k in unexpected:
+            del sd[k]
+        still = [k for k in missing if k not in self._state]
+        if still:
+            raise RuntimeError("load_state_dict(strict=False): no earlier value to keep for missing key(s): " + ", ".join(still))
+        merged = dict(self._state) if missing else {}
+        merged.update(sd)
+        self.engine.load_tensors(merged, prefix=pre)
         self.engine.finalize_fusion(self.feature_dim, self._part)
-        self._state = sd
+        self._state = merged
+        self.missing_keys, self.unexpected_keys = missing, unexpected
         return self
 
     def state_dict(self):

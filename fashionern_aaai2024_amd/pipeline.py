@@ -63,6 +63,8 @@ class ComposedQueryPipeline:
     call with a bigger batch / gallery / K, another precision, a direct call on ``engines[0]``) its `ws_generation` moves and
     every graph of the lane is dropped and re-captured on its next use instead of being replayed against freed memory."""
 
+    _live: dict = {}      # id(pipeline) -> lanes of every pipeline that has not been closed (the tuner's concurrency is process-wide)
+
     def __init__(self, engine: FernEngine, lanes: int = 3, timing: bool = False, graphs: bool = False):
         self.timing = bool(timing)
         self.graphs = bool(graphs)
@@ -71,7 +73,9 @@ class ComposedQueryPipeline:
             raise ValueError("lanes must be >= 1")
         if engine.clip_cfg is None or engine.feature_dim is None:
             raise RuntimeError("the engine needs finalised CLIP and fusion weights")
-        engine.tuner_set_concurrency(lanes)      # shapes tuned from here on are scored for `lanes` batches in flight
+        # process-wide tuner setting: shapes tuned from here on are scored for the most batches any LIVE pipeline keeps in flight
+        ComposedQueryPipeline._live[id(self)] = lanes
+        engine.tuner_set_concurrency(max(ComposedQueryPipeline._live.values()))
         self.engines: List[FernEngine] = [engine] + [engine.fork() for _ in range(lanes - 1)]
         self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(lanes)]
         self._next = 0
@@ -160,4 +164,7 @@ class ComposedQueryPipeline:
         for e in self.engines[1:]:
             e.close()
         self.engines = self.engines[:1]
-        self.engines[0].tuner_set_concurrency(1)      # process-wide setting: shapes tuned after this pipeline are scored stand-alone again
+        # process-wide setting: the survivors' maximum (a c2 and a c5 pipeline in one serving process: closing one must not make the
+        # other's later shapes be scored for stand-alone latency -- ADVICE r4); stand-alone again only when the last one closes
+        ComposedQueryPipeline._live.pop(id(self), None)
+        self.engines[0].tuner_set_concurrency(max(ComposedQueryPipeline._live.values(), default=1))

@@ -129,10 +129,11 @@ typedef enum {
 
 /* kernel-time accounting for bench.py's roofline block */
 typedef struct {
-    double gemm_ms;        /* sum of HIP-event durations of every fp32-MFMA GEMM launch */
+    double gemm_ms;        /* every fp32-MFMA GEMM launch: sum over its kernel dispatches of the dispatch's own begin -> end timestamps
+                              (hipExtLaunchKernelGGL event pairs = what rocprofv3 --kernel-trace reports per kernel), not stream-marker intervals */
     double gemm_flops;     /* sum of 2*M*N*K of those launches */
     int64_t gemm_launches;
-    double attn_ms;
+    double attn_ms;        /* attention launches, per-dispatch begin -> end timestamps like gemm_ms */
     double attn_flops;
     int64_t attn_launches;
     double topk_ms;        /* the rest of the ranking stage: sample pass, bound, candidate selection, gated exact pass and every launch
@@ -256,6 +257,25 @@ FERN_API int fern_sim_topk(fern_ctx* ctx, const float* q /*[B,D]*/, const float*
 FERN_API int fern_gallery_to_bf16(fern_ctx* ctx, const float* src, uint16_t* dst, int64_t n, int d, void* stream);
 FERN_API int fern_sim_topk_bf16(fern_ctx* ctx, const float* q /*[B,D] f32*/, const uint16_t* gallery /*[N,D] bf16*/, int B, int64_t N, int D,
                                 int K, float* out_scores, int32_t* out_idx, int64_t idx_offset, const int32_t* exclude_idx, void* stream);
+/* The fp32-gallery ranking stage made HBM-bound: a CERTIFIED bf16 pre-filter + exact fp32 rescoring.  Same contract as fern_sim_topk --
+ * `distances = 1 - q @ g.T; argsort` of run/test/test_fiq.py:49-50 on the fp32 gallery: the scores returned are the exact fp32 fma-chain
+ * scores fern_sim_topk returns, the ordering is bit-identical to it -- but the pass over the gallery reads a bf16 copy (half the bytes,
+ * bf16 MFMA rate), and only the few rows that can still be in the top-K are scored in fp32.
+ *   fern_gallery_prepare: once per gallery (the reference builds its index once per evaluation, run/test/test_fiq.py:45-46):
+ *       out_bf16 [N, D] = bf16(gallery) (round to nearest even = fern_gallery_to_bf16) and out_meta (DEVICE, 4 floats) =
+ *       {max_n ||g_n - bf16(g_n)||, max_n ||bf16(g_n)||, max_n ||g_n||, 0}.  D % 4 == 0.  Re-run after the gallery changes.
+ *   fern_sim_topk_prefiltered: per query b, |exact score - bf16 score| <= eps_b = ||q_b|| meta[0] + ||q_b - bf16(q_b)|| meta[1] + slack
+ *       for EVERY row (Cauchy-Schwarz; slack = fp32 accumulation of both dot products), so every row of the exact top-K has a bf16
+ *       score within 2 eps_b of the K-th best bf16 score: those rows -- K plus the few inside the margin -- are rescored with the exact
+ *       chain from `gallery` and ranked.  Nothing about the result depends on the bf16 scores.  Queries whose candidates do not fit
+ *       (galleries of near-ties) take fern_sim_topk's exact pass, as there.  D % 64 == 0 and D <= 768 use the pre-filter; other
+ *       shapes run fern_sim_topk itself.  `gallery_bf16` / `meta` must come from fern_gallery_prepare on the same `gallery`. */
+FERN_API int fern_gallery_prepare(fern_ctx* ctx, const float* gallery /*[N,D]*/, int64_t N, int D, uint16_t* out_bf16 /*[N,D]*/,
+                                  float* out_meta /*[4], device*/, void* stream);
+FERN_API int fern_sim_topk_prefiltered(fern_ctx* ctx, const float* q /*[B,D]*/, const float* gallery /*[N,D] f32*/,
+                                       const uint16_t* gallery_bf16 /*[N,D]*/, const float* meta /*[4]*/, int B, int64_t N, int D, int K,
+                                       float* out_scores /*[B,K]*/, int32_t* out_idx /*[B,K]*/, int64_t idx_offset,
+                                       const int32_t* exclude_idx, void* stream);
 /* scores of explicitly named gallery rows (CIRR subset ranking, run/test/test_cirr.py:64-66);
  * idx < 0 -> -inf */
 FERN_API int fern_gather_scores(fern_ctx* ctx, const float* q /*[B,D]*/, const float* gallery /*[N,D]*/,
@@ -344,7 +364,10 @@ FERN_API int fern_tuner_set_concurrency(int lanes);
 FERN_API uint64_t fern_ws_generation(const fern_ctx* ctx);
 
 /* profiling ----------------------------------------------------------------------------- */
-FERN_API int fern_prof_enable(fern_ctx* ctx, int on);    /* wrap GEMM/attention/top-K launches in HIP events */
+/* While on, GEMM / attention / sweep launches are dispatched with a (start, stop) event pair each and timed by the dispatch's own begin /
+ * end timestamps; the ranking STAGE (sample, bound, sweep, select, exact gate and the boundaries between them) is one stream-marker
+ * interval.  A launch that fails while instrumented leaves no record behind. */
+FERN_API int fern_prof_enable(fern_ctx* ctx, int on);
 FERN_API int fern_prof_collect(fern_ctx* ctx, fern_prof_stats* out);  /* synchronises, sums, resets */
 
 #ifdef __cplusplus

@@ -1,0 +1,152 @@
+"""The fp32-gallery ranking stage as a CERTIFIED bf16 pre-filter + exact fp32 rescoring (fern_gallery_prepare /
+fern_sim_topk_prefiltered; FernEngine.prepare_gallery + sim_topk), through the C ABI.
+
+Reference semantics are fern_sim_topk's: `distances = 1 - q @ g.T; argsort(distances)[:, :K]` on the fp32 gallery
+(run/test/test_fiq.py:49-50).  The contract of the pre-filter is that NOTHING about the result depends on the bf16 scores: the
+scores returned are the exact fp32 fma-chain scores (oracle/chain.c), the ordering is the chain's, bit for bit -- including on
+galleries built so that the bf16 ranking is wrong (rows inside the margin), on ties, with exclusions, and when the candidates do
+not fit and the exact pass takes over."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chain
+from oracle import rank as orank
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(n, d, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, d, generator=g) * scale
+
+
+def _int_unit(n, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(-1, 2, (n, d), generator=g).float() / 8.0
+
+
+def _same_bits(s, i, cs, ci):
+    return np.array_equal(i.cpu().numpy(), ci) and np.array_equal(s.cpu().numpy().view(np.uint32), cs.view(np.uint32))
+
+
+@pytest.mark.parametrize("B,N,D", [(3, 1000, 64), (64, 9001, 640), (130, 3000, 128), (1, 70_000, 512), (64, 46_000, 512), (5, 40, 64), (2, 7, 1024)])
+def test_prefiltered_ranking_is_bit_identical_to_the_fma_chain(engine, B, N, D):
+    """Random operands at the shapes of test_sim_topk_bit_identical_to_the_fma_chain plus BASELINE C2's (64 x 46 000 x 512) and
+    galleries smaller than K: same bits as the sequential fp32 fma chain, same ranking -- and the same as the plain fp32 stage."""
+    q, g = _rand(B, D, seed=B + N), _rand(N, D, seed=N + D, scale=D ** -0.5)
+    pg = engine.prepare_gallery(g)
+    s, i = engine.sim_topk(q, pg, 50)
+    cs, ci = chain.chain_topk(q.numpy(), g.numpy(), 50)
+    assert _same_bits(s, i, cs, ci)
+    s0, i0 = engine.sim_topk(q, g, 50)
+    assert torch.equal(s, s0) and torch.equal(i, i0)
+
+
+def test_prepare_reports_the_norms_that_certify_the_margin(engine):
+    """meta = {max ||g - bf16(g)||, max ||bf16(g)||, max ||g||}; with them |exact - bf16 score| <= eps_b of include/fern.h for every
+    (query, row) -- checked against the actual errors of the bf16 operands in float64."""
+    d = 512
+    q, g = _rand(32, d, 5, 0.7), _rand(20_000, d, 6, d ** -0.5)
+    g[17] *= 9.0                                           # one long row sets the maxima
+    pg = engine.prepare_gallery(g)
+    gb = g.bfloat16().float()
+    assert torch.equal(pg.bf16.cpu().view(torch.int16), g.bfloat16().view(torch.int16))
+    want = torch.stack([(g - gb).norm(dim=1).max(), gb.norm(dim=1).max(), g.norm(dim=1).max()])
+    meta = pg.meta.cpu()
+    assert torch.allclose(meta[:3], want, rtol=1e-5) and meta[3] == 0
+    qb = q.bfloat16().float()
+    err = (q.double() @ g.double().T - qb.double() @ gb.double().T).abs()                    # [32, 20000]
+    eps = q.double().norm(dim=1) * meta[0].double() + (q - qb).double().norm(dim=1) * meta[1].double()
+    assert (err.max(dim=1).values <= eps).all()
+    assert err.max() > 1e-3 * eps.max()                   # ... and the bound is a bound on something (Cauchy-Schwarz is ~sqrt(D) loose on random rows)
+
+
+@pytest.mark.parametrize("near", [400, 3000])
+def test_rows_inside_the_margin_are_rescored_not_trusted(engine, near):
+    """`near` gallery rows score within ~1e-4 of each other for every query (they are the query direction plus a little noise),
+    far inside the bf16 error (~1e-3): the bf16 ranking of them is scrambled -- asserted -- and only the exact rescoring can order
+    them.  400 rows fit the rescoring kernel; 3000 exceed its 1024 survivors and take the exact pass.  Result = the chain's, bit for bit."""
+    d, n, k = 512, 30_000, 50
+    base = torch.nn.functional.normalize(_rand(1, d, 77), dim=-1)
+    q = torch.nn.functional.normalize(base + 0.02 * _rand(8, d, 78) * d ** -0.5, dim=-1)
+    g = torch.nn.functional.normalize(_rand(n, d, 79), dim=-1)
+    rows = torch.randperm(n, generator=torch.Generator().manual_seed(80))[:near]
+    g[rows] = torch.nn.functional.normalize(base + 0.03 * _rand(near, d, 81) * d ** -0.5, dim=-1)
+    cs, ci = chain.chain_topk(q.numpy(), g.numpy(), k)
+    approx = (q.bfloat16().float() @ g.bfloat16().float().T).topk(k, dim=1).indices
+    scrambled = sum(set(a.tolist()) != set(b.tolist()) for a, b in zip(approx, torch.from_numpy(ci.astype(np.int64))))
+    assert scrambled >= 6, "the case must be one where the bf16 scores pick the wrong rows"
+    s, i = engine.sim_topk(q, engine.prepare_gallery(g), k)
+    assert _same_bits(s, i, cs, ci)
+
+
+@pytest.mark.parametrize("n", [1, 63, 1025, 65_537])
+def test_all_scores_equal_only_the_index_breaks_ties(engine, n):
+    d, k = 64, 50
+    q = _int_unit(3, d, 5)
+    g = _int_unit(1, d, 6).repeat(n, 1)
+    rs, ri = orank.cosine_topk(q, g, k)
+    s, i = engine.sim_topk(q, engine.prepare_gallery(g), k)
+    engine.sync()
+    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
+
+
+def test_exclusion_offsets_and_large_batches(engine):
+    """CIRR's shape (BASELINE C4): B crosses the 1024-query plan chunk and the 128-query sweep blocks, K = 51, one excluded
+    gallery index per query, idx_offset of a gallery shard."""
+    n, d = 21_552, 64
+    q, g = _rand(1300, d, 51), _rand(n, d, 52, d ** -0.5)
+    ex = torch.randint(0, n, (1300,), generator=torch.Generator().manual_seed(3), dtype=torch.int32) + 7000
+    pg = engine.prepare_gallery(g)
+    s, i = engine.sim_topk(q, pg, 51, idx_offset=7000, exclude_idx=ex)
+    s0, i0 = engine.sim_topk(q, g, 51, idx_offset=7000, exclude_idx=ex)
+    engine.sync()
+    assert torch.equal(s, s0) and torch.equal(i, i0)
+    assert not (i.cpu() == ex[:, None]).any()
+    cs, ci = chain.chain_topk(q[:40].numpy(), g.numpy(), 52)            # the chain's top-52 minus the excluded row = the top-51
+    for b in range(40):
+        keep = [(sc, ix + 7000) for sc, ix in zip(cs[b], ci[b]) if ix + 7000 != int(ex[b])][:51]
+        assert [x for _, x in keep] == i[b].cpu().tolist()
+        assert np.array_equal(np.array([x for x, _ in keep], np.float32).view(np.uint32), s[b].cpu().numpy().view(np.uint32))
+
+
+def test_excluded_row_is_the_best_row_and_a_sampled_row(engine):
+    from test_gpu_rank_fused import plan, sample_row                     # the plain plan's sample; the pre-filter's is denser at this N
+    n, d, k = 70_000, 64, 5
+    q, g = _int_unit(6, d, 31), _int_unit(n, d, 32)
+    s_rows = max(n // 32, min(n, 4096))
+    r = n // s_rows
+    ex_rows = [sample_row(c, r) for c in (0, 17, 500, s_rows - 1, 3, 9)]
+    for b, row in enumerate(ex_rows):
+        g[row] = torch.sign(q[b]) / 8.0 + (q[b] == 0) * 0.125
+    ex = torch.tensor(ex_rows, dtype=torch.int32)
+    rs, ri = orank.cosine_topk(q, g, k, exclude_idx=ex)
+    s, i = engine.sim_topk(q, engine.prepare_gallery(g), k, exclude_idx=ex)
+    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
+    assert plan(n)[0] <= s_rows
+
+
+def test_rows_of_very_different_lengths(engine):
+    """Un-normalised operands: the margin scales with the longest gallery row, so short rows' scores sit deep inside it."""
+    n, d, k = 20_000, 128, 50
+    q = _rand(9, d, 91) * 3.7
+    g = _rand(n, d, 92) * torch.logspace(-1, 1.3, n)[torch.randperm(n, generator=torch.Generator().manual_seed(93))][:, None]
+    cs, ci = chain.chain_topk(q.numpy(), g.numpy(), k)
+    s, i = engine.sim_topk(q, engine.prepare_gallery(g), k)
+    assert _same_bits(s, i, cs, ci)
+
+
+def test_prepared_gallery_is_refilled_in_place_and_feeds_the_pipeline_entry_points(engine):
+    d = 64
+    g1, g2, q = _rand(5000, d, 1, 0.1), _rand(5000, d, 2, 0.1), _rand(4, d, 3)
+    pg = engine.prepare_gallery(g1)
+    pg2 = engine.prepare_gallery(g2, out=pg)
+    assert pg2.bf16.data_ptr() == pg.bf16.data_ptr() and pg2.meta.data_ptr() == pg.meta.data_ptr()
+    s, i = engine.sim_topk(q, pg2, 10)
+    s0, i0 = engine.sim_topk(q, g2, 10)
+    assert torch.equal(s, s0) and torch.equal(i, i0)
+    idx = torch.tensor([[0, 5, 4999, -1]] * 4, dtype=torch.int32)
+    assert torch.equal(engine.gather_scores(q, pg2, idx), engine.gather_scores(q, g2, idx))
+    s, i = engine.sim_topk(q, engine.prepare_gallery(g2[:0]), 10)        # an empty shard
+    assert (i.cpu() == -1).all()

@@ -148,6 +148,22 @@ def test_standalone_modules_take_unprefixed_reference_keys():
     assert np.abs(dvr(rl, ts, rg, tg).numpy() - gold["d128_dvr_module"]).max() < 1e-6
     with pytest.raises(ValueError):
         VisualSR(d, num_region=9, engine=OracleEngine())
+    # strict follows nn.Module.load_state_dict, as ERN's does (run/test/test_fiq.py:149 loads with the default, strict=True):
+    # a stand-alone module names the offending key instead of failing later inside fern_finalize_fusion
+    csd = sub("Combiner_module.")
+    short = {k: v for k, v in csd.items() if k != "dynamic_scalar.3.bias"}
+    with pytest.raises(RuntimeError, match=r"CombinerSimple: missing key\(s\): dynamic_scalar.3.bias"):
+        CombinerSimple(d, 4 * d, 8 * d, engine=OracleEngine()).load_state_dict(short)
+    with pytest.raises(RuntimeError, match=r"unexpected key\(s\): not_a_weight"):
+        comb.load_state_dict(dict(csd, not_a_weight=np.zeros(2, np.float32)))
+    with pytest.raises(RuntimeError, match="no earlier value"):
+        CombinerSimple(d, 4 * d, 8 * d, engine=OracleEngine()).load_state_dict(short, strict=False)
+    assert comb.load_state_dict(dict(short, not_a_weight=np.zeros(2, np.float32)), strict=False) is comb      # earlier bias kept
+    assert comb.missing_keys == ["dynamic_scalar.3.bias"] and comb.unexpected_keys == ["not_a_weight"]
+    assert np.abs(comb(raw, txt).numpy() - gold["d128_combiner_target"]).max() < 1e-6
+    dsd = sub("DVR.")
+    no_cls = {k: v for k, v in dsd.items() if not k.endswith("cls_token")}      # GPU-trained checkpoints lack it: optional
+    assert DVR_module(d, engine=OracleEngine()).load_state_dict(no_cls).missing_keys == []
 
 
 def test_collate_fn_drops_none_and_tokenizer_registry():
@@ -223,6 +239,16 @@ def test_encode_text_cache_hits_only_on_identity_or_equal_host_tokens():
     assert len(calls) == 3                                           # another visual_emb object: re-encoded
     clip.encode_text(b, mode="seq", visual_emb=ve)
     assert len(calls) == 3
+    # a preallocated visual_emb buffer refilled IN PLACE is a different argument (identity alone would hit)
+    clip.encode_text(b, visual_emb=ve)
+    assert len(calls) == 4
+    ve.copy_(torch.ones_like(ve))
+    clip.encode_text(b, mode="seq", visual_emb=ve)
+    assert len(calls) == 5
+    # ... and the entry is dropped once the seq call of a pair was served: no caller tensors are kept alive past it
+    clip.encode_text(b)
+    clip.encode_text(b, mode="seq")
+    assert len(calls) == 6 and clip._text_cache is None
 
     class DeviceTokens:                                              # a duck-typed "cuda" tensor: same address / shape / version every time
         is_cuda, dtype, _version = True, torch.int64, 0
