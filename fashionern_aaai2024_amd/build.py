@@ -106,7 +106,9 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
                 f.write(f"{src} {name} vgpr={u.get('VGPRs', '?')} sgpr={u.get('TotalSGPRs', '?')} scratch={u.get('ScratchSize [bytes/lane]', '?')} "
                         f"vgpr_spill={u.get('VGPRs Spill', '?')} sgpr_spill={u.get('SGPRs Spill', '?')} lds={u.get('LDS Size [bytes/block]', '?')} "
                         f"occupancy={u.get('Occupancy [waves/SIMD]', '?')}\n")
-    spilled = [(src, n, u) for src in SOURCES for n, u in usage.get(src, {}).items() if int(u.get("VGPRs Spill", 0)) or int(u.get("ScratchSize [bytes/lane]", 0))]
+    # (a "VGPRs Spill" count with ScratchSize 0 is a spill into the wave's AGPR half of the register file -- v_accvgpr moves, no memory
+    # traffic: a 256-thread kernel that keeps 192 row values in registers uses it on purpose; what is an error is SCRATCH memory)
+    spilled = [(src, n, u) for src in SOURCES for n, u in usage.get(src, {}).items() if int(u.get("ScratchSize [bytes/lane]", 0))]
     if spilled and not os.environ.get("FERN_ALLOW_SPILLS"):
         lines = "\n".join(f"  {src}: {n}: {u.get('VGPRs Spill')} VGPRs spilled, {u.get('ScratchSize [bytes/lane]')} B/lane scratch" for src, n, u in spilled)
         raise RuntimeError("kernels spill registers (restructure them, or set FERN_ALLOW_SPILLS=1 to build anyway):\n" + lines)

@@ -133,6 +133,7 @@ struct fern_ctx {
     ClipW clip;
     Clip4CirW c4c;
     int precision = FERN_PREC_FP32;  // operand precision of the CLIP towers' token-level GEMMs (fern_set_precision)
+    int rank_strategy = 0;           // fern_rank_set_strategy (FERN_RANK_AUTO)
     bool f32x3 = false;              // FERN_PREC_F32X3: `precision` stays FP32 (same buffers, same code paths), GEMMs run split (run_gemm)
     // workspace arena (bump allocator; blocks are consolidated at the start of the next op)
     struct Block { char* p; size_t cap; };
@@ -466,6 +467,7 @@ extern "C" int fern_ctx_fork(fern_ctx* parent, fern_ctx** out) {
     c->clip = parent->clip;
     c->c4c = parent->c4c;
     c->precision = parent->precision;
+    c->rank_strategy = parent->rank_strategy;
     c->f32x3 = parent->f32x3;
     *out = c;
     return FERN_OK;
@@ -1682,6 +1684,31 @@ static long prefilter_sample_rows(int64_t N) {
     return std::min<long>(std::max<long>(N / 32, std::min<long>(N, 4096)), 32768);
 }
 
+// Which form of the stage runs (results are identical, bit for bit): FERN_RANK_PLAIN = fern_sim_topk's fp32-MFMA sweep;
+// FERN_RANK_LISTS = bf16 sample pass + bound - margin + filtered bf16 sweep into candidate lists + rescoring (five launches; for
+// galleries whose [B, N] score matrix would be real traffic); FERN_RANK_DENSE = bf16 sweep that stores its scores + one
+// select-and-rescore kernel (three launches; small galleries, where the stage is launch boundaries, not bytes).
+static int rank_strategy_for(const fern_ctx* c, int B, int64_t N, int D) {
+    const bool dense_ok = N <= 262144 && (double)B * N * 4 <= 256e6;      // the [B, N] fp32 score matrix stays small next to the gallery
+    if (c->rank_strategy != FERN_RANK_AUTO) return (c->rank_strategy == FERN_RANK_DENSE && !dense_ok) ? (int)FERN_RANK_LISTS : c->rank_strategy;
+    const long QBLK = (D == 64 || D == 128 || D == 256 || D == 512) ? 128 : 64;
+    const double nblk = (double)((B + QBLK - 1) / QBLK), stream_us = (double)N * D * 2 / 4.5e6;      // one bf16 pass at ~4.5 TB/s
+    const double plain = 38.0 + 2.0 * B * (double)N * D / 95e6;                                        // launches + fp32 MFMA at ~95 TFLOP/s (skinny M)
+    const double dense = nblk * (std::max(17.0, stream_us + 8.0) + (double)std::min<long>(B, QBLK) * N * 4 / 3e6) + 18.0 * ((B + 255) / 256) + 5.0;
+    const double lists = nblk * (14.0 + std::max(17.0, stream_us + 8.0)) + 8.0 + 16.0 * ((B + 255) / 256) + 5.0;
+    int best = FERN_RANK_PLAIN;
+    double t = plain;
+    if (lists < t) { best = FERN_RANK_LISTS; t = lists; }
+    if (dense_ok && dense < t) best = FERN_RANK_DENSE;
+    return best;
+}
+
+extern "C" int fern_rank_set_strategy(fern_ctx* c, int strategy) {
+    if (!c || strategy < FERN_RANK_AUTO || strategy > FERN_RANK_DENSE) return fail(FERN_ERR_ARG, "fern_rank_set_strategy: unknown strategy");
+    c->rank_strategy = strategy;
+    return FERN_OK;
+}
+
 extern "C" int fern_sim_topk_prefiltered(fern_ctx* c, const float* q, const float* gallery, const uint16_t* gallery_bf16, const float* meta, int B,
                                          int64_t N, int D, int K, float* out_scores, int32_t* out_idx, int64_t idx_offset,
                                          const int32_t* exclude_idx, void* stream) {
@@ -1689,28 +1716,54 @@ extern "C" int fern_sim_topk_prefiltered(fern_ctx* c, const float* q, const floa
     if (B < 0 || N < 0 || K < 1 || K > 64 || D <= 0 || D % 32) return fail(FERN_ERR_ARG, "fern_sim_topk_prefiltered: need 1<=K<=64, D % 32 == 0");
     if (B && (!q || !out_scores || !out_idx || (N && (!gallery || !gallery_bf16 || !meta)))) return fail(FERN_ERR_ARG, "fern_sim_topk_prefiltered: NULL argument");
     if (N > 0x7FFFFFF0LL) return fail(FERN_ERR_ARG, "fern_sim_topk_prefiltered: N too large for int32 indices");
-    static const bool off = [] { const char* e = std::getenv("FERN_RANK_PREFILTER"); return e && e[0] == '0'; }();      // A/B switch
-    if (off || D % 64 || D > 768 || N == 0)       // outside the bf16 sweep's shapes (its LDS ring needs >= 3 stages): the plain fp32 stage (identical results)
+    const int strategy = (D % 64 || D > 768 || N == 0 || B == 0) ? (int)FERN_RANK_PLAIN : rank_strategy_for(c, B, N, D);
+    if (strategy == FERN_RANK_PLAIN)      // (also: outside the bf16 sweep's shapes -- its LDS ring needs >= 3 stages)
         return fern_sim_topk(c, q, gallery, B, N, D, K, out_scores, out_idx, idx_offset, exclude_idx, stream);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    if (B == 0) return FERN_OK;
+    const long QBLK = (D == 64 || D == 128 || D == 256 || D == 512) ? 128 : 64;
+    const double alg_bytes_per_q = (double)D * 4 + (double)K * 8;
     for (long o = 0; o < B; o += (long)kRankQueryChunk) {
         const int m = (int)std::min<long>((long)kRankQueryChunk, B - o);
         const int32_t* ex = exclude_idx ? exclude_idx + o : nullptr;
         FERN_TRY(ws_begin(c, s));
+        int slot, stage;
+        if (strategy == FERN_RANK_DENSE) {
+            const long ld = (N + 3) & ~3L;
+            const int groups = (int)std::min<long>(256, std::max<long>(1, (N + 4095) / 4096));
+            float* approx; unsigned long long *thr, *partial; int *flags, *state;
+            FERN_TRY(ws_get(c, (size_t)m * ld, &approx));
+            FERN_TRY(ws_get(c, (size_t)m, &thr));
+            FERN_TRY(ws_get(c, (size_t)4, &flags));
+            FERN_TRY(ws_get(c, (size_t)2 * m, &state));
+            FERN_TRY(ws_get(c, (size_t)m * groups * 64, &partial));
+            FERN_TRY(prof_open(c, PROF_STAGE, 0, s, &stage));
+            for (long b0 = 0; b0 < m; b0 += QBLK) {
+                const int mb = (int)std::min<long>(QBLK, m - b0);
+                // bytes this kernel moves: the bf16 copy once, the queries, its [mb, N] fp32 scores out
+                FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + (double)mb * D * 4 + (double)mb * N * 4, s, &slot, mb, (int)N, D, 17));
+                const hipError_t le = launch_sweep_bf16(q + (o + b0) * D, gallery_bf16, approx + b0 * ld, ld, mb, N, D, N, 1, nullptr, nullptr, s,
+                                                        b0 == 0 ? flags : nullptr);
+                HIP_TRY_PROF(le, c, slot);
+                FERN_TRY(prof_close(c, slot, s));
+            }
+            HIP_TRY(launch_topk_dense_rescore(approx, ld, N, q + o * D, gallery, D, meta, m, K, ex, idx_offset, idx_offset, out_scores + o * K,
+                                              out_idx + o * K, thr, flags, state, state + m, s));
+            HIP_TRY(launch_rank_exact(q + o * D, gallery, 0, m, N, D, K, state, thr, ex, idx_offset, idx_offset, partial, groups, state + m,
+                                      out_scores + o * K, out_idx + o * K, flags, s));
+            FERN_TRY(prof_close(c, stage, s));
+            continue;
+        }
         RankPlan P;
         FERN_TRY(rank_plan(c, m, N, K, ex, idx_offset, &P, prefilter_sample_rows(N)));
         float* margin;
         FERN_TRY(ws_get(c, (size_t)m, &margin));
-        const long QBLK = (D == 64 || D == 128 || D == 256 || D == 512) ? 128 : 64;
         auto block_filter = [&](long b0) {
             TopkFilter f = P.filt;
             f.cand += b0 * RANK_SLOTS * P.cap; f.thr_key += b0; f.count += b0 * RANK_SLOTS;
             if (f.exclude) f.exclude += b0;
             return f;
         };
-        int slot, stage;
         FERN_TRY(prof_open(c, PROF_STAGE, 0, s, &stage));
         for (long b0 = 0; b0 < m; b0 += QBLK)
             HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery_bf16, P.sample + b0 * P.ld, P.ld, (int)std::min<long>(QBLK, m - b0), N, D, P.S, P.R,
@@ -1721,7 +1774,7 @@ extern "C" int fern_sim_topk_prefiltered(fern_ctx* c, const float* q, const floa
             const TopkFilter f = block_filter(b0);
             // bytes this kernel streams: the bf16 copy once, the queries, nothing stored (the STAGE's algorithmic bytes -- SURVEY 8d, an fp32
             // gallery: N D 4 -- are the caller's to quote against the stage time)
-            FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + (double)mb * D * 4 + (double)mb * K * 8, s, &slot, mb, (int)N, D, 16));
+            FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + mb * alg_bytes_per_q, s, &slot, mb, (int)N, D, 16));
             const hipError_t le = launch_sweep_bf16(q + (o + b0) * D, gallery_bf16, nullptr, 0, mb, N, D, 0, 1, &f, nullptr, s);
             HIP_TRY_PROF(le, c, slot);
             FERN_TRY(prof_close(c, slot, s));

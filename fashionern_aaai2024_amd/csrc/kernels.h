@@ -371,8 +371,10 @@ hipError_t launch_gallery_prepare(const float* x, unsigned short* y, long n, int
 // q < B <= 64 queries against a bf16 gallery [N, D] (D % 64 == 0), fp32 accumulation.
 // Sample form (filt == null): scores[q, c] = Q[q] . G[sample_row(c, R)] for c < S, row stride ld.
 // Filter form (filt != null): nothing is stored, survivors go to filt (gate as GemmParams.gate).
+// zero_flags (sample form only, may be null): two ints the first workgroup zeroes (the ranking stage's overflow flags, when no bound
+// kernel runs before the selection).
 hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
-                             const TopkFilter* filt, const int* gate, hipStream_t s);
+                             const TopkFilter* filt, const int* gate, hipStream_t s, int* zero_flags = nullptr);
 
 // ---- top-K (topk.hip) ------------------------------------------------------------------------
 // Fused sweep, step 2: per query the K-th best key of the sample scores [B, ld] (S valid columns; column c is gallery row
@@ -387,6 +389,13 @@ hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S,
 // Final step of the certified pre-filter: T~ = K-th best approximate key of each query's lists, survivors = rows within `margin` of it,
 // exact fp32 fma-chain score (the sweep's k order) of every survivor from the fp32 gallery, exact top-K of those.  Queries without
 // room (list overflow, > 6144 candidates, > 1024 survivors) are flagged for launch_rank_exact.  D % 32 == 0, D <= 1024.
+// Dense form for small galleries: `approx` [B, ld] holds the bf16 sweep's score of EVERY row (launch_sweep_bf16 in its sample form with
+// S = N, R = 1); one kernel does bound, collection, T~, survivors, exact rescoring and ranking per query.  Sets state[b] / done[b] and
+// (when a query has no room) thr_key[b] + flags[0] for launch_rank_exact; flags[0..1] must be zero before (launch_sweep_bf16's
+// zero_flags does it).
+hipError_t launch_topk_dense_rescore(const float* approx, long ld, long N, const float* q, const float* gallery, int D, const float* meta,
+                                     int B, int K, const int* exclude, long exclude_off, long idx_offset, float* out_scores,
+                                     int* out_idx, unsigned long long* thr_key, int* flags, int* state, int* done, hipStream_t s);
 hipError_t launch_topk_rescore(const TopkFilter& f, const float* q, const float* gallery, int D, const float* margin, int B, int K, long idx_offset,
                                float* out_scores, int* out_idx, int* flags, int* state, hipStream_t s);
 // Fused sweep, final step: exact top-K of each query's candidate list -> out (idx = row + idx_offset; unfilled: -inf / -1).

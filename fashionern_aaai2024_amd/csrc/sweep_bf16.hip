@@ -94,9 +94,10 @@ constexpr int QUEUE_BYTES = 4 * QCAP * 12 + 128 * 8 + 128 * 4;     // 4 waves x 
 // the ring shrinks from 9 to 5 stages per wave to make room.  MFMA time per gallery byte doubles and stays far below the HBM time.
 template <int STAGES, bool FILTER, int KCH, int QB = 1>
 __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u16* g, float* scores, long ld, int B, long N, int D, long S, int R,
-                                                         TopkFilter filt, const int* gate) {
+                                                         TopkFilter filt, const int* gate, int* zero_flags) {
     static_assert(QB == 1 || KCH > 0, "two query blocks need the register-resident form");
     if (gate && *gate == 0) return;
+    if (!FILTER && zero_flags && blockIdx.x == 0 && threadIdx.x == 0) { zero_flags[0] = 0; zero_flags[1] = 0; }
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int q_stride = D * 2 + 16;                               // bytes; +16 spreads rows over the banks
     // KCH > 0, QB = 1: the ring overlays the query image; QB = 2: the image of queries 64..127 stays, the ring follows it
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
     }
     auto issue_next = [&]() {
         unsigned char* dst = ring + slot_issue * STAGE_BYTES;
-        if (FILTER && (t_issue + 1) * ROWS_T <= N) {
+        if ((FILTER || R == 1) && (t_issue + 1) * ROWS_T <= (FILTER ? N : S)) {      // whole tile of consecutive rows (the full sweep; the store-all form S = N, R = 1)
             const unsigned char* base = reinterpret_cast<const unsigned char*>(g) + (t_issue * ROWS_T * D + (long)kc_issue * KSTAGE) * 2;
 #pragma unroll
             for (int p = 0; p < 4; ++p)
@@ -348,7 +349,7 @@ hipError_t launch_bf16_to_f32(const unsigned short* x, float* y, long n, hipStre
 
 template <int STAGES, bool FILTER, int KCH, int QB = 1>
 static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
-                                    const TopkFilter& filt, const int* gate, hipStream_t s) {
+                                    const TopkFilter& filt, const int* gate, hipStream_t s, int* zf) {
     const size_t qbytes = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024;
     const size_t ringq = (size_t)4 * STAGES * STAGE_BYTES + QUEUE_BYTES;
     const size_t lds = (KCH > 0 && QB == 1) ? std::max(qbytes, ringq) : qbytes + ringq;
@@ -362,50 +363,50 @@ static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, flo
     const long ntiles = ((FILTER ? N : S) + ROWS_T - 1) / ROWS_T;
     long blocks = (ntiles + 3) / 4;
     if (blocks > 256) blocks = 256;                                // one persistent workgroup per CU
-    FERN_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, s, q, g, scores, ld, B, N, D, S, R, filt, gate);
+    FERN_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, s, q, g, scores, ld, B, N, D, S, R, filt, gate, zf);
     return hipGetLastError();
 }
 
 template <bool FILTER>
 static hipError_t launch_sweep_mode(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
-                                    const TopkFilter& filt, const int* gate, hipStream_t s) {
+                                    const TopkFilter& filt, const int* gate, hipStream_t s, int* zf) {
     static const bool regq = [] { const char* e = getenv("FERN_SWEEP_REGQ"); return !(e && e[0] == '0'); }();      // A/B switch
     if (B > 64) {    // 65..128 queries per gallery pass: second query block in LDS, 5-stage ring
         switch (D) {
-            case 64: return launch_sweep_inst<5, FILTER, 1, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
-            case 128: return launch_sweep_inst<5, FILTER, 2, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
-            case 256: return launch_sweep_inst<5, FILTER, 4, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
-            case 512: return launch_sweep_inst<5, FILTER, 8, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+            case 64: return launch_sweep_inst<5, FILTER, 1, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
+            case 128: return launch_sweep_inst<5, FILTER, 2, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
+            case 256: return launch_sweep_inst<5, FILTER, 4, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
+            case 512: return launch_sweep_inst<5, FILTER, 8, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
             default: return hipErrorInvalidValue;
         }
     }
     if (regq) {      // register-resident queries, 9-stage ring
         switch (D) {
-            case 64: return launch_sweep_inst<9, FILTER, 1>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
-            case 128: return launch_sweep_inst<9, FILTER, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
-            case 256: return launch_sweep_inst<9, FILTER, 4>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
-            case 512: return launch_sweep_inst<9, FILTER, 8>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
-            case 640: return launch_sweep_inst<9, FILTER, 10>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);      // RN50x4 (C3): 320 fragment VGPRs of the 512
+            case 64: return launch_sweep_inst<9, FILTER, 1>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
+            case 128: return launch_sweep_inst<9, FILTER, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
+            case 256: return launch_sweep_inst<9, FILTER, 4>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
+            case 512: return launch_sweep_inst<9, FILTER, 8>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
+            case 640: return launch_sweep_inst<9, FILTER, 10>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);      // RN50x4 (C3): 320 fragment VGPRs of the 512
             default: break;
         }
     }
     const size_t qbytes = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024;
     const size_t room = (size_t)160 * 1024 - qbytes - QUEUE_BYTES;
     const int stages = (int)(room / (4 * STAGE_BYTES));
-    if (stages >= 5) return launch_sweep_inst<5, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
-    if (stages >= 4) return launch_sweep_inst<4, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
-    if (stages >= 3) return launch_sweep_inst<3, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s);
+    if (stages >= 5) return launch_sweep_inst<5, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
+    if (stages >= 4) return launch_sweep_inst<4, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
+    if (stages >= 3) return launch_sweep_inst<3, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
-                             const TopkFilter* filt, const int* gate, hipStream_t s) {
+                             const TopkFilter* filt, const int* gate, hipStream_t s, int* zero_flags) {
     if (B <= 0 || N <= 0) return hipSuccess;
     if (B > 128 || (B > 64 && D != 64 && D != 128 && D != 256 && D != 512) || D % 64 || D > 1024 || R < 1) return hipErrorInvalidValue;
-    if (filt) return launch_sweep_mode<true>(q, g, nullptr, 0, B, N, D, 0, 1, *filt, gate, s);
+    if (filt) return launch_sweep_mode<true>(q, g, nullptr, 0, B, N, D, 0, 1, *filt, gate, s, nullptr);
     if (S <= 0) return hipSuccess;
     if (!scores || (S - 1) * (long)R >= N) return hipErrorInvalidValue;      // every sample run must start inside the gallery
-    return launch_sweep_mode<false>(q, g, scores, ld, B, N, D, S, R, TopkFilter{}, gate, s);
+    return launch_sweep_mode<false>(q, g, scores, ld, B, N, D, S, R, TopkFilter{}, gate, s, zero_flags);
 }
 
 }  // namespace fern

@@ -15,6 +15,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace fern {
 
@@ -522,25 +523,136 @@ typedef float f32x4e __attribute__((ext_vector_type(4)));
 // exact K-th best too.
 constexpr int RESC_MAX = 1024;                  // survivors per query that are rescored here
 constexpr int RESC_PER = RESC_MAX / 256;
-constexpr int RESC_CH = 32;                     // k per chunk of the transposing tile
+constexpr int RESC_CH = 32;                     // k per step of the transposing tile
 constexpr int RESC_TLD = RESC_CH + 4;           // floats per tile row (+ 4: lane l's ds_read_b128 of row l starts 4 banks after lane l-1's)
-static_assert(4 * 64 * RESC_TLD * 4 <= CAND_MAX * 8, "the four waves' tiles overlay the candidate keys");
+constexpr int RESC_ROWS = 32;                   // survivors per wave and round
+constexpr int RESC_TILE_FLOATS = 4 * 2 * RESC_ROWS * RESC_TLD;      // the four waves' tiles, double buffered
+
+// One wave, 32 survivors surv[s0 .. s0 + 32) (rows past ns redo survivor s0): their exact fp32 chains against qrow.  D = 32 nsteps k,
+// nsteps % RING == 0.  A step is four load instructions (8 rows x 32 floats each: whole 128-byte lines) whose registers go through
+// the wave's LDS tile so that lane l < 32 can continue survivor l's chain over those 32 k.  The loads of the next RING steps are always
+// in flight -- a register ring, a slot refilled right after its registers were written to the tile -- and the tile is double buffered:
+// step c + 1 is written while step c is read.  The loop body is BRANCH-FREE (loads past the row's end re-read its last step, the
+// tile write after the last step is never read): behind `if (c < nsteps)` guards the compiler waited for every load right after
+// issuing it (s_waitcnt vmcnt(0..3) in front of each tile write) and the ring was one deep.
+template <int RING>
+__device__ __forceinline__ float rescore_rows(const unsigned* surv, int s0, int ns, const float* qrow, const float* gallery, int D, float* tl) {
+    const int lane = threadIdx.x & 63;
+    const int lrow = lane >> 3, lcol = (lane & 7) * 4;       // loader role: row inside a group of 8, float offset inside a 32-float step
+    const int l31 = lane & 31;
+    const int nsteps = D / RESC_CH;
+    const float* src[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int r = s0 + rg * 8 + lrow;
+        src[rg] = gallery + (long)surv[r < ns ? r : s0] * D + lcol;
+    }
+    f32x4e reg[RING][4];
+#pragma unroll
+    for (int c = 0; c < RING; ++c)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) reg[c][rg] = *reinterpret_cast<const f32x4e*>(src[rg] + c * RESC_CH);      // nsteps >= RING
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) *reinterpret_cast<f32x4e*>(tl + (rg * 8 + lrow) * RESC_TLD + lcol) = reg[0][rg];      // step 0's tile
+    {
+        const int cn = RING < nsteps ? RING : nsteps - 1;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) reg[0][rg] = *reinterpret_cast<const f32x4e*>(src[rg] + cn * RESC_CH);
+    }
+    float acc = 0.0f;
+    for (int c0 = 0; c0 < nsteps; c0 += RING) {
+#pragma unroll
+        for (int cc = 0; cc < RING; ++cc) {
+            const int c = c0 + cc;
+            constexpr int TS = RESC_ROWS * RESC_TLD;
+            const int nslot = (cc + 1) % RING;
+            float* nt = tl + ((cc + 1) & 1) * TS;            // RING is even: step c + 1's buffer parity is static
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) *reinterpret_cast<f32x4e*>(nt + (rg * 8 + lrow) * RESC_TLD + lcol) = reg[nslot][rg];
+            {
+                const int cn = c + 1 + RING < nsteps ? c + 1 + RING : nsteps - 1;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) reg[nslot][rg] = *reinterpret_cast<const f32x4e*>(src[rg] + cn * RESC_CH);
+            }
+            const float* mrow = tl + (cc & 1) * TS + l31 * RESC_TLD;
+            const float* qk = qrow + c * RESC_CH;
+            f32x4e gg[RESC_CH / 4], qq[RESC_CH / 4];
+#pragma unroll
+            for (int g4 = 0; g4 < RESC_CH / 4; ++g4) {
+                gg[g4] = *reinterpret_cast<const f32x4e*>(mrow + g4 * 4);
+                qq[g4] = *reinterpret_cast<const f32x4e*>(qk + g4 * 4);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this step's reads (and the next step's tile writes) are done
+#pragma unroll
+            for (int g8 = 0; g8 < RESC_CH / 8; ++g8) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = __builtin_fmaf(qq[2 * g8][e], gg[2 * g8][e], acc);
+                    acc = __builtin_fmaf(qq[2 * g8 + 1][e], gg[2 * g8 + 1][e], acc);
+                }
+            }
+        }
+    }
+    return acc;
+}
+
+// Exact scores of the survivors surv[0..ns) of query row `qrow` (LDS) and their ranking: the tail shared by the two rescoring
+// kernels.  Every thread of the 256-thread workgroup calls it.  A wave takes 32 survivors per round (rescore_rows).
+// Ranking: every thread counts the keys above its survivor's key (LDS broadcast reads) and writes rank < K straight to its slot -- no
+// second selection, no sort.  D % 64 == 0.
+__device__ __forceinline__ void rescore_and_rank(const unsigned* surv, int ns, const float* qrow, const float* gallery, int D, float* tiles,
+                                                 u64* x_key, int K, long idx_offset, float* out_scores, int* out_idx) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* tl = tiles + wave * (2 * RESC_ROWS * RESC_TLD);
+    const int nsteps = D / RESC_CH;
+    for (int s0 = wave * RESC_ROWS; s0 < ns; s0 += 4 * RESC_ROWS) {
+        float acc;
+        if (nsteps % 8 == 0) acc = rescore_rows<8>(surv, s0, ns, qrow, gallery, D, tl);
+        else if (nsteps % 4 == 0) acc = rescore_rows<4>(surv, s0, ns, qrow, gallery, D, tl);
+        else acc = rescore_rows<2>(surv, s0, ns, qrow, gallery, D, tl);
+        if (lane < RESC_ROWS && s0 + lane < ns) x_key[s0 + lane] = make_key(acc, surv[s0 + lane]);
+    }
+    if (tid < 4) x_key[ns + tid] = 0;                // the counting loop reads four keys at a time: zeros never count (x_key holds RESC_MAX + 4)
+    __syncthreads();
+    // rank by counting: keys are distinct (the index is part of the key); four keys per pair of LDS reads
+    for (int i = tid; i < ns; i += 256) {
+        const u64 key = x_key[i];
+        int rank = 0;
+        for (int j0 = 0; j0 < ns; j0 += 4) {
+            const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(x_key + j0), c = *reinterpret_cast<const ulonglong2*>(x_key + j0 + 2);
+            rank += (a.x > key) + (a.y > key) + (c.x > key) + (c.y > key);
+        }
+        if (rank < K) {
+            out_scores[rank] = unorderable((unsigned)(key >> 32));
+            out_idx[rank] = (int)((long)(0xFFFFFFFFu - (unsigned)key) + idx_offset);
+        }
+    }
+    for (int r = ns + tid; r < K; r += 256) { out_scores[r] = -INFINITY; out_idx[r] = -1; }      // fewer survivors than K: the gallery ran out
+}
+
+static_assert(RESC_TILE_FLOATS * 4 <= CAND_MAX * 8, "the four waves' (double-buffered) tiles overlay the candidate keys");
 __global__ __launch_bounds__(256) void topk_rescore_kernel(TopkFilter f, const float* q, const float* gallery, int D, const float* margin_in, int K,
                                                            long idx_offset, float* out_scores, int* out_idx, int* flags, int* state) {
     __shared__ __attribute__((aligned(16))) u64 c_key[CAND_MAX];      // candidates (approximate keys); then select_kth_fast's compact list; then the waves' tiles
-    __shared__ u64 x_key[RESC_MAX];             // exact keys of the survivors
+    __shared__ __attribute__((aligned(16))) u64 x_key[RESC_MAX + 4];      // exact keys of the survivors
     __shared__ unsigned surv[RESC_MAX];         // gallery rows of the survivors
     __shared__ __attribute__((aligned(16))) float qrow[1024];
     __shared__ int red[32];
-    __shared__ u64 lists[64];
-    __shared__ int wtotal[4], over[4], nsel, nsurv;
+    __shared__ int wtotal[4], over[4], nsurv;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cnt_raw = f.count[(long)b * RANK_SLOTS + tid];      // thread t owns list t
+    const u64* mylist = f.cand + ((long)b * RANK_SLOTS + tid) * f.cap;      // thread t owns list t
+    // the list's first entries are requested together with its count (entries past the count are stale and dropped below): one
+    // round trip instead of two for the ~K R / 256 entries a list typically holds
+    constexpr int SPEC = 8;
+    u64 first[SPEC];
+#pragma unroll
+    for (int u = 0; u < SPEC; ++u) first[u] = u < f.cap ? mylist[u] : 0;
+    const int cnt_raw = f.count[(long)b * RANK_SLOTS + tid];
     const int cnt = cnt_raw < f.cap ? cnt_raw : f.cap;
     const bool overflow_w = __any(cnt_raw > f.cap);
     const int incl = wave_inclusive_sum(cnt, lane);
     if (lane == 63) { wtotal[wave] = incl; over[wave] = overflow_w ? 1 : 0; }
-    if (tid == 0) { nsel = 0; nsurv = 0; }
+    if (tid == 0) nsurv = 0;
     for (int i = tid; i < D; i += 256) qrow[i] = q[(long)b * D + i];
     __syncthreads();
     const int total = wtotal[0] + wtotal[1] + wtotal[2] + wtotal[3];
@@ -550,14 +662,15 @@ __global__ __launch_bounds__(256) void topk_rescore_kernel(TopkFilter f, const f
     }
     int base = incl - cnt;
     for (int w = 0; w < wave; ++w) base += wtotal[w];
-    const u64* cand = f.cand + (long)b * RANK_SLOTS * f.cap;
     {
+#pragma unroll
+        for (int u = 0; u < SPEC; ++u)
+            if (u < cnt) c_key[base + u] = first[u];
         int maxc = cnt;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(maxc, m); maxc = o > maxc ? o : maxc; }
-        const u64* mylist = cand + (long)tid * f.cap;
 #pragma unroll 1
-        for (int e0 = 0; e0 < maxc; e0 += 8) {
+        for (int e0 = SPEC; e0 < maxc; e0 += 8) {
             u64 key[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) key[u] = e0 + u < cnt ? mylist[e0 + u] : 0;
@@ -594,83 +707,238 @@ __global__ __launch_bounds__(256) void topk_rescore_kernel(TopkFilter f, const f
         if (tid == 0) { state[b] = 1; flags[0] = 1; }
         return;
     }
-    // exact rescoring, 64 survivors per wave and round
-    float* tl = reinterpret_cast<float*>(c_key) + wave * (64 * RESC_TLD);
-    const int lrow = lane >> 3, lcol = (lane & 7) * 4;       // loader role: row inside a group of 8, float offset inside the 32-float chunk
-    for (int s0 = wave * 64; s0 < ns; s0 += 256) {
-        const float* src[8];
+    rescore_and_rank(surv, ns, qrow, gallery, D, reinterpret_cast<float*>(c_key), x_key, K, idx_offset, out_scores + (long)b * K, out_idx + (long)b * K);
+}
+
+// ---- dense form of the certified pre-filter (galleries up to DENSE_MAX_N rows) -------------------------------------------------------
+// For a small gallery the stage is launch boundaries, not bytes (C2: five kernels, 76 us, of which the sweep's 47 MB are ~10).  Here
+// the bf16 sweep simply STORES its approximate scores ([B, ld] fp32: a quarter of the bf16 gallery's bytes at B = 64, D = 512) -- no
+// sample pass, no bound kernel, no candidate lists, no atomics -- and this kernel does everything else, one workgroup per query:
+//   pass 1  every thread's maximum over its strided share of the row -> per wave the ceil(K / 4)-th largest lane maximum -> l0 = the
+//           smallest of the four: at least K scores are >= l0, so T~ (the K-th best approximate score) >= l0;
+//   pass 2  (the row again, from L2) collect the rows with s~ >= l0 - margin: a superset of {s~ >= T~ - margin};
+//   T~ among the collected, survivors = collected rows with s~ >= T~ - margin, exact rescoring + ranking (rescore_and_rank).
+// Without room (more than DENSE_CAP collected, more than RESC_MAX survivors) the query is flagged for the exact pass with the bound
+// it had reached (l0 - margin or T~ - margin: lower bounds of the exact K-th best).  Resets done[b] for that pass; flags[0] is
+// zeroed by the host launcher before the sweep.
+constexpr int DENSE_SEG = 1024;                 // collected keys per wave (4 segments)
+constexpr int DENSE_UB = 16;                    // 16-byte loads a thread keeps in flight while it walks the score row
+constexpr int DENSE_BATCH = 1024 * DENSE_UB;    // floats the workgroup covers per batch
+// NB > 0: the row fits NB batches, which stay in registers between the two passes (N <= NB * 16384); NB = 0: any N, the row is read
+// twice (the second time from this XCD's L2).
+template <int NB>
+__global__ __launch_bounds__(256) void topk_dense_rescore_kernel(const float* approx, long ld, long N, const float* q, const float* gallery, int D,
+                                                                 BoundMargin mg, int K, const int* exclude, long exclude_off, long idx_offset,
+                                                                 float* out_scores, int* out_idx, u64* thr_key, int* flags, int* state, int* done, int stop) {
+    __shared__ __attribute__((aligned(16))) u64 ckey[4][DENSE_SEG + 2];      // per wave: collected approximate keys (+ zero padding)
+    __shared__ __attribute__((aligned(16))) float tiles[RESC_TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) u64 x_key[RESC_MAX + 4];
+    __shared__ unsigned surv[RESC_MAX];
+    __shared__ __attribute__((aligned(16))) float qrow[1024];
+    __shared__ int red[32];
+    __shared__ unsigned wmax[4];
+    __shared__ int wcnt[4];
+    __shared__ int nsurv;
+    __shared__ unsigned kth_hi;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = approx + (long)b * ld;
+    if (tid == 0) { nsurv = 0; kth_hi = 0; state[b] = 0; done[b] = 0; }
+    for (int i = tid; i < D; i += 256) qrow[i] = q[(long)b * D + i];
+    long drop = -1;
+    if (exclude) {
+        const long er = (long)exclude[b] - exclude_off;
+        if (er >= 0 && er < N) drop = er;
+    }
+    const long n4 = N & ~3L;
+    constexpr int NBR = NB > 0 ? NB : 1;
+    f32x4e v[NBR][DENSE_UB];
+    // This kernel runs ONE wave per SIMD (64 workgroups on 64 CUs): every VALU instruction of a phase is 4 cycles of its latency, so
+    // the walks over the row are written for instruction count -- float maxima (v_max3_f32) instead of orderable keys, the excluded
+    // row handled by a separate (rare) path, keys built only for the ~100 collected rows.
+    // One batch: DENSE_UB loads per thread, UNCONDITIONAL on a clamped address and masked afterwards (behind `if (i < n4)` the
+    // compiler put every load in its own branch with an s_waitcnt vmcnt(0) in front: sixteen serial round trips per batch).  The
+    // row was written by the sweep from other XCDs: it comes from HBM / the Infinity Cache at 1-2 us a round trip.
+    // Loaded values are SANITISED once (positions past the row and the excluded row become -inf), so that the two walks are one
+    // v_max3 / one v_cmp per element.
+    auto load_batch = [&](long base, f32x4e (&dst)[DENSE_UB]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = s0 + i * 8 + lrow;
-            src[i] = gallery + (long)surv[r < ns ? r : s0] * D + lcol;      // rows past the end redo survivor s0 (discarded)
+        for (int u = 0; u < DENSE_UB; ++u) {
+            const long i = base + u * 1024L + tid * 4;
+            dst[u] = *reinterpret_cast<const f32x4e*>(row + (i < n4 ? i : 0));
         }
-        f32x4e nxt[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) nxt[i] = *reinterpret_cast<const f32x4e*>(src[i]);
-        float acc = 0.0f;
-        for (int c0 = 0; c0 < D; c0 += RESC_CH) {
+        for (int u = 0; u < DENSE_UB; ++u) {
+            const long i = base + u * 1024L + tid * 4;
+            const bool in = i < n4;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4e*>(tl + (i * 8 + lrow) * RESC_TLD + lcol) = nxt[i];
-            if (c0 + RESC_CH < D) {
+            for (int e = 0; e < 4; ++e) dst[u][e] = in ? dst[u][e] : -INFINITY;
+            if (drop >= i && drop < i + 4) dst[u][drop - i] = -INFINITY;     // (rare: the excluded row)
+        }
+    };
+    // the query's two norms (bound_margin_of): loads issued now, reduced after pass 1
+    float qa = 0.f, qe = 0.f;
+    for (int i = tid; i < D; i += 256) {
+        const float x = q[(long)b * D + i];
+        const float dd = x - bf16_bits_to_f32(f32_to_bf16_bits(x));
+        qa += x * x;
+        qe += dd * dd;
+    }
+    // pass 1: every thread's maximum score.  fmax drops NaNs; the running SUM of the scores is NaN whenever one of them is (or when
+    // +inf meets -inf: a false alarm that only costs speed) -- a NaN anywhere makes the wave collect everything.
+    float fmax_t = -INFINITY, nsum = 0.f;
+    auto max_batch = [&](const f32x4e (&src)[DENSE_UB]) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) nxt[i] = *reinterpret_cast<const f32x4e*>(src[i] + c0 + RESC_CH);
+        for (int u = 0; u < DENSE_UB; ++u) {
+            fmax_t = fmaxf(fmaxf(fmax_t, src[u][0]), fmaxf(src[u][1], fmaxf(src[u][2], src[u][3])));
+            nsum += (src[u][0] + src[u][1]) + (src[u][2] + src[u][3]);      // (sanitised -inf positions keep the sum at -inf, not NaN)
+        }
+    };
+    if (NB > 0) {
+#pragma unroll
+        for (int nb = 0; nb < NBR; ++nb) load_batch((long)nb * DENSE_BATCH, v[nb]);
+#pragma unroll
+        for (int nb = 0; nb < NBR; ++nb) max_batch(v[nb]);
+    } else {
+        for (long base = 0; base < n4; base += DENSE_BATCH) {
+            load_batch(base, v[0]);
+            max_batch(v[0]);
+        }
+    }
+    float tail = -INFINITY;                          // the row's last N % 4 scores, one per thread (-inf: none / excluded)
+    if (tid < (int)(N - n4) && n4 + tid != drop) { tail = row[n4 + tid]; fmax_t = fmaxf(fmax_t, tail); nsum += tail; }
+    const bool nan_t = nsum != nsum;
+    unsigned tmax = fmax_t == -INFINITY ? 0u : orderable(fmax_t);      // 0 = "no row": a thread without rows, or only -inf scores
+    if (stop == 1) { if (tmax == 0x12345) out_idx[0] = 1; return; }
+    // margin (bound_margin_of's arithmetic on the sums started above)
+    float margin;
+    {
+        float* fred = reinterpret_cast<float*>(red);
+#pragma unroll
+        for (int x = 32; x >= 1; x >>= 1) { qa += __shfl_xor(qa, x); qe += __shfl_xor(qe, x); }
+        if (lane == 0) { fred[wave] = qa; fred[4 + wave] = qe; }
+        __syncthreads();
+        const float a = fred[0] + fred[1] + fred[2] + fred[3], e = fred[4] + fred[5] + fred[6] + fred[7];
+        const float nq = sqrtf(a), eq = sqrtf(e);
+        const float E = mg.meta[0], Gt = mg.meta[1], G = mg.meta[2];
+        const float eps = (nq * E + eq * Gt) * 1.00390625f + (float)D * 4.76837158203125e-7f * nq * fmaxf(G, Gt);
+        margin = 2.0f * eps * 1.0009765625f;
+    }
+    const unsigned sorted = sort64_desc_u32(tmax, lane);
+    const int tw = (K + 3) / 4;
+    const unsigned vw = (unsigned)__builtin_amdgcn_readlane((int)sorted, tw - 1);
+    if (lane == 0) wmax[wave] = __any(nan_t) ? 0u : vw;                 // a NaN score anywhere in the wave's share: collect everything
+    __syncthreads();
+    unsigned l0 = wmax[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) l0 = wmax[w] < l0 ? wmax[w] : l0;
+    // l0 == 0: some wave holds fewer than ceil(K / 4) rows (a gallery of < ~K rows): everything is collected (-inf scores included,
+    // except the sanitised positions, which are told apart by their index)
+    const bool all = l0 == 0;
+    const float cut0 = all ? -INFINITY : unorderable(l0) - margin;
+    if (stop == 2) { if (cut0 == 0.12345f) out_idx[0] = 1; return; }
+    // pass 2: collect the rows at or above cut0 into THIS WAVE's segment -- one compare + ballot per element, no atomics (one returning
+    // LDS atomic per hit was ~200 cycles each); stored as raw (score bits, row), keyed after the pass
+    u64* seg = ckey[wave];
+    int wn = 0;                                      // wave-uniform: entries in the segment so far
+    auto collect_one = [&](float val, long n, bool hit) {
+        const u64 m = __ballot(hit);
+        if (m) {
+            const int pos = wn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (hit && pos < DENSE_SEG) seg[pos] = ((u64)__float_as_uint(val) << 32) | (unsigned)n;
+            wn += __popcll(m);
+        }
+    };
+    auto collect_batch = [&](long base, const f32x4e (&src)[DENSE_UB]) {
+#pragma unroll
+        for (int u = 0; u < DENSE_UB; ++u) {
+            const long i = base + u * 1024L + tid * 4;
+            if (all) {                                                      // (rare) everything that is a row: positions inside the row, not the excluded one
+#pragma unroll
+                for (int e = 0; e < 4; ++e) collect_one(src[u][e], i + e, i < n4 && i + e != drop);
+            } else {
+                // two v_max3 + one compare reject a position (64 lanes x 4 scores) that holds nothing at or above the cut -- about half of them
+                const float m4 = fmaxf(fmaxf(src[u][0], src[u][1]), fmaxf(src[u][2], src[u][3]));
+                const bool nan4 = (src[u][0] + src[u][1]) + (src[u][2] + src[u][3]) != (src[u][0] + src[u][1]) + (src[u][2] + src[u][3]);
+                if (__ballot(!(m4 < cut0) || nan4) == 0) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) collect_one(src[u][e], i + e, !(src[u][e] < cut0));      // sanitised positions are -inf < cut0
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own tile writes have landed (no other wave touches this tile)
-            const float* mrow = tl + lane * RESC_TLD;
+        }
+    };
+    if (stop == 21) {
+    } else if (NB > 0) {
 #pragma unroll
-            for (int g8 = 0; g8 < RESC_CH / 8; ++g8) {
-                const f32x4e g0 = *reinterpret_cast<const f32x4e*>(mrow + g8 * 8), g1 = *reinterpret_cast<const f32x4e*>(mrow + g8 * 8 + 4);
-                const f32x4e q0 = *reinterpret_cast<const f32x4e*>(qrow + c0 + g8 * 8), q1 = *reinterpret_cast<const f32x4e*>(qrow + c0 + g8 * 8 + 4);
+        for (int nb = 0; nb < NBR; ++nb) collect_batch((long)nb * DENSE_BATCH, v[nb]);
+    } else {
+        for (long base = 0; base < n4; base += DENSE_BATCH) {
+            load_batch(base, v[0]);
+            collect_batch(base, v[0]);
+        }
+    }
+    collect_one(tail, n4 + tid, tid < (int)(N - n4) && n4 + tid != drop && (all || !(tail < cut0)));
+    // raw entries -> ranking keys (orderable score, ~row), in place: the wave's own entries, no barrier needed before
+    for (int i = lane; i < (wn < DENSE_SEG ? wn : DENSE_SEG); i += 64) {
+        const u64 r = seg[i];
+        seg[i] = make_key(__uint_as_float((unsigned)(r >> 32)), (unsigned)r);
+    }
+    const int wkeep = wn < DENSE_SEG ? wn : DENSE_SEG;
+    if (lane < 2) seg[wkeep + lane] = 0;             // zero padding: the counting loop reads two keys at a time
+    if (lane == 0) wcnt[wave] = wn;
+    __syncthreads();
+    const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+    const int nc = c0 + c1 + c2 + c3;
+    if (stop == 3 || stop == 21) { if (tid == 0) out_idx[(long)b * K] = nc; return; }
+    if (c0 > DENSE_SEG || c1 > DENSE_SEG || c2 > DENSE_SEG || c3 > DENSE_SEG) {
+        if (tid == 0) { state[b] = 1; flags[0] = 1; thr_key[b] = cut0 == cut0 && l0 != 0 ? (u64)orderable(cut0) << 32 : 0ull; }
+        return;
+    }
+    // the i-th collected key (segments in wave order)
+    auto key_at = [&](int i) -> u64 {
+        if (i < c0) return ckey[0][i];
+        i -= c0;
+        if (i < c1) return ckey[1][i];
+        i -= c1;
+        if (i < c2) return ckey[2][i];
+        return ckey[3][i - c2];
+    };
+    // T~ = K-th best approximate key of the collected rows (= of the gallery), by counting: keys are distinct, one 64-bit compare per
+    // pair (the scores and rows as separate words cost ~15 VALU instructions per pair: 10 us at 127 collected rows)
+    unsigned khi = 0;
+    if (nc > K) {
+        for (int i = tid; i < nc; i += 256) {
+            const u64 key = key_at(i);
+            int rank = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc = __builtin_fmaf(q0[e], g0[e], acc);
-                    acc = __builtin_fmaf(q1[e], g1[e], acc);
+            for (int w = 0; w < 4; ++w) {
+                const int cw = w == 0 ? c0 : w == 1 ? c1 : w == 2 ? c2 : c3;
+                for (int j0 = 0; j0 < cw; j0 += 2) {
+                    const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(&ckey[w][j0]);
+                    rank += (a.x > key) + (a.y > key);
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile reads done before the next chunk overwrites it
+            if (rank == K - 1) kth_hi = (unsigned)(key >> 32);
         }
-        if (s0 + lane < ns) x_key[s0 + lane] = make_key(acc, surv[s0 + lane]);
+        if (stop == 36) return;
+        __syncthreads();
+        khi = kth_hi;
+    }
+    const float cut = khi != 0 ? unorderable(khi) - margin : -INFINITY;
+    if (stop == 4) { if (cut == 0.12345f) out_idx[0] = 1; return; }
+    for (int i = tid; i < nc; i += 256) {
+        const u64 key = key_at(i);
+        if (!(unorderable((unsigned)(key >> 32)) < cut)) {
+            const int p = atomicAdd(&nsurv, 1);
+            if (p < RESC_MAX) surv[p] = 0xFFFFFFFFu - (unsigned)key;
+        }
     }
     __syncthreads();
-    // rank the exact keys
-    u64 best = 0;
-    if (ns <= 64) {
-        if (wave != 0) return;
-        best = sort64_desc(lane < ns ? x_key[lane] : 0, lane);
-    } else {
-        u64 xm[RESC_PER];
-        unsigned xh[RESC_PER];
-#pragma unroll
-        for (int j = 0; j < RESC_PER; ++j) {
-            const int i = tid + 256 * j;
-            xm[j] = i < ns ? x_key[i] : 0;
-            xh[j] = (unsigned)(xm[j] >> 32);
-        }
-        const int want2 = ns < K ? ns : K;
-        __syncthreads();
-        const u64 kx = select_kth_largest<RESC_PER, 4, true>(xh, [&](int j) { return (unsigned)xm[j]; }, want2, red, c_key);
-#pragma unroll
-        for (int j = 0; j < RESC_PER; ++j) {
-            if (xm[j] != 0 && xm[j] >= kx) {
-                const int p = atomicAdd(&nsel, 1);
-                if (p < 64) lists[p] = xm[j];
-            }
-        }
-        __syncthreads();
-        if (wave != 0) return;
-        const int n64 = nsel < 64 ? nsel : 64;
-        best = sort64_desc(lane < n64 ? lists[lane] : 0, lane);
+    const int ns = nsurv;
+    if (stop == 5) { if (tid == 0) out_idx[(long)b * K] = ns; return; }
+    if (ns > RESC_MAX) {
+        if (tid == 0) { state[b] = 1; flags[0] = 1; thr_key[b] = cut == cut && khi != 0 ? (u64)orderable(cut) << 32 : 0ull; }
+        return;
     }
-    if (lane < K) {
-        float sc = -INFINITY;
-        int idx = -1;
-        if (best != 0) {
-            sc = unorderable((unsigned)(best >> 32));
-            idx = (int)((long)(0xFFFFFFFFu - (unsigned)best) + idx_offset);
-        }
-        out_scores[(long)b * K + lane] = sc;
-        out_idx[(long)b * K + lane] = idx;
-    }
+    rescore_and_rank(surv, ns, qrow, gallery, D, tiles, x_key, K, idx_offset, out_scores + (long)b * K, out_idx + (long)b * K);
 }
 
 // ---- exact pass ---------------------------------------------------------------------------------------------------------------
@@ -848,8 +1116,28 @@ hipError_t launch_topk_candidates(const TopkFilter& f, int B, int K, long idx_of
 hipError_t launch_topk_rescore(const TopkFilter& f, const float* q, const float* gallery, int D, const float* margin, int B, int K, long idx_offset,
                                float* out_scores, int* out_idx, int* flags, int* state, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (K < 1 || K > 64 || f.cap < 1 || f.cap > 64 || D < 32 || D % 32 || D > 1024 || !margin) return hipErrorInvalidValue;
+    if (K < 1 || K > 64 || f.cap < 1 || f.cap > 64 || D < 64 || D % 64 || D > 1024 || !margin) return hipErrorInvalidValue;
     FERN_LAUNCH(topk_rescore_kernel, dim3(B), dim3(256), 0, s, f, q, gallery, D, margin, K, idx_offset, out_scores, out_idx, flags, state);
+    return hipGetLastError();
+}
+
+hipError_t launch_topk_dense_rescore(const float* approx, long ld, long N, const float* q, const float* gallery, int D, const float* meta,
+                                     int B, int K, const int* exclude, long exclude_off, long idx_offset, float* out_scores,
+                                     int* out_idx, unsigned long long* thr_key, int* flags, int* state, int* done, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (K < 1 || K > 64 || D < 64 || D % 64 || D > 1024 || N < 1 || (ld & 3) || !meta) return hipErrorInvalidValue;
+    const BoundMargin mg{q, D, meta, nullptr};
+    // lab switch (tools/rank_bench.py): FERN_DENSE_STOP=k ends the kernel after phase k (results are then garbage) to attribute its time
+    static const int stop = [] { const char* e = getenv("FERN_DENSE_STOP"); return e ? atoi(e) : 0; }();
+    const long n4 = N & ~3L;
+#define FERN_DENSE_GO(NB)                                                                                                                       \
+    FERN_LAUNCH(topk_dense_rescore_kernel<NB>, dim3(B), dim3(256), 0, s, approx, ld, N, q, gallery, D, mg, K, exclude, exclude_off, idx_offset, \
+                out_scores, out_idx, thr_key, flags, state, done, stop)
+    if (n4 <= 1L * DENSE_BATCH) FERN_DENSE_GO(1);
+    else if (n4 <= 2L * DENSE_BATCH) FERN_DENSE_GO(2);
+    else if (n4 <= 3L * DENSE_BATCH) FERN_DENSE_GO(3);
+    else FERN_DENSE_GO(0);
+#undef FERN_DENSE_GO
     return hipGetLastError();
 }
 

@@ -306,6 +306,12 @@ class FernEngine:
                                           int(idx_offset), _ptr(ex), _stream()), "fern_sim_topk")
         return scores, idx
 
+    def set_rank_strategy(self, strategy) -> None:
+        """Form of the PreparedGallery ranking stage: "auto" (cost model), "plain" (fp32 sweep), "lists", "dense" -- identical results
+        (include/fern.h: fern_rank_strategy); a tuning / test knob."""
+        code = {"auto": 0, "plain": 1, "lists": 2, "dense": 3}[strategy] if isinstance(strategy, str) else int(strategy)
+        _lib.check(self.lib.fern_rank_set_strategy(self._h, code), "fern_rank_set_strategy")
+
     def _sim_topk_prefiltered(self, q, pg: PreparedGallery, k: int, idx_offset: int = 0, exclude_idx=None):
         q, g = self._f32(q), pg.f32
         if q.dim() != 2 or q.shape[1] != g.shape[1]:

@@ -276,6 +276,15 @@ FERN_API int fern_sim_topk_prefiltered(fern_ctx* ctx, const float* q /*[B,D]*/, 
                                        const uint16_t* gallery_bf16 /*[N,D]*/, const float* meta /*[4]*/, int B, int64_t N, int D, int K,
                                        float* out_scores /*[B,K]*/, int32_t* out_idx /*[B,K]*/, int64_t idx_offset,
                                        const int32_t* exclude_idx, void* stream);
+/* Which form of fern_sim_topk_prefiltered's stage runs on this context (forks inherit at fork time).  Every form returns the same bits;
+ * AUTO picks by a cost model of (B, N, D).  A tuning / test knob like fern_tuner_*: no reference counterpart. */
+typedef enum {
+    FERN_RANK_AUTO = 0,
+    FERN_RANK_PLAIN = 1,   /* fern_sim_topk's fp32-MFMA sweep (the pre-filter copy is not read) */
+    FERN_RANK_LISTS = 2,   /* bf16 sample pass -> bound - margin -> filtered bf16 sweep into candidate lists -> rescoring: large galleries */
+    FERN_RANK_DENSE = 3    /* bf16 sweep storing its [B, N] scores -> one select + rescore kernel: small galleries (N <= 262144) */
+} fern_rank_strategy;
+FERN_API int fern_rank_set_strategy(fern_ctx* ctx, int strategy);
 /* scores of explicitly named gallery rows (CIRR subset ranking, run/test/test_cirr.py:64-66);
  * idx < 0 -> -inf */
 FERN_API int fern_gather_scores(fern_ctx* ctx, const float* q /*[B,D]*/, const float* gallery /*[N,D]*/,

@@ -26,6 +26,24 @@ def _int_unit(n, d, seed):
     return torch.randint(-1, 2, (n, d), generator=g).float() / 8.0
 
 
+@pytest.fixture(params=["auto", "lists", "dense"])
+def engine(request):
+    """Every test of this file runs under each form of the stage (include/fern.h: fern_rank_strategy): the cost model's pick, the
+    candidate-list form and the dense form (which falls back to the lists beyond its size limit) -- all must give the same bits."""
+    eng = request.getfixturevalue("_session_engine")
+    eng.set_rank_strategy(request.param)
+    yield eng
+    eng.set_rank_strategy("auto")
+
+
+@pytest.fixture(scope="module")
+def _session_engine():
+    from fashionern_aaai2024_amd.engine import FernEngine
+    eng = FernEngine("cuda:0")
+    yield eng
+    eng.close()
+
+
 def _same_bits(s, i, cs, ci):
     return np.array_equal(i.cpu().numpy(), ci) and np.array_equal(s.cpu().numpy().view(np.uint32), cs.view(np.uint32))
 
@@ -38,7 +56,9 @@ def test_prefiltered_ranking_is_bit_identical_to_the_fma_chain(engine, B, N, D):
     pg = engine.prepare_gallery(g)
     s, i = engine.sim_topk(q, pg, 50)
     cs, ci = chain.chain_topk(q.numpy(), g.numpy(), 50)
-    assert _same_bits(s, i, cs, ci)
+    m = min(N, 50)                                         # fewer rows than K: the tail is (-inf, -1)
+    assert _same_bits(s[:, :m], i[:, :m], cs, ci)
+    assert (i[:, m:].cpu() == -1).all() and torch.isinf(s[:, m:].cpu()).all()
     s0, i0 = engine.sim_topk(q, g, 50)
     assert torch.equal(s, s0) and torch.equal(i, i0)
 

@@ -26,6 +26,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", type=str, default=None)
+    ap.add_argument("--trace", type=str, default=None,
+                    help="SHAPE:fp32_sweep|prefiltered -- for `rocprofv3 --kernel-trace`: warm up, emit the marker dispatch tools/step_timeline.py "
+                         "keys on, run --reps calls of that one variant, exit")
     args = ap.parse_args()
     eng = FernEngine("cuda:0")
     dev = eng.device
@@ -40,9 +43,24 @@ def main():
         pg = eng.prepare_gallery(gal)
         torch.cuda.synchronize()
         prep_ms = (time.perf_counter() - t0) * 1e3
+        if args.trace:
+            tname, variant = args.trace.split(":")
+            if tname != name:
+                continue
+            gg = pg if variant.startswith("prefiltered") else gal
+            eng.set_rank_strategy({"prefiltered_lists": "lists", "prefiltered_dense": "dense"}.get(variant, "auto"))
+            for _ in range(3):
+                eng.sim_topk(q, gg, k)
+            torch.cuda.synchronize()
+            eng.l2_normalize(torch.zeros(3, 64, device=dev))
+            for _ in range(args.reps):
+                eng.sim_topk(q, gg, k)
+            torch.cuda.synchronize()
+            return
         rec = {"B": b, "N": n, "D": d, "K": k, "prepare_ms_first_call": prep_ms, "algorithmic_bytes": n * d * 4 + b * d * 4 + b * k * 8}
         res = {}
-        for label, gg in (("fp32_sweep", gal), ("prefiltered", pg)):
+        for label, gg in (("fp32_sweep", gal), ("prefiltered_lists", pg), ("prefiltered_dense", pg), ("prefiltered", pg)):
+            eng.set_rank_strategy({"prefiltered_lists": "lists", "prefiltered_dense": "dense"}.get(label, "auto"))
             for _ in range(3):
                 res[label] = eng.sim_topk(q, gg, k)
             torch.cuda.synchronize()
@@ -62,7 +80,8 @@ def main():
                           "sweep_launches_per_call": st["sweep_launches"] / args.reps, "wall_us_per_call": wall,
                           "stage_GBs_of_algorithmic_bytes": rec["algorithmic_bytes"] / (stage * 1e-6) / 1e9 * max(1, (b + 1023) // 1024),
                           "frac_of_8TBs": rec["algorithmic_bytes"] / (stage * 1e-6) / 1e9 / 8000.0 * max(1, (b + 1023) // 1024)}
-        same = torch.equal(res["fp32_sweep"][0], res["prefiltered"][0]) and torch.equal(res["fp32_sweep"][1], res["prefiltered"][1])
+        same = all(torch.equal(res["fp32_sweep"][0], res[v][0]) and torch.equal(res["fp32_sweep"][1], res[v][1])
+                   for v in ("prefiltered_lists", "prefiltered_dense", "prefiltered"))
         rec["identical"] = bool(same)
         out[name] = rec
         print(name, json.dumps(rec), flush=True)
