@@ -78,6 +78,9 @@ def parse_args():
     ap.add_argument("--pmc-mode", action="store_true",
                     help="for `rocprofv3 --pmc`: warm up, emit a marker dispatch, run exactly --steps steps on one stream, exit (no JSON)")
     ap.add_argument("--save-tiles", type=str, default=None, help="write the GEMM tuner's choices to this file (FERN_GEMM_TILES format)")
+    ap.add_argument("--rank-plain", action="store_true",
+                    help="rank the fp32 gallery with the fp32-MFMA sweep (fern_sim_topk) instead of its prepared form (certified bf16 pre-filter + "
+                         "exact fp32 rescoring, fern_sim_topk_prefiltered): same results, the round-4 stage")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default c2 run at N = 1: do not also run the c3 / c4 / c5 workloads (short child runs of this script, reported "
                          "under `other_configs`)")
@@ -398,6 +401,18 @@ def main():
     ag_ms = ev0.elapsed_time(ev1)
     ag_bytes = (world - 1) * per * D * shard.element_size()      # bytes this rank receives
     shard_start = start
+    # fp32 galleries are ranked through their PREPARED form (engine.prepare_gallery: bf16 pre-filter copy + the norms that certify it;
+    # built once, like the index itself): the same exact fp32 scores and ordering, one HBM-bound bf16 pass + rescoring of the few rows
+    # that can still be in the top-K instead of an fp32-MFMA-bound sweep.  --rank-plain keeps the round-4 stage for comparison.
+    gallery_raw = gallery
+    prepare_ms = None
+    if not w["bf16_gallery"] and not args.rank_plain:
+        eng.prepare_gallery(gallery)                          # warm
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gallery = eng.prepare_gallery(gallery)
+        torch.cuda.synchronize()
+        prepare_ms = (time.perf_counter() - t0) * 1e3
 
     # CIRR extras (c4): one excluded gallery index (the reference image) and 6 img_set members per query
     ex_idx = members = None
@@ -591,23 +606,50 @@ def main():
     gemm_peak = {"fp32": F32_MFMA_PEAK_TFLOPS, "f32x3": F32X3_BOUND_TFLOPS, "mx8": MX8_MFMA_PEAK_TFLOPS}.get(precision, BF16_MFMA_PEAK_TFLOPS)
     attn_tflops = st["attn_flops"] / (st["attn_ms"] * 1e-3) / 1e12 if st["attn_ms"] > 0 else 0.0
 
-    def sweep_block(stats, calls, kernel):
-        """The ranking stage against SURVEY 8d's bytes (N*D*s_g + B*D*4 + B*K*8 per call): `achieved` counts the WHOLE stage
-        (sample pass + bound + sweep + selection + the gated exact pass), `sweep_only_*` the filtered sweep kernel alone."""
+    def sweep_block(stats, calls, kernel, alg_bytes_per_call=None):
+        """The ranking stage against SURVEY 8d's bytes (N*D*s_g + B*D*4 + B*K*8 per call, s_g = the bytes per element of the gallery the
+        CALLER holds: 4 for an fp32 gallery even when the stage streams its bf16 pre-filter copy): `achieved` counts the WHOLE stage
+        (every launch of it and the boundaries between them), `sweep_only_*` the sweep kernel alone against the bytes IT moves."""
         if calls <= 0 or stats["sweep_ms"] <= 0:
             return None
         total_ms = stats["sweep_ms"] + stats["topk_ms"]
-        by = stats["sweep_bytes"]
+        kb = stats["sweep_bytes"]
+        by = alg_bytes_per_call * calls if alg_bytes_per_call else kb
         return {"bound": "hbm", "achieved": by / (total_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": by / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
                 "algorithmic_bytes_per_call": by / calls, "stage_us": total_ms / calls * 1e3,
-                "sweep_only_us": stats["sweep_ms"] / calls * 1e3, "sweep_only_GBs": by / (stats["sweep_ms"] * 1e-3) / 1e9,
+                "sweep_only_us": stats["sweep_ms"] / calls * 1e3, "sweep_kernel_bytes_per_call": kb / calls,
+                "sweep_only_GBs": kb / (stats["sweep_ms"] * 1e-3) / 1e9,
                 "selection_us": stats["topk_ms"] / calls * 1e3}
 
-    sweep_kernel = ("sweep_bf16_kernel<FILTER> (bf16 gallery)" if w["bf16_gallery"] else
-                    "gemm_f32 kernels with the EPI_TOPK_FILTER epilogue (fp32 gallery)") + \
-        " + topk_sample_bound_kernel / topk_candidates_kernel; the [B, N] score matrix is never stored"
-    rank_roof = sweep_block(st, prof_steps, sweep_kernel)
+    if w["bf16_gallery"]:
+        sweep_kernel = "sweep_bf16_kernel<FILTER> (bf16 gallery) + topk_sample_bound_kernel / topk_candidates_kernel; the [B, N] score matrix is never stored"
+    elif args.rank_plain:
+        sweep_kernel = ("gemm_f32 kernels with the EPI_TOPK_FILTER epilogue (fp32 gallery) + topk_sample_bound_kernel / topk_candidates_kernel; "
+                        "the [B, N] score matrix is never stored")
+    else:
+        sweep_kernel = ("certified bf16 pre-filter + exact fp32 rescoring of an fp32 gallery (fern_sim_topk_prefiltered): sweep_bf16_kernel over the "
+                        "prepared bf16 copy, then topk_dense_rescore_kernel (small galleries: the sweep stores its [B, N] approximate scores) or "
+                        "sample bound - margin + candidate lists + topk_rescore_kernel (large ones); scores and order are the fp32 fma chain's")
+    alg_rank_bytes = float(n_gal) * D * (2 if w["bf16_gallery"] else 4) + B * D * 4 + B * K * 8
+    rank_roof = sweep_block(st, prof_steps, sweep_kernel, alg_rank_bytes)
+    rank_plain_roof = None
+    if rank == 0 and not w["bf16_gallery"] and not args.rank_plain and not args.pmc_mode:
+        # the same stage on the un-prepared gallery (round 4's fp32-MFMA sweep), and that the two agree bit for bit
+        im, tk, lc = batches[0]
+        qf = eng.dvr_fuse(eng.encode_image(im), lc, *eng.encode_text(tk))
+        for _ in range(3):
+            eng.sim_topk(qf, gallery_raw, K, exclude_idx=ex_idx)
+        eng.prof_enable(True)
+        for _ in range(10):
+            ps, pi = eng.sim_topk(qf, gallery_raw, K, exclude_idx=ex_idx)
+        sp = eng.prof_collect()
+        eng.prof_enable(False)
+        fs, fi = eng.sim_topk(qf, gallery, K, exclude_idx=ex_idx)
+        rank_plain_roof = sweep_block(sp, 10, "fern_sim_topk: gemm_f32 EPI_TOPK_FILTER sweep on the fp32 gallery (round 4's stage)", alg_rank_bytes)
+        rank_plain_roof["identical_to_prefiltered"] = bool(torch.equal(ps, fs) and torch.equal(pi, fi))
+        if not rank_plain_roof["identical_to_prefiltered"]:
+            raise SystemExit("bench: the pre-filtered ranking differs from the fp32 sweep's")
 
     enc_ips = lookup_qps = None
     big_roof = None
@@ -709,6 +751,8 @@ def main():
                          "gemm_us_per_dispatch": (st["gemm_ms"] * 1e3 / max(1, st["gemm_dispatches"])) if precision == "fp32" else None,
                          "f32_gemm_ms_per_step": st["gemm_ms"] / prof_steps},
             "roofline_sim_sweep": rank_roof,
+            "roofline_sim_sweep_fp32_mfma_form": rank_plain_roof,
+            "gallery_prepare_ms": prepare_ms,
             "roofline_sim_sweep_bf16_1M": big_roof,
             "encoder_f32x3": f32x3_info,
             "encoder_bf16": bf16_info,
@@ -740,6 +784,7 @@ def main():
             qf = eng.dvr_fuse(rf, lc, tg, ts)
             gpu_topk = eng.sim_topk(qf, gallery.float(), K) if w["bf16_gallery"] else eng.sim_topk(qf, gallery, K)
             torch.cuda.synchronize()
+            gallery = gallery_raw                                                       # plain tensor from here on (slicing, .cpu())
             n_cpu = gallery.shape[0] if gallery.shape[0] <= 200_000 else 200_000      # bound the CPU matmul on the 1M-row config
             if n_cpu != gallery.shape[0]:
                 gpu_topk = eng.sim_topk(qf, gallery[:n_cpu].float(), K)

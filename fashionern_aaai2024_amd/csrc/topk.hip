@@ -831,11 +831,15 @@ __global__ __launch_bounds__(256) void topk_dense_rescore_kernel(const float* ap
     unsigned l0 = wmax[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) l0 = wmax[w] < l0 ? wmax[w] : l0;
-    // l0 == 0: some wave holds fewer than ceil(K / 4) rows (a gallery of < ~K rows): everything is collected (-inf scores included,
-    // except the sanitised positions, which are told apart by their index)
-    const bool all = l0 == 0;
-    const float cut0 = all ? -INFINITY : unorderable(l0) - margin;
+    // l0 == 0: some wave holds fewer than ceil(K / 4) rows (a gallery of < ~K rows), or met a NaN score
+    if (l0 == 0) {      // (uniform) no bound: flagged for the exact pass with "accept all" -- tiny galleries, where that pass is cheap, or NaN scores
+        if (tid == 0) { state[b] = 1; flags[0] = 1; thr_key[b] = 0ull; }
+        return;
+    }
+    const float cut0 = unorderable(l0) - margin;
     if (stop == 2) { if (cut0 == 0.12345f) out_idx[0] = 1; return; }
+    // (This kernel runs ONCE per CU on a cold instruction cache: its time follows the bytes of code it executes.  A second, never-taken
+    // copy of the collection code (an "accept everything" form for tiny galleries) cost 4 us; those queries go to the exact pass instead.)
     // pass 2: collect the rows at or above cut0 into THIS WAVE's segment -- one compare + ballot per element, no atomics (one returning
     // LDS atomic per hit was ~200 cycles each); stored as raw (score bits, row), keyed after the pass
     u64* seg = ckey[wave];
@@ -852,10 +856,7 @@ __global__ __launch_bounds__(256) void topk_dense_rescore_kernel(const float* ap
 #pragma unroll
         for (int u = 0; u < DENSE_UB; ++u) {
             const long i = base + u * 1024L + tid * 4;
-            if (all) {                                                      // (rare) everything that is a row: positions inside the row, not the excluded one
-#pragma unroll
-                for (int e = 0; e < 4; ++e) collect_one(src[u][e], i + e, i < n4 && i + e != drop);
-            } else {
+            {
                 // two v_max3 + one compare reject a position (64 lanes x 4 scores) that holds nothing at or above the cut -- about half of them
                 const float m4 = fmaxf(fmaxf(src[u][0], src[u][1]), fmaxf(src[u][2], src[u][3]));
                 const bool nan4 = (src[u][0] + src[u][1]) + (src[u][2] + src[u][3]) != (src[u][0] + src[u][1]) + (src[u][2] + src[u][3]);
@@ -875,7 +876,7 @@ __global__ __launch_bounds__(256) void topk_dense_rescore_kernel(const float* ap
             collect_batch(base, v[0]);
         }
     }
-    collect_one(tail, n4 + tid, tid < (int)(N - n4) && n4 + tid != drop && (all || !(tail < cut0)));
+    collect_one(tail, n4 + tid, tid < (int)(N - n4) && n4 + tid != drop && !(tail < cut0));
     // raw entries -> ranking keys (orderable score, ~row), in place: the wave's own entries, no barrier needed before
     for (int i = lane; i < (wn < DENSE_SEG ? wn : DENSE_SEG); i += 64) {
         const u64 r = seg[i];
@@ -889,7 +890,7 @@ __global__ __launch_bounds__(256) void topk_dense_rescore_kernel(const float* ap
     const int nc = c0 + c1 + c2 + c3;
     if (stop == 3 || stop == 21) { if (tid == 0) out_idx[(long)b * K] = nc; return; }
     if (c0 > DENSE_SEG || c1 > DENSE_SEG || c2 > DENSE_SEG || c3 > DENSE_SEG) {
-        if (tid == 0) { state[b] = 1; flags[0] = 1; thr_key[b] = cut0 == cut0 && l0 != 0 ? (u64)orderable(cut0) << 32 : 0ull; }
+        if (tid == 0) { state[b] = 1; flags[0] = 1; thr_key[b] = cut0 == cut0 ? (u64)orderable(cut0) << 32 : 0ull; }
         return;
     }
     // the i-th collected key (segments in wave order)

@@ -57,6 +57,12 @@ class PreparedGallery:
     def float(self):
         return self.f32
 
+    def data_ptr(self) -> int:
+        return self.f32.data_ptr()
+
+    def is_contiguous(self) -> bool:
+        return True
+
 
 class FernEngine:
     """One native context on one GPU.  Not thread-safe (one per device per process)."""

@@ -82,8 +82,9 @@ class ComposedQueryPipeline:
 
     def submit(self, images: Optional[torch.Tensor], tokens: torch.Tensor, local: torch.Tensor, gallery: torch.Tensor, k: int,
                exclude_idx=None, members=None, idx_offset: int = 0, ref_feats: Optional[torch.Tensor] = None) -> QueryResult:
-        """images [B,3,S,S], tokens [B,77] int64, local [B,13,D] (device tensors), fused gallery [N,D] fp32 -- or bf16, which
-        selects the bf16 sweep -- -> QueryResult.  `exclude_idx` [B] drops one gallery index per query and `members` [B,m]
+        """images [B,3,S,S], tokens [B,77] int64, local [B,13,D] (device tensors), fused gallery [N,D] fp32 -- or a `PreparedGallery`
+        of it (engine.prepare_gallery: the same exact fp32 ranking through the certified bf16 pre-filter, the form a serving process
+        keeps), or bf16, which selects the bf16 sweep -- -> QueryResult.  `exclude_idx` [B] drops one gallery index per query and `members` [B,m]
         (fp32 gallery) also returns the scores of those rows: CIRR's reference removal and subset ranking
         (run/test/test_cirr.py:55-66).  `ref_feats` [B,D] (with `images=None`) is the reference harness's own query form: the
         reference image's RAW feature is looked up in the gallery index instead of being encoded again (test_fiq.py:104-107), so

@@ -119,7 +119,10 @@ def _ranked(model, predicted, index_fused, k, exclude=None) -> np.ndarray:
     start, stop, per = _my_rows(q)
     ex = None if exclude is None else torch.as_tensor(exclude[start:stop], dtype=torch.int32)
     if stop > start:
-        _, idx = eng.sim_topk(predicted[start:stop], index_fused, k, exclude_idx=ex)
+        # the gallery is ranked against once per evaluation, like the reference builds its index once (test_fiq.py:45-46): the
+        # prepared form (bf16 pre-filter copy + its certificate) lets the engine pick the cheapest exact form of the stage
+        prepared = eng.prepare_gallery(index_fused) if hasattr(eng, "prepare_gallery") and torch.is_tensor(index_fused) else index_fused
+        _, idx = eng.sim_topk(predicted[start:stop], prepared, k, exclude_idx=ex)
     else:
         idx = torch.empty((0, k), dtype=torch.int32, device=predicted.device)
     if hasattr(eng, "sync"):

@@ -231,6 +231,13 @@ def test_pipeline_lanes_are_bit_identical_to_serial():
             s, i = fut.wait()
             torch.cuda.current_stream().synchronize()
             assert torch.equal(i, ri) and torch.equal(s, rs)
+    # the PREPARED gallery (certified bf16 pre-filter + exact fp32 rescoring): same bits through the lanes, eager and (below) captured
+    pgal = eng.prepare_gallery(gal)
+    futures = [pipe.submit(im, tk, lc, pgal, 20) for im, tk, lc in batches]
+    for (rs, ri), fut in zip(serial, futures):
+        s, i = fut.wait()
+        torch.cuda.current_stream().synchronize()
+        assert torch.equal(i, ri) and torch.equal(s, rs)
     pipe.close()
     # the same stream of batches with every lane's step replayed from a hipGraph (captured at a lane's third call): identical
     # results for inputs the graph was not captured with, results of earlier replays not overwritten by later ones
@@ -242,6 +249,12 @@ def test_pipeline_lanes_are_bit_identical_to_serial():
             torch.cuda.current_stream().synchronize()
             assert torch.equal(i, ri) and torch.equal(s, rs)
     assert all(lg.graph is not None for d_ in pipe._lane_graphs for lg in d_.values())
+    for _ in range(3):
+        futures = [pipe.submit(im, tk, lc, pgal, 20) for im, tk, lc in batches]
+        for (rs, ri), fut in zip(serial, futures):
+            s, i = fut.wait()
+            torch.cuda.current_stream().synchronize()
+            assert torch.equal(i, ri) and torch.equal(s, rs)
     # a captured graph holds addresses inside its lane's workspace.  A later, bigger call on the same lane engines
     # (here: a 700-query batch -- 90 MB of candidate lists against the 64 MB first block -- eager on every lane) makes the
     # contexts re-allocate their workspaces; the old graphs must be noticed as stale and re-captured, never replayed.
