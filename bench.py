@@ -70,7 +70,7 @@ def parse_args():
     ap.add_argument("--gallery", type=int, default=None, help="override the workload's gallery rows")
     ap.add_argument("--lanes", type=int, default=3, help="query batches kept in flight on separate HIP streams")
     ap.add_argument("--graphs", action="store_true", help="replay each lane's step from a hipGraph (captured after two eager calls)")
-    ap.add_argument("--precision", choices=["fp32", "f32x3", "bf16", "fp8", "mx8"], default=None,
+    ap.add_argument("--precision", choices=["fp32", "f32x3", "bf16", "fp8", "mx8", "mx8mlp"], default=None,
                     help="override the encoder operand precision of the TIMED path (fp32 = parity mode, the c2 headline)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary legs (reduced-precision modes, lookup variant, 1M-row bf16 sweep, encode rate): the GEMM "
@@ -105,7 +105,7 @@ def other_config_lines(steps: int) -> dict:
     process, started after this one is done with its timed region; never an exec): one compact record per config so that the
     driver's single default run carries a c3 / c4 / c5 number too.  `value` of the main line is untouched."""
     out = {}
-    keep = ("value", "unit", "ms_per_step", "dtype", "encoder_precision", "accuracy_vs_fp32_encoder")
+    keep = ("value", "unit", "ms_per_step", "dtype", "encoder_precision", "accuracy_vs_fp32_encoder", "reduced_modes")
     for name in ("c3", "c4", "c5"):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "4", "--no-cpu-baseline", "--no-other-configs"]
         if name != "c5":
@@ -279,7 +279,31 @@ def cpu_baseline(clip_sd, fusion_sd, cfg, w, images, tokens, loc, gallery, sampl
                 "rank_ms": t_rank * 1e3, "fuse_plus_rank_queries_per_s": b / (t_test + t_rank)}
 
     cpu_model, host_cores = _host_cpu()
+    # the same path with torch's intra-op pool on EVERY schedulable core (BASELINE.md 3 planned os.cpu_count()): on a 256-logical-core
+    # host the pool's fork / join per small op dominates and the rate collapses, which is why `value` is quoted at 32 threads; a
+    # 4-query sample, one warm-up + one timed run, bounded at ~60 s
+    all_cores = None
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    if avail > threads:
+        torch.set_num_threads(avail)
+        ns = min(4, sample)
+        im4, tk4, lc4 = im[:ns], tk[:ns], lc[:ns]
+
+        def small():
+            with torch.no_grad():
+                rf = oclip.encode_image(csd, cfg, im4)
+                tg, ts = oclip.encode_text(csd, cfg, tk4)
+                return orank.cosine_topk(ofusion.dvr_fuse(fsd, lc4, ts, rf, tg), gal, k)
+
+        t_warm = _timed(small)
+        t_run = _timed(small) if t_warm < 30 else t_warm
+        all_cores = {"value": ns / t_run, "unit": "composed queries/sec", "threads": avail, "sample": f"{ns} composed queries, one timed run"}
+        torch.set_num_threads(threads)
     return {"value": sample / best, "unit": "composed queries/sec", "cores": threads, "threads": threads, "host_cores": host_cores,
+            "all_schedulable_cores": all_cores,
             "cpu_model": cpu_model, "kind": "port",
             "cores_note": "`cores` = torch intra-op threads actually used = min(schedulable cores, 32); `host_cores` = os.cpu_count() of the box",
             "sample": f"{sample} composed queries ({cfg.name} image + text encode, fusion, top-{k} of {gal.shape[0]} rows), "
@@ -288,6 +312,156 @@ def cpu_baseline(clip_sd, fusion_sd, cfg, w, images, tokens, loc, gallery, sampl
             "parity_vs_hip_modes": parity_modes,
             "c2_fuse_rank_full_size": stage_rates(d, min(gal.shape[0], 46_000), 64, "cpu-c2") if d == 512 else None,
             "c1_plumbing": stage_rates(640, 1000, 32, "cpu-c1")}
+
+
+class _BenchIndexDataset:
+    """Index dataset in the reference's tuple format (dataloader/fashioniq.py:82-100, mode="classic": name, image, 13 local features);
+    images come from a small pool (a 46k-image fp32 pool would be 27 GB of host memory)."""
+
+    def __init__(self, n, images, local):
+        self.n, self.images, self.local = n, images, local
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return f"img{i:06d}", self.images[i % len(self.images)], self.local[i % len(self.local)]
+
+
+class _BenchRelativeDataset:
+    """Relative (query) dataset in the reference's tuple format (fashioniq.py:69-81, mode="relative", split="val"): reference
+    name, target name, the two relative captions, the reference image's 13 local features."""
+
+    def __init__(self, q, n_gallery, local, seed=5):
+        import numpy as np
+        r = np.random.default_rng(seed)
+        self.ref = r.integers(0, n_gallery, size=q)
+        self.tgt = r.integers(0, n_gallery, size=q)
+        words = ("red", "blue", "longer", "shorter", "sleeves", "striped", "floral", "darker", "brighter", "collar", "with", "is",
+                 "more", "less", "formal", "casual", "pattern", "plain", "v-neck", "buttons")
+        self.caps = [[" ".join(r.choice(words, size=int(r.integers(3, 8)))) + ".", " ".join(r.choice(words, size=int(r.integers(3, 8))))]
+                     for _ in range(q)]
+        self.local = local
+
+    def __len__(self):
+        return len(self.ref)
+
+    def __getitem__(self, i):
+        return f"img{int(self.ref[i]):06d}", f"img{int(self.tgt[i]):06d}", self.caps[i], self.local[i % len(self.local)]
+
+
+def retrieval_quality_leg(torch, eng, cfg, D, device, modes, n_gallery=8192, queries=2048, k=64):
+    """what a reduced-precision encoder costs in the metric BASELINE names -- Recall@10 / Recall@50 -- on a synthetic
+    FashionIQ-shaped split: `n_gallery` images ENCODED under each mode (the raw index features a query's reference is looked up in,
+    run/test/test_fiq.py:104-107, and the mode="index" gallery both come from that mode's image tower), `queries` composed queries
+    (reference = a gallery row, 77-token caption) through that mode's text tower and fusion, exact ranking.  A query's TARGET is the row
+    its fp32 ranking holds at a position drawn uniformly from 0..63 (so the fp32 recalls are ~15.6 % / ~78 %: targets sit at the ranks
+    where Recall@10 / @50 are decided, not at rank 0).  Random-init weights on random inputs are the hard case for rank agreement --
+    the top scores of a query lie ~1e-3 apart -- real checkpoints separate their neighbours better."""
+    import numpy as np
+    g = torch.Generator(device=device).manual_seed(2024)
+    local = torch.randn((n_gallery, 13, D), generator=g, device=device)
+    ref = torch.randint(0, n_gallery, (queries,), generator=g, device=device)
+    toks = torch.randint(1, cfg.vocab_size - 2, (queries, cfg.context_length), generator=g, device=device)
+    toks[:, 0] = cfg.vocab_size - 2
+    toks[:, -1] = cfg.vocab_size - 1
+    pos = torch.randint(0, k, (queries,), generator=g, device=device)
+    prev = eng.precision
+    out, ranked = {}, {}
+    for mode in modes:
+        eng.set_precision(mode)
+        gi = torch.Generator(device=device).manual_seed(99)          # the SAME images for every mode
+        raw = torch.empty((n_gallery, D), device=device)
+        for o in range(0, n_gallery, 64):
+            raw[o:o + 64] = eng.encode_image(torch.randn((64, 3, cfg.image_size, cfg.image_size), generator=gi, device=device))
+        gallery = eng.index_fuse(raw, local, normalize_input=True)
+        idx = torch.empty((queries, k), dtype=torch.int32, device=device)
+        for o in range(0, queries, 64):
+            tg, ts = eng.encode_text(toks[o:o + 64])
+            r = ref[o:o + 64]
+            q = eng.dvr_fuse(raw[r], local[r], tg, ts)
+            idx[o:o + 64] = eng.sim_topk(q, gallery, k)[1]
+        ranked[mode] = idx.cpu()
+    eng.set_precision(prev)
+    base = ranked[modes[0]]
+    target = base[torch.arange(queries), pos.cpu()]
+
+    def recalls(idx):
+        hit = idx == target[:, None]
+        return float(hit[:, :10].any(1).float().mean() * 100), float(hit[:, :50].any(1).float().mean() * 100)
+
+    r10_0, r50_0 = recalls(base)
+    for mode in modes:
+        idx = ranked[mode]
+        r10, r50 = recalls(idx)
+        ov = np.mean([len(set(a.tolist()) & set(b.tolist())) / 50.0 for a, b in zip(base[:, :50], idx[:, :50])])
+        out[mode] = {"recall_at_10": r10, "recall_at_50": r50, "delta_recall_at_10_pp": r10 - r10_0, "delta_recall_at_50_pp": r50 - r50_0,
+                     "top1_same": float((idx[:, 0] == base[:, 0]).float().mean()), "top50_overlap": float(ov)}
+    return {"queries": queries, "gallery_rows": n_gallery, "reference_mode": modes[0], "modes": out,
+            "note": "targets = the fp32 ranking's row at a uniform position 0..63 per query; deltas in percentage points of queries "
+                    "(1 pp = 1 query in 100)"}
+
+
+def harness_leg(torch, eng, clip, model, cfg, D, device, n_gal, lookup_qps, enc_ips, queries=2048, images=2048):
+    """what a caller of the REFERENCE API gets.  The drop-in harness itself -- `compute_fiq_val_metrics` /
+    `generate_fiq_val_predictions` (run/test/test_fiq.py:18-122) and `extract_index_features` (utils/utils.py:44-69), called exactly as
+    the reference's driver calls them -- on a synthetic FashionIQ-shaped split at the C2 size: DataLoader batches on the HOST, captions
+    tokenised on the host by the CLIP BPE algorithm (synthetic merge table: the released vocabulary is not available offline),
+    host -> device copies per batch, the reference-feature lookup, mode="test", the gallery's mode="index" fusion and the ranking."""
+    import numpy as np
+    from fashionern_aaai2024_amd import synth
+    from fashionern_aaai2024_amd.run.test_fiq import compute_fiq_val_metrics, generate_fiq_val_predictions
+    from fashionern_aaai2024_amd.tokenizer import ClipBpeTokenizer, register_tokenizer
+    from fashionern_aaai2024_amd.utils import extract_index_features
+    letters = "abcdefghijklmnopqrstuvwxyz-"
+    merges = [(a, b) for a in "sleroncdbtfpmv" for b in "aeioulrt"][:96] + [(a, b + "</w>") for a in letters[:20] for b in "esdrnty"][:96]
+    register_tokenizer("bench-clip-bpe", ClipBpeTokenizer(merges))
+    g = torch.Generator(device=device).manual_seed(77)
+    index_features = torch.randn((n_gal, D), generator=g, device=device)
+    index_local = torch.randn((n_gal, 13, D), generator=g, device=device)
+    index_names = [f"img{i:06d}" for i in range(n_gal)]
+    host_local = torch.from_numpy(synth.local_feats(256, D, 31, "bench-ql"))
+    rel = _BenchRelativeDataset(queries, n_gal, host_local)
+    out = {"queries": queries, "gallery_rows": n_gal, "batch_size": 64, "tokenizer": "ClipBpeTokenizer (CLIP BPE algorithm, synthetic merge table), host",
+           "lanes": int(os.environ.get("FERN_HARNESS_LANES", "3"))}
+
+    def timed(fn, reps=2):
+        fn()                                          # first call: forks, workspaces, tile tuning
+        best, val = None, None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            val = fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return best, val
+
+    t_pred, _ = timed(lambda: generate_fiq_val_predictions(clip, rel, model, index_names, index_features, device, D, 64, 0, "bench-clip-bpe"))
+    t_full, rec = timed(lambda: compute_fiq_val_metrics(rel, clip, index_features, index_local, index_names, model, device, D, 64, 0, "bench-clip-bpe"))
+    out["generate_fiq_val_predictions"] = {"wall_s": t_pred, "queries_per_s": queries / t_pred,
+                                           "note": "the query loop alone (host batches -> tokenise -> upload -> lookup -> text tower -> mode=test): "
+                                                   "the figure comparable with the engine's `lookup_variant`"}
+    out["compute_fiq_val_metrics"] = {"wall_s": t_full, "queries_per_s": queries / t_full, "recall_at_10_50": list(rec),
+                                      "note": "query loop + mode=index fusion of the whole gallery + ranking + recall arithmetic, per call as the reference does"}
+    out["engine_lookup_variant_queries_per_s"] = lookup_qps
+    out["predictions_vs_engine_lookup"] = (queries / t_pred) / lookup_qps if lookup_qps else None
+    os.environ["FERN_HARNESS_LANES"] = "0"
+    t_serial, _ = timed(lambda: generate_fiq_val_predictions(clip, rel, model, index_names, index_features, device, D, 64, 0, "bench-clip-bpe"), reps=1)
+    os.environ.pop("FERN_HARNESS_LANES")
+    out["generate_fiq_val_predictions_call_by_call"] = {"wall_s": t_serial, "queries_per_s": queries / t_serial,
+                                                        "note": "FERN_HARNESS_LANES=0: the round-4 loop (one stream, two encode_text calls served by one pass)"}
+    pool_im = torch.from_numpy(synth.images(32, cfg, 9))
+    pool_lc = torch.from_numpy(synth.local_feats(32, D, 9, "bench-il"))
+    ds = _BenchIndexDataset(images, pool_im, pool_lc)
+    t_ext, res = timed(lambda: extract_index_features(ds, clip, 13, device, D), reps=1)
+    out["extract_index_features"] = {"images": images, "wall_s": t_ext, "images_per_s": images / t_ext, "batch_size": 32, "num_workers": 4,
+                                     "engine_encode_images_per_s": enc_ips,
+                                     "note": "the reference's loop (utils/utils.py:44-69): batches of 32 from a 4-worker DataLoader, pinned host "
+                                             "memory, one host -> device copy of 19 MB per batch, encode_image"}
+    del index_features, index_local
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -542,11 +716,11 @@ def main():
             step_serial(j)
         sp = eng.prof_collect()
         eng.prof_enable(False)
-        key = {"fp8": "gemm_fp8", "mx8": "gemm_mx8", "bf16": "gemm_bf16", "f32x3": "gemm"}[prec]
+        key = {"fp8": "gemm_fp8", "mx8": "gemm_mx8", "mx8mlp": "gemm_mx8", "bf16": "gemm_bf16", "f32x3": "gemm"}[prec]
         # f32x3: the GEMMs stay fp32 GEMMs algorithmically (2MNK flop each, accounted under the fp32 family) but run six 32-cycle bf16
         # MFMAs per pair of 64-cycle fp32 MFMAs, so the bound of their arithmetic is 157.3 x 128 / 48 = 419.5 fp32-equivalent TFLOP/s:
         # THAT is the peak `gemm_frac` is quoted against (quoted against the fp32 peak it read 0.987 and was no roofline fraction)
-        peak = MX8_MFMA_PEAK_TFLOPS if prec == "mx8" else F32X3_BOUND_TFLOPS if prec == "f32x3" else BF16_MFMA_PEAK_TFLOPS
+        peak = MX8_MFMA_PEAK_TFLOPS if prec in ("mx8", "mx8mlp") else F32X3_BOUND_TFLOPS if prec == "f32x3" else BF16_MFMA_PEAK_TFLOPS
         tfl = sp[key + "_flops"] / (sp[key + "_ms"] * 1e-3) / 1e12 if sp[key + "_ms"] > 0 else 0.0
         overlap = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(ref_idx.cpu(), b_idx.cpu())) / ref_idx.numel()
         info = {"value": world * B * args.steps / el, "unit": "queries/sec", "ms_per_step": el / args.steps * 1e3,
@@ -554,7 +728,8 @@ def main():
                 "dtype": ("f32 data; plain GEMMs of >= 256 rows as three bf16 planes per operand, six bf16 MFMAs per fp32 pair, f32 accumulate "
                           "(fp32-accurate, not the bit-exact fma chain; attention, statistics and the ranking stage unchanged)") if prec == "f32x3" else
                          {"bf16": "bf16", "fp8": "fp8 e4m3fn (per-token / per-channel scales)",
-                          "mx8": "fp8 e4m3fn, one E8M0 scale per 32-element block (block-scaled MFMA)"}[prec] +
+                          "mx8": "fp8 e4m3fn, one E8M0 scale per 32-element block (block-scaled MFMA)",
+                          "mx8mlp": "MLP pair (c_fc, c_proj): fp8 e4m3fn block-scaled; QKV / out-proj: bf16 --"}[prec] +
                          " operands, f32 accumulate (encoder block GEMMs; attention and the fusion BERT blocks in bf16 operand form)",
                 "gemm_tflops": tfl, "gemm_peak_tflops": peak, "gemm_frac": tfl / peak,
                 "gemm_speedup_vs_fp32_mfma_peak": (tfl / F32_MFMA_PEAK_TFLOPS) if prec == "f32x3" else None,
@@ -566,7 +741,7 @@ def main():
         return info
 
     secondary = not args.headline_only and args.config == "c2" and precision == "fp32"
-    bf16_info = fp8_info = mx8_info = f32x3_info = accuracy = None
+    bf16_info = fp8_info = mx8_info = f32x3_info = mx8mlp_info = accuracy = quality = None
     if secondary:
         step_no[0] = 0
         ref_scores, ref_idx = step().wait()
@@ -574,7 +749,14 @@ def main():
         bf16_info = reduced_precision_leg("bf16", ref_scores, ref_idx)
         fp8_info = reduced_precision_leg("fp8", ref_scores, ref_idx)
         mx8_info = reduced_precision_leg("mx8", ref_scores, ref_idx)
-    elif not args.headline_only and precision in ("fp8", "mx8"):
+        mx8mlp_info = reduced_precision_leg("mx8mlp", ref_scores, ref_idx)
+        if rank == 0:
+            pipe.synchronize()
+            quality = retrieval_quality_leg(torch, eng, cfg, D, device, ["fp32", "f32x3", "bf16", "mx8mlp", "fp8", "mx8"])
+            for name, info in (("f32x3", f32x3_info), ("bf16", bf16_info), ("mx8mlp", mx8mlp_info), ("fp8", fp8_info), ("mx8", mx8_info)):
+                quality["modes"][name]["queries_per_s"] = info["value"]
+            quality["modes"]["fp32"]["queries_per_s"] = value
+    elif not args.headline_only and precision in ("fp8", "mx8", "mx8mlp"):
         # c5: what the timed fp8 form costs in ranking agreement with the fp32 encoder on the same gallery, and the other fp8 form
         pipe.set_precision("fp32")
         step_no[0] = 0
@@ -585,11 +767,16 @@ def main():
         accuracy = {"vs_fp32_top1_same": float((ref_idx[:, 0] == t_idx[:, 0]).float().mean().item()),
                     "vs_fp32_top50_overlap": sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(ref_idx.cpu(), t_idx.cpu())) / ref_idx.numel(),
                     "vs_fp32_max_abs_top1_score_diff": float((ref_scores[:, 0] - t_scores[:, 0]).abs().max().item())}
-        other = reduced_precision_leg("fp8" if precision == "mx8" else "mx8", ref_scores, ref_idx)
-        if precision == "mx8":
-            fp8_info = other
-        else:
-            mx8_info = other
+        others = [m for m in ("mx8", "mx8mlp", "fp8") if m != precision]
+        infos = {m: reduced_precision_leg(m, ref_scores, ref_idx) for m in others}
+        fp8_info, mx8_info, mx8mlp_info = infos.get("fp8"), infos.get("mx8"), infos.get("mx8mlp")
+        if rank == 0:
+            pipe.synchronize()
+            quality = retrieval_quality_leg(torch, eng, cfg, D, device, ["fp32", precision] + others)
+            for m in others:
+                quality["modes"][m]["queries_per_s"] = infos[m]["value"]
+            quality["modes"][precision]["queries_per_s"] = value
+            accuracy["recall"] = quality["modes"][precision]
 
     # ---- roofline: instrumented passes (events around every kernel class), outside the timed region ----------
     for j in range(n_batches):
@@ -601,9 +788,9 @@ def main():
         step_serial(j)
     st = eng.prof_collect()
     eng.prof_enable(False)
-    gkey = {"fp32": "gemm", "f32x3": "gemm", "bf16": "gemm_bf16", "fp8": "gemm_fp8", "mx8": "gemm_mx8"}[precision]      # the dominant GEMM family of this run
+    gkey = {"fp32": "gemm", "f32x3": "gemm", "bf16": "gemm_bf16", "fp8": "gemm_fp8", "mx8": "gemm_mx8", "mx8mlp": "gemm_mx8"}[precision]      # the dominant GEMM family of this run
     gemm_tflops = st[gkey + "_flops"] / (st[gkey + "_ms"] * 1e-3) / 1e12 if st[gkey + "_ms"] > 0 else 0.0
-    gemm_peak = {"fp32": F32_MFMA_PEAK_TFLOPS, "f32x3": F32X3_BOUND_TFLOPS, "mx8": MX8_MFMA_PEAK_TFLOPS}.get(precision, BF16_MFMA_PEAK_TFLOPS)
+    gemm_peak = {"fp32": F32_MFMA_PEAK_TFLOPS, "f32x3": F32X3_BOUND_TFLOPS, "mx8": MX8_MFMA_PEAK_TFLOPS, "mx8mlp": MX8_MFMA_PEAK_TFLOPS}.get(precision, BF16_MFMA_PEAK_TFLOPS)
     attn_tflops = st["attn_flops"] / (st["attn_ms"] * 1e-3) / 1e12 if st["attn_ms"] > 0 else 0.0
 
     def sweep_block(stats, calls, kernel, alg_bytes_per_call=None):
@@ -653,6 +840,7 @@ def main():
 
     enc_ips = lookup_qps = None
     big_roof = None
+    harness_info = None
     if secondary:
         im, tk, lc = batches[0]
         torch.cuda.synchronize()
@@ -693,6 +881,9 @@ def main():
         eng.prof_enable(False)
         big_roof = sweep_block(sb, 10, "sweep_bf16_kernel<FILTER>: 64 queries x 1M-row bf16 gallery + sample bound / candidate select")
         del gal_bf16
+        gal_bf16_early = None
+        torch.cuda.empty_cache()
+        harness_info = harness_leg(torch, eng, clip, model, cfg, D, device, n_gal, lookup_qps, enc_ips) if rank == 0 else None
 
     result = None
     if rank == 0:
@@ -709,7 +900,7 @@ def main():
         result = {
             "metric": "composed queries/sec", "value": value, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "bf16x3", "bf16": "bf16", "fp8": "fp8", "mx8": "fp8"}[precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "bf16x3", "bf16": "bf16", "fp8": "fp8", "mx8": "fp8", "mx8mlp": "fp8"}[precision], "data": "synthetic",
             "config": {"workload": w["text"], "name": args.config, "clip": cfg.name, "query_batch_per_gpu": B, "gallery_rows": n_gal,
                        "gallery_dtype": "bf16" if w["bf16_gallery"] else "f32", "feature_dim": D, "top_k": K,
                        "image": f"3x{cfg.image_size}x{cfg.image_size}", "tokens": 77, "patch_feats": 13, "batches_in_flight": args.lanes,
@@ -731,7 +922,8 @@ def main():
                                     "f32x3": "gemm_f32_glds_kernel<SPLIT=3> (fp32 operands as three bf16 planes; peak = the six-product bf16 bound, 419.5 fp32-equivalent TFLOP/s)",
                                     "bf16": "gemm_bf16_glds_kernel (bf16 MFMA GEMM of the encoder blocks)",
                                     "fp8": "gemm_bf16_glds_kernel<FP8> (fp8 MFMA GEMM of the encoder blocks)",
-                                    "mx8": "gemm_mx8_kernel (block-scaled fp8 GEMM of the encoder blocks, v_mfma_scale_f32_32x32x64_f8f6f4)"}[precision],
+                                    "mx8": "gemm_mx8_kernel (block-scaled fp8 GEMM of the encoder blocks, v_mfma_scale_f32_32x32x64_f8f6f4)",
+                                    "mx8mlp": "gemm_mx8_kernel (block-scaled fp8 GEMMs of the MLP pair; QKV / out-proj run on gemm_bf16_glds_kernel)"}[precision],
                          "peak_basis": "nominal (MI355X_MICROARCH.md, 2.4 GHz).  Measured on this pool with operands in registers and random data "
                                        "(tools/probe/mfma_issue_probe.hip, bf16_issue_probe.hip, mx_issue_probe.hip; profiles/r04_*_issue_probe.txt): the "
                                        "MFMA stream itself delivers 140-156 TFLOP/s fp32 (~2.04 GHz held inside the GEMM), 1.9-2.0 PFLOP/s bf16 and "
@@ -758,10 +950,13 @@ def main():
             "encoder_bf16": bf16_info,
             "encoder_fp8": fp8_info,
             "encoder_mx8": mx8_info,
+            "encoder_mx8mlp": mx8mlp_info,
+            "reduced_modes": quality,
             "encoder_precision": precision,
             "accuracy_vs_fp32_encoder": accuracy,
             "sharded_merge": sharded_info,
             "attention": {"achieved_tflops": attn_tflops, "ms_per_step": st["attn_ms"] / prof_steps},
+            "harness": harness_info,
             "lookup_variant": None if lookup_qps is None else {"value": lookup_qps * world, "unit": "queries/sec",
                                "note": "reference-faithful query path (test_fiq.py:104-107): reference features looked up in the index, "
                                        f"no per-query image encode; {args.lanes} batches in flight like the headline"},

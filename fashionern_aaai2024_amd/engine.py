@@ -21,8 +21,8 @@ COMBINER_TARGET, COMBINER_DVR_GLOBAL, COMBINER_DVR_LOCAL, COMBINER_DVR_FINAL = 0
 SR_TARGET, SR_DVR = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
 PART_DVR, PART_TARGET_SR, PART_TARGET_COMBINER, PART_ALL = 1, 2, 4, 7
-PREC_FP32, PREC_BF16, PREC_FP8, PREC_MX8, PREC_F32X3 = 0, 1, 2, 3, 4
-_PREC_NAMES = {"fp32": PREC_FP32, "bf16": PREC_BF16, "fp8": PREC_FP8, "mx8": PREC_MX8, "f32x3": PREC_F32X3}
+PREC_FP32, PREC_BF16, PREC_FP8, PREC_MX8, PREC_F32X3, PREC_MX8_MLP = 0, 1, 2, 3, 4, 5
+_PREC_NAMES = {"fp32": PREC_FP32, "bf16": PREC_BF16, "fp8": PREC_FP8, "mx8": PREC_MX8, "f32x3": PREC_F32X3, "mx8mlp": PREC_MX8_MLP}
 PATCH_NUM = 13
 
 
@@ -106,6 +106,13 @@ class FernEngine:
         return {v: k for k, v in _PREC_NAMES.items()}[self.lib.fern_get_precision(self._h)]
 
     def close(self):
+        pipe = getattr(self, "_harness_pipe", None)      # forks of this context (run/_common.py keeps a query pipeline here) go first
+        if pipe is not None:
+            self._harness_pipe = None
+            try:
+                pipe.close()
+            except Exception:
+                pass
         if getattr(self, "_h", None):
             self.lib.fern_ctx_destroy(self._h)
             self._h = None

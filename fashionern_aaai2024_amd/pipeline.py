@@ -43,6 +43,19 @@ class QueryResult:
         return self.scores, self.idx
 
 
+class FusedResult:
+    """Fused query features of one `submit_fuse` batch; valid on the caller's stream after `wait()`."""
+
+    def __init__(self, fused: torch.Tensor, event: torch.cuda.Event, keep):
+        self.fused, self._event, self._keep = fused, event, keep
+
+    def wait(self) -> torch.Tensor:
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self._event)
+        self.fused.record_stream(cur)
+        return self.fused
+
+
 class _LaneGraph:
     """One captured step of one lane: static input buffers, the hipGraph, the tensors it writes."""
 
@@ -112,6 +125,30 @@ class ComposedQueryPipeline:
             ev.record(stream)
         fused, scores, idx, member_scores = outs
         return QueryResult(scores, idx, fused, ev, member_scores, ev0)
+
+    def submit_fuse(self, tokens: torch.Tensor, local: torch.Tensor, ref_rows: torch.Tensor, index_features: torch.Tensor) -> "FusedResult":
+        """The query loop of the reference harness as ONE lane job (run/test/test_fiq.py:98-118): tokens [B,77] int64 and local
+        [B,13,D] as the DataLoader / tokenizer leave them -- HOST tensors (pinned ones upload asynchronously) or device tensors --,
+        `ref_rows` [B] int64 = the gallery rows of the reference images, whose RAW features are looked up in `index_features`
+        (test_fiq.py:104-107); text tower (one pass for global + seq) + `mode="test"` fusion -> fused [B,D].  Uploads, lookup and
+        kernels all go to the lane's stream: batch i + 1 is tokenised / uploaded by the host while batch i's kernels run, and
+        consecutive batches overlap on the lanes.  No synchronisation; `FusedResult.wait()` orders the caller's stream behind it."""
+        lane = self._next
+        self._next = (self._next + 1) % len(self.engines)
+        eng, stream = self.engines[lane], self.streams[lane]
+        stream.wait_stream(torch.cuda.current_stream())
+        keep = (tokens, local, ref_rows)                              # host staging buffers must outlive their asynchronous copies
+        with torch.cuda.stream(stream):
+            dev = eng.device
+            tk = tokens.to(dev, non_blocking=True)
+            lc = local.to(dev, dtype=torch.float32, non_blocking=True)
+            rows = ref_rows.to(index_features.device, non_blocking=True)
+            ref = index_features[rows].to(dev)
+            tg, ts = eng.encode_text(tk)
+            fused = eng.dvr_fuse(ref, lc, tg, ts)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return FusedResult(fused, ev, keep)
 
     @staticmethod
     def _step(eng, args, gallery, k, idx_offset):

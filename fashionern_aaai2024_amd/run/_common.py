@@ -58,6 +58,14 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
     loader = DataLoader(dataset=relative_val_dataset, batch_size=batch_size, num_workers=num_workers,
                         pin_memory=(device.type == "cuda"), collate_fn=collate_fn, shuffle=False)
     name_to_row = {n: i for i, n in enumerate(index_names)}      # duplicates: last row wins, like dict(zip(...)) (:88)
+    # The HIP encoder + fusion on one engine: the loop below keeps its reference shape (same batches, same arithmetic, bit-identical
+    # features) but every batch is ONE asynchronous lane job of a ComposedQueryPipeline -- uploads, the RAW reference-feature
+    # lookup, one text-tower pass (the reference's two encode_text calls) and mode="test" -- so the host tokenises batch i + 1 while
+    # batch i's kernels run and consecutive batches overlap on three streams; the only wait is at the end of the loop.
+    # FERN_HARNESS_LANES=0 keeps the plain call-by-call loop (any clip_model / model objects take that path anyway).
+    pipe = _query_pipeline(clip_model, model, device)
+    pipe_box = [pipe]
+    pending = []
     predicted: List[torch.Tensor] = []
     target_names: List[str] = []
     reference_names: List[str] = []
@@ -77,6 +85,18 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
         else:
             raise ValueError(kind)
         text_inputs = tokenizer(list(captions), context_length=77)
+        if pipe is not None:
+            if not text_inputs.is_cuda and text_inputs.numel() and (int(text_inputs.min()) < 0 or int(text_inputs.max()) >= clip_model.cfg.vocab_size):
+                raise IndexError(f"token id out of range [0, {clip_model.cfg.vocab_size})")      # nn.Embedding's error in the reference
+            rows = torch.tensor([name_to_row[n] for n in ref_names], dtype=torch.int64)
+            if device.type == "cuda" and not text_inputs.is_cuda:
+                text_inputs, rows = text_inputs.pin_memory(), rows.pin_memory()
+            pending.append(_submit_fuse(pipe_box, clip_model, model, device, text_inputs, ref_patch, rows, index_features))
+            target_names.extend(batch_targets)
+            reference_names.extend(ref_names)
+            if members is not None:
+                group_members.extend(members)
+            continue
         ref_patch = ref_patch.to(device)
         with torch.no_grad():
             visual_emb = ref_patch.transpose(0, 1)                                   # [13,B,D]  (:101)
@@ -91,6 +111,8 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
         reference_names.extend(ref_names)
         if members is not None:
             group_members.extend(members)
+    if pipe is not None:
+        predicted = [p.wait() for p in pending]
     pred = torch.cat(predicted, dim=0) if predicted else torch.empty((0, feature_dim), device=device)
     if world > 1:       # every rank returns all Q predictions in dataset order, like the single-process loop
         per_row = [(t, r, group_members[i] if group_members else None) for i, (t, r) in enumerate(zip(target_names, reference_names))]
@@ -98,6 +120,41 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
         target_names, reference_names = [p[0] for p in per_row], [p[1] for p in per_row]
         group_members = [p[2] for p in per_row] if any(p[2] is not None for p in per_row) else []
     return {"predicted": pred, "targets": target_names, "references": reference_names, "members": group_members}
+
+
+def _query_pipeline(clip_model, model, device):
+    """A 3-lane ComposedQueryPipeline when the encoder and the fusion model are the HIP ones on ONE engine on a GPU, else None."""
+    import os
+    from ..clip_model import FernCLIP
+    from ..engine import FernEngine
+    lanes = int(os.environ.get("FERN_HARNESS_LANES", "3"))
+    eng = getattr(model, "engine", None)
+    if lanes < 1 or not isinstance(clip_model, FernCLIP) or not isinstance(eng, FernEngine) or clip_model.engine is not eng or device.type != "cuda":
+        return None
+    from ..pipeline import ComposedQueryPipeline
+    # kept on the engine across calls (the reference's drivers evaluate category after category, test_fiq.py:176-190): forked
+    # contexts allocate their workspaces on first use, which is worth paying once
+    pipe = getattr(eng, "_harness_pipe", None)
+    if pipe is None or len(pipe.engines) != lanes:
+        if pipe is not None:
+            pipe.close()
+        pipe = eng._harness_pipe = ComposedQueryPipeline(eng, lanes=lanes)
+    return pipe
+
+
+def _submit_fuse(pipe_box, clip_model, model, device, *args):
+    """submit_fuse, rebuilding the cached pipeline once if its forks went stale (the weights were re-loaded since it was made)."""
+    from .._lib import FernError
+    try:
+        return pipe_box[0].submit_fuse(*args)
+    except FernError as e:
+        if "stale" not in str(e):
+            raise
+        eng = model.engine
+        eng._harness_pipe.close()
+        eng._harness_pipe = None
+        pipe_box[0] = _query_pipeline(clip_model, model, device)
+        return pipe_box[0].submit_fuse(*args)
 
 
 def fuse_index(model, index_features, index_local_features):

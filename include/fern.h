@@ -100,7 +100,10 @@ typedef enum {
      * sequential fp32 fma chain, so results are fp32-accurate but not bit-identical to FERN_PREC_FP32 (they are bit-identical across
      * tile shapes and batch sizes).  The ranking stage never uses it: fern_sim_topk* scores stay the exact chain.  No reference
      * counterpart (cuBLAS's own TF32x3-style modes are the closest relative). */
-    FERN_PREC_F32X3 = 4
+    FERN_PREC_F32X3 = 4,
+    /* MX8 for the MLP pair only (c_fc + c_proj: two thirds of a block's GEMM flops), BF16 for LayerNorm-1 / QKV / attention / out-proj,
+     * fp32 residual stream: half of MX8's fp8 rounding points at roughly the middle of the two modes' speed (bench.py `reduced_modes`). */
+    FERN_PREC_MX8_MLP = 5
 } fern_precision;
 
 typedef enum {

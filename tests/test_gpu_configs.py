@@ -322,7 +322,30 @@ def test_bf16_sweep_exact_ties_and_one_million_rows():
     assert (got - s_c[:4]).abs().max().item() < 2e-6
 
 
-@pytest.mark.parametrize("precision", ["fp8", "mx8"])
+def test_mx8mlp_sits_between_bf16_and_mx8():
+    """FERN_PREC_MX8_MLP (round 5): MX8 for the MLP pair, bf16 for LayerNorm-1 / QKV / attention / out-proj, fp32 residual stream.
+    Half of MX8's fp8 rounding points: its features must be closer to the fp32 mode's than MX8's are, and not closer than bf16's."""
+    cfg = synth.CLIP_CONFIGS["ViT-B-16"]
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(synth.clip_state_dict(cfg, seed=3))
+    eng.finalize_clip(cfg)
+    imgs = torch.from_numpy(synth.images(8, cfg, 5))
+    toks = torch.from_numpy(synth.captions(8, cfg, 5))
+    f32 = eng.encode_image(imgs), eng.encode_text(toks)[0]
+    err = {}
+    for prec in ("bf16", "mx8mlp", "mx8"):
+        eng.set_precision(prec)
+        assert eng.precision == prec
+        fi, ft = eng.encode_image(imgs), eng.encode_text(toks)[0]
+        assert torch.isfinite(fi).all() and torch.isfinite(ft).all()
+        err[prec] = ((1 - F.cosine_similarity(fi, f32[0], dim=-1)).mean().item(), (1 - F.cosine_similarity(ft, f32[1], dim=-1)).mean().item())
+    for tower in (0, 1):
+        assert err["bf16"][tower] <= err["mx8mlp"][tower] < err["mx8"][tower], err
+    assert err["mx8mlp"][0] < 5e-3 and err["mx8mlp"][1] < 5e-3, err
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["fp8", "mx8", "mx8mlp"])
 def test_c5_fp8_encoder_with_bf16_similarity_end_to_end(precision):
     """BASELINE configs[4] as one path on one GPU's share: ViT-B/16 towers in an fp8 mode -- "fp8" (per-row scales) and "mx8"
     (block-scaled, the precision `bench.py --config c5` times: VERDICT r3 item 1b) -> fusion -> 1M-row bf16 gallery sweep + top-50
@@ -364,11 +387,11 @@ def test_c5_fp8_encoder_with_bf16_similarity_end_to_end(precision):
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp8", "mx8"])
+@pytest.mark.parametrize("precision", ["bf16", "fp8", "mx8", "mx8mlp"])
 def test_full_step_is_hipgraph_capturable_in_reduced_precision(precision):
     """encode -> fuse -> rank of the tiny towers in a reduced-precision mode: after a warm-up call (workspaces, bf16 / fp8 / mx8
     tile tuning) the whole step only enqueues kernels and replays from a hipGraph with identical results."""
-    cfg = synth.CLIP_CONFIGS["tiny-w256" if precision == "mx8" else "tiny-hd64"]
+    cfg = synth.CLIP_CONFIGS["tiny-w256" if precision in ("mx8", "mx8mlp") else "tiny-hd64"]
     d = cfg.embed_dim
     eng = FernEngine("cuda:0")
     eng.load_tensors(synth.clip_state_dict(cfg, seed=2))
