@@ -437,8 +437,10 @@ def harness_leg(torch, eng, clip, model, cfg, D, device, n_gal, lookup_qps, enc_
             best = dt if best is None or dt < best else best
         return best, val
 
-    t_pred, _ = timed(lambda: generate_fiq_val_predictions(clip, rel, model, index_names, index_features, device, D, 64, 0, "bench-clip-bpe"))
-    t_full, rec = timed(lambda: compute_fiq_val_metrics(rel, clip, index_features, index_local, index_names, model, device, D, 64, 0, "bench-clip-bpe"))
+    nw = 4                                            # the reference driver's default (run/test/test_fiq.py:131)
+    out["num_workers"] = nw
+    t_pred, _ = timed(lambda: generate_fiq_val_predictions(clip, rel, model, index_names, index_features, device, D, 64, nw, "bench-clip-bpe"))
+    t_full, rec = timed(lambda: compute_fiq_val_metrics(rel, clip, index_features, index_local, index_names, model, device, D, 64, nw, "bench-clip-bpe"))
     out["generate_fiq_val_predictions"] = {"wall_s": t_pred, "queries_per_s": queries / t_pred,
                                            "note": "the query loop alone (host batches -> tokenise -> upload -> lookup -> text tower -> mode=test): "
                                                    "the figure comparable with the engine's `lookup_variant`"}
@@ -447,7 +449,7 @@ def harness_leg(torch, eng, clip, model, cfg, D, device, n_gal, lookup_qps, enc_
     out["engine_lookup_variant_queries_per_s"] = lookup_qps
     out["predictions_vs_engine_lookup"] = (queries / t_pred) / lookup_qps if lookup_qps else None
     os.environ["FERN_HARNESS_LANES"] = "0"
-    t_serial, _ = timed(lambda: generate_fiq_val_predictions(clip, rel, model, index_names, index_features, device, D, 64, 0, "bench-clip-bpe"), reps=1)
+    t_serial, _ = timed(lambda: generate_fiq_val_predictions(clip, rel, model, index_names, index_features, device, D, 64, nw, "bench-clip-bpe"), reps=1)
     os.environ.pop("FERN_HARNESS_LANES")
     out["generate_fiq_val_predictions_call_by_call"] = {"wall_s": t_serial, "queries_per_s": queries / t_serial,
                                                         "note": "FERN_HARNESS_LANES=0: the round-4 loop (one stream, two encode_text calls served by one pass)"}

@@ -29,7 +29,7 @@ from torch.utils.data import DataLoader, Subset
 
 from .. import distributed as fd
 from ..tokenizer import get_tokenizer
-from ..utils import collate_fn
+from ..utils import collate_fn, host_threads
 
 TOPK = 50
 
@@ -70,7 +70,7 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
     target_names: List[str] = []
     reference_names: List[str] = []
     group_members: List[List[str]] = []
-    for batch in loader:
+    def parse(batch):
         members = None
         if kind in ("fiq", "val"):
             ref_names, batch_targets, captions, ref_patch = batch
@@ -84,33 +84,79 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
             _, ref_names, captions, batch_targets, _, ref_patch = batch              # test_200k.py:89
         else:
             raise ValueError(kind)
-        text_inputs = tokenizer(list(captions), context_length=77)
+        return ref_names, batch_targets, captions, ref_patch, members
+
+    def prepared_batches():
+        """Fast path: everything the host does per batch BEFORE the engine sees it -- DataLoader iteration, caption formatting,
+        tokenising, the name -> row lookup, pinning -- runs in a producer thread, a few batches ahead of the consumer (the main
+        thread spends its time inside libfern calls, which release the GIL)."""
+        import queue
+        import threading
+        q: "queue.Queue" = queue.Queue(maxsize=6)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for batch in loader:
+                    ref_names, batch_targets, captions, ref_patch, members = parse(batch)
+                    text_inputs = tokenizer(list(captions), context_length=77)
+                    if not text_inputs.is_cuda and text_inputs.numel() and (int(text_inputs.min()) < 0 or int(text_inputs.max()) >= clip_model.cfg.vocab_size):
+                        raise IndexError(f"token id out of range [0, {clip_model.cfg.vocab_size})")      # nn.Embedding's error in the reference
+                    rows = torch.tensor([name_to_row[n] for n in ref_names], dtype=torch.int64)
+                    if device.type == "cuda" and not text_inputs.is_cuda:
+                        text_inputs, rows = text_inputs.pin_memory(), rows.pin_memory()
+                    item = (ref_names, batch_targets, members, text_inputs, ref_patch, rows)
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                q.put(None)
+            except BaseException as e:      # noqa: BLE001 -- handed to the consumer, which re-raises it
+                q.put(e)
+
+        t = threading.Thread(target=produce, name="fern-harness-producer", daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+
+    with host_threads():
         if pipe is not None:
-            if not text_inputs.is_cuda and text_inputs.numel() and (int(text_inputs.min()) < 0 or int(text_inputs.max()) >= clip_model.cfg.vocab_size):
-                raise IndexError(f"token id out of range [0, {clip_model.cfg.vocab_size})")      # nn.Embedding's error in the reference
-            rows = torch.tensor([name_to_row[n] for n in ref_names], dtype=torch.int64)
-            if device.type == "cuda" and not text_inputs.is_cuda:
-                text_inputs, rows = text_inputs.pin_memory(), rows.pin_memory()
-            pending.append(_submit_fuse(pipe_box, clip_model, model, device, text_inputs, ref_patch, rows, index_features))
-            target_names.extend(batch_targets)
-            reference_names.extend(ref_names)
-            if members is not None:
-                group_members.extend(members)
-            continue
-        ref_patch = ref_patch.to(device)
-        with torch.no_grad():
-            visual_emb = ref_patch.transpose(0, 1)                                   # [13,B,D]  (:101)
-            text_features, _ = clip_model.encode_text(text_inputs, visual_emb=visual_emb)              # :102
-            text_seq = clip_model.encode_text(text_inputs, mode="seq", visual_emb=visual_emb)          # :103
-            rows = torch.as_tensor([name_to_row[n] for n in ref_names], device=index_features.device)
-            ref_feats = index_features[rows]                                         # RAW gallery features (:104-107)
-            fused = model(ref_feats=ref_feats.to(device), ref_local_feats=ref_patch, text_feats=text_features.to(device),
-                          text_seq_feats=text_seq.to(device), mode="test")           # :112-118
-        predicted.append(fused)
-        target_names.extend(batch_targets)
-        reference_names.extend(ref_names)
-        if members is not None:
-            group_members.extend(members)
+            for ref_names, batch_targets, members, text_inputs, ref_patch, rows in prepared_batches():
+                pending.append(_submit_fuse(pipe_box, clip_model, model, device, text_inputs, ref_patch, rows, index_features))
+                target_names.extend(batch_targets)
+                reference_names.extend(ref_names)
+                if members is not None:
+                    group_members.extend(members)
+        else:
+            for batch in loader:
+                ref_names, batch_targets, captions, ref_patch, members = parse(batch)
+                text_inputs = tokenizer(list(captions), context_length=77)
+                ref_patch = ref_patch.to(device)
+                with torch.no_grad():
+                    visual_emb = ref_patch.transpose(0, 1)                                   # [13,B,D]  (:101)
+                    text_features, _ = clip_model.encode_text(text_inputs, visual_emb=visual_emb)              # :102
+                    text_seq = clip_model.encode_text(text_inputs, mode="seq", visual_emb=visual_emb)          # :103
+                    rows = torch.as_tensor([name_to_row[n] for n in ref_names], device=index_features.device)
+                    ref_feats = index_features[rows]                                         # RAW gallery features (:104-107)
+                    fused = model(ref_feats=ref_feats.to(device), ref_local_feats=ref_patch, text_feats=text_features.to(device),
+                                  text_seq_feats=text_seq.to(device), mode="test")           # :112-118
+                predicted.append(fused)
+                target_names.extend(batch_targets)
+                reference_names.extend(ref_names)
+                if members is not None:
+                    group_members.extend(members)
     if pipe is not None:
         predicted = [p.wait() for p in pending]
     pred = torch.cat(predicted, dim=0) if predicted else torch.empty((0, feature_dim), device=device)
