@@ -29,7 +29,7 @@ from torch.utils.data import DataLoader, Subset
 
 from .. import distributed as fd
 from ..tokenizer import get_tokenizer
-from ..utils import collate_fn, host_threads
+from ..utils import collate_fn, host_threads, make_loader
 
 TOPK = 50
 
@@ -55,8 +55,7 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
     if world > 1:       # query data parallel: this rank's contiguous slice of the queries
         q_start, q_stop, _ = fd.shard_rows(len(relative_val_dataset), rank, world)
         relative_val_dataset = Subset(relative_val_dataset, range(q_start, q_stop))
-    loader = DataLoader(dataset=relative_val_dataset, batch_size=batch_size, num_workers=num_workers,
-                        pin_memory=(device.type == "cuda"), collate_fn=collate_fn, shuffle=False)
+    loader = make_loader(relative_val_dataset, batch_size, num_workers, device, collate_fn)
     name_to_row = {n: i for i, n in enumerate(index_names)}      # duplicates: last row wins, like dict(zip(...)) (:88)
     # The HIP encoder + fusion on one engine: the loop below keeps its reference shape (same batches, same arithmetic, bit-identical
     # features) but every batch is ONE asynchronous lane job of a ComposedQueryPipeline -- uploads, the RAW reference-feature

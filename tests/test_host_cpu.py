@@ -166,6 +166,38 @@ def test_standalone_modules_take_unprefixed_reference_keys():
     assert DVR_module(d, engine=OracleEngine()).load_state_dict(no_cls).missing_keys == []
 
 
+def test_threaded_loader_yields_the_dataloaders_batches_in_order():
+    """utils.ThreadedLoader stands in for the reference's forked DataLoader workers next to the GPU path (a forked child of a process
+    that owns a ROCm context makes every kernel launch of the parent ~40x slower): same batches, same order, ragged tail, None
+    items dropped by collate_fn, an exception inside a worker surfaces in the consumer."""
+    from fashionern_aaai2024_amd.utils import ThreadedLoader, make_loader
+    g = sdata.Gallery(101, 32, 3)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 101
+
+        def __getitem__(self, i):
+            if i == 40:
+                return None
+            return g.names[i], torch.from_numpy(g.images[i]), torch.from_numpy(g.local[i])
+
+    a = list(ThreadedLoader(DS(), 16, 4, collate_fn, False))
+    b = list(torch.utils.data.DataLoader(DS(), batch_size=16, collate_fn=collate_fn))
+    assert len(a) == len(b) == 7 and [len(x[0]) for x in a] == [16, 16, 15, 16, 16, 16, 5]
+    assert all(list(x[0]) == list(y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2]) for x, y in zip(a, b))
+    assert isinstance(make_loader(DS(), 16, 4, "cpu", collate_fn), torch.utils.data.DataLoader)      # CPU consumers keep the DataLoader
+
+    class Bad(DS):
+        def __getitem__(self, i):
+            if i == 70:
+                raise OSError("unreadable item")
+            return super().__getitem__(i)
+
+    with pytest.raises(OSError, match="unreadable item"):
+        list(ThreadedLoader(Bad(), 16, 4, collate_fn, False))
+
+
 def test_collate_fn_drops_none_and_tokenizer_registry():
     batch = [("a", torch.zeros(2)), None, ("b", torch.ones(2))]
     names, t = collate_fn(batch)
