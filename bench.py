@@ -843,6 +843,7 @@ def main():
     enc_ips = lookup_qps = None
     big_roof = None
     harness_info = None
+    pcie_info = None
     if secondary:
         im, tk, lc = batches[0]
         torch.cuda.synchronize()
@@ -869,6 +870,50 @@ def main():
         pipe.synchronize()
         torch.cuda.synchronize()
         lookup_qps = B * args.steps / (time.perf_counter() - t0)
+
+        # PCIe-inclusive rate (measured, not the 3 % estimate): the step's inputs start in PINNED HOST memory --
+        # 38.5 MB of images, tokens, 1.7 MB of patch features per batch -- and are copied by a dedicated stream into rotating device
+        # staging buffers while earlier batches compute; `value` of the main line keeps its inputs resident in HBM
+        host_batches = [tuple(t.cpu().pin_memory() for t in bt) for bt in batches]
+        n_sets = 2 * args.lanes
+        staging = [tuple(torch.empty_like(t) for t in batches[0]) for _ in range(n_sets)]
+        set_done = [None] * n_sets
+        copy_stream = torch.cuda.Stream(device=device)
+        pc = [0]
+
+        def step_pcie():
+            j = pc[0] % n_sets
+            src = host_batches[pc[0] % n_batches]
+            pc[0] += 1
+            with torch.cuda.stream(copy_stream):
+                if set_done[j] is not None:
+                    copy_stream.wait_event(set_done[j])          # the batch that last used this staging set has been consumed
+                for dst, hs in zip(staging[j], src):
+                    dst.copy_(hs, non_blocking=True)
+                up = torch.cuda.Event()
+                up.record(copy_stream)
+            torch.cuda.current_stream().wait_event(up)
+            r = pipe.submit(*staging[j], gallery, K)
+            set_done[j] = r.done_event
+            return r
+
+        for _ in range(2 * n_sets):
+            step_pcie()
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_pcie()
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        pcie_s = time.perf_counter() - t0
+        in_bytes = sum(t.numel() * t.element_size() for t in host_batches[0])
+        pcie_info = {"value": B * args.steps / pcie_s, "unit": "queries/sec", "ms_per_step": pcie_s / args.steps * 1e3,
+                     "host_to_device_bytes_per_step": in_bytes, "host_to_device_GBs": in_bytes * args.steps / pcie_s / 1e9,
+                     "vs_resident_inputs": (B * args.steps / pcie_s) / value,
+                     "note": "inputs in pinned host memory, uploaded per step by a dedicated copy stream into rotating staging buffers "
+                             f"({n_sets} sets), {args.lanes} batches in flight; one GPU's share"}
+        del staging, host_batches
 
         # HBM-bound form of the ranking stage (BASELINE config 5 "bf16 similarity"): 1M-row bf16 gallery, 64 queries
         big_n = 1_000_000
@@ -959,6 +1004,7 @@ def main():
             "sharded_merge": sharded_info,
             "attention": {"achieved_tflops": attn_tflops, "ms_per_step": st["attn_ms"] / prof_steps},
             "harness": harness_info,
+            "pcie_inclusive": pcie_info,
             "lookup_variant": None if lookup_qps is None else {"value": lookup_qps * world, "unit": "queries/sec",
                                "note": "reference-faithful query path (test_fiq.py:104-107): reference features looked up in the index, "
                                        f"no per-query image encode; {args.lanes} batches in flight like the headline"},

@@ -31,25 +31,36 @@ def is_filter_gemm(name):      # gemm_f32_glds_kernel<BM, BN, WM, WN, BKT, MINW,
     return re.search(r"gemm_f32_glds_kernel<(\d+,\s*){6}(true|false),\s*\d+,\s*true\b", name) is not None
 
 
+RANK_KERNELS = ("sweep_bf16_kernel", "topk_sample_bound_kernel", "topk_candidates_kernel", "topk_rescore_kernel", "topk_dense_rescore_kernel",
+                "rank_exact_kernel")
+
+
 def summarise(rows, scale):
+    """Per family: dispatches and counter bytes.  Ranking stage = every kernel of fern_sim_topk / _prefiltered / _bf16 (the bf16 sweeps,
+    bound, select / rescore kernels, the gated exact pass; for the fp32-MFMA form also the sample GEMM in front of the bound kernel and
+    the filtered GEMM sweep); sweep = the full-gallery pass of each call (bf16 sweep in its filter / store-all form, or the filtered GEMM)."""
     rank_ids, sweep_ids = set(), set()
     for i, r in enumerate(rows):
-        if "topk_sample_bound_kernel" in r[1]:
+        name = r[1]
+        if any(k in name for k in RANK_KERNELS) or is_filter_gemm(name):
             rank_ids.add(r[0])
-            if i > 0 and "gemm_f32" in rows[i - 1][1]:
-                rank_ids.add(rows[i - 1][0])                      # the sample pass: the GEMM right before the bound kernel
-            seen = 0
-            for nxt in rows[i + 1:i + 6]:                          # filtered sweep, select, gated sweep, gated select
-                if is_filter_gemm(nxt[1]) or "topk_candidates_kernel" in nxt[1] or "rank_exact_kernel" in nxt[1]:
-                    rank_ids.add(nxt[0])
-                    if is_filter_gemm(nxt[1]) and seen == 0:
-                        sweep_ids.add(nxt[0])
-                        seen = 1
-    gemm = [r for r in rows if "gemm_f32" in r[1] and r[0] not in rank_ids]
+        if "topk_sample_bound_kernel" in name and i > 0 and "gemm_f32" in rows[i - 1][1]:
+            rank_ids.add(rows[i - 1][0])                          # fp32 form: the sample pass is the GEMM right before the bound kernel
+        if is_filter_gemm(name):
+            sweep_ids.add(r[0])
+        if "sweep_bf16_kernel" in name:
+            # the full pass of a call: the filter form, or the store-all form (the dense pre-filter: followed by topk_dense_rescore_kernel)
+            nxt = rows[i + 1][1] if i + 1 < len(rows) else ""
+            if re.search(r"sweep_bf16_kernel<\d+,\s*true", name) or "topk_dense_rescore_kernel" in nxt or "sweep_bf16_kernel" in nxt:
+                sweep_ids.add(r[0])
+    fam = lambda key: [r for r in rows if key in r[1] and r[0] not in rank_ids]  # noqa: E731
+    gemm, mx8, b16 = fam("gemm_f32"), fam("gemm_mx8_kernel"), fam("gemm_bf16_glds_kernel")
     rank = [r for r in rows if r[0] in rank_ids]
     sweep = [r for r in rows if r[0] in sweep_ids]
+    calls = sum(1 for r in rows if "rank_exact_kernel" in r[1])   # one gated exact-pass launch closes every ranking call
     tot = lambda rs: sum(r[4] for r in rs) * 1024 * scale  # noqa: E731
-    return {"gemm_launches": len(gemm), "gemm_bytes": tot(gemm), "rank_calls": len(sweep), "rank_bytes": tot(rank), "sweep_bytes": tot(sweep)}
+    return {"gemm_launches": len(gemm), "gemm_bytes": tot(gemm), "mx8_launches": len(mx8), "mx8_bytes": tot(mx8), "bf16_launches": len(b16),
+            "bf16_bytes": tot(b16), "rank_calls": calls, "rank_bytes": tot(rank), "sweep_bytes": tot(sweep)}
 
 
 def main():
@@ -71,13 +82,19 @@ def main():
                   "stage_write_bytes_per_call": write["rank_bytes"] / max(1, write["rank_calls"]),
                   "sweep_kernel_fetch_bytes": fetch["sweep_bytes"] / calls,
                   "sweep_kernel_write_bytes": write["sweep_bytes"] / max(1, write["rank_calls"]),
-                  "note": "stage = sample GEMM + bound + filtered sweep + candidate select + gated exact pass of one fern_sim_topk call; the "
-                          "[B, N] score matrix (B*N*4 bytes) is never written: the stage's writes are the sample scores, the surviving "
-                          "candidates and the [B, K] result"},
+                  "note": "stage = every kernel of one ranking call (fern_sim_topk_prefiltered on a prepared fp32 gallery: bf16 sweep + "
+                          "select / rescore + gated exact pass; the dense form stores its [B, N] approximate scores, the list forms only "
+                          "sample scores and candidates)"},
         "note": "FETCH_SIZE counts L2->fabric read requests (Infinity-Cache hits included), i.e. the sum over the 8 private XCD L2s: every XCD "
                 "streams the weight panels of its tiles once per generation of resident tiles, so for the GEMM family this is L2-miss traffic "
                 "(largely served by the 256 MiB Infinity Cache), not DRAM traffic.",
     }
+    for fam_key, name in (("mx8", "gemm_mx8"), ("bf16", "gemm_bf16")):
+        if fetch[fam_key + "_launches"]:
+            n = fetch[fam_key + "_launches"]
+            out[name] = {"launches_per_step": n / steps, "fetch_bytes_per_launch": fetch[fam_key + "_bytes"] / n,
+                         "write_bytes_per_launch": write[fam_key + "_bytes"] / max(1, write[fam_key + "_launches"])}
+            out[name]["hbm_bytes_per_launch"] = out[name]["fetch_bytes_per_launch"] + out[name]["write_bytes_per_launch"]
     out["gemm"]["hbm_bytes_per_launch"] = out["gemm"]["fetch_bytes_per_launch"] + out["gemm"]["write_bytes_per_launch"]
     out["sweep"]["hbm_bytes_per_launch"] = out["sweep"]["stage_fetch_bytes_per_call"] + out["sweep"]["stage_write_bytes_per_call"]
     print(json.dumps(out, indent=1))
