@@ -1729,7 +1729,9 @@ static int rank_strategy_for(const fern_ctx* c, int B, int64_t N, int D) {
     const long QBLK = (D == 64 || D == 128 || D == 256 || D == 512) ? 128 : 64;
     const double nblk = (double)((B + QBLK - 1) / QBLK), stream_us = (double)N * D * 2 / 4.5e6;      // one bf16 pass at ~4.5 TB/s
     const double plain = 38.0 + 2.0 * B * (double)N * D / 95e6;                                        // launches + fp32 MFMA at ~95 TFLOP/s (skinny M)
-    const double dense = nblk * (std::max(17.0, stream_us + 8.0) + (double)std::min<long>(B, QBLK) * N * 4 / 3e6) + 18.0 * ((B + 255) / 256) + 5.0;
+    // dense: the sweep also writes its [B, N] scores, and the select kernel streams a query's row twice with ONE workgroup (~60 GB/s)
+    const double dense = nblk * (std::max(17.0, stream_us + 8.0) + (double)std::min<long>(B, QBLK) * N * 4 / 3e6) +
+                         ((B + 255) / 256) * (14.0 + (double)N * 8 / 6e4) + 5.0;
     const double lists = nblk * (14.0 + std::max(17.0, stream_us + 8.0)) + 8.0 + 16.0 * ((B + 255) / 256) + 5.0;
     int best = FERN_RANK_PLAIN;
     double t = plain;

@@ -608,6 +608,7 @@ __device__ __forceinline__ void rescore_and_rank(const unsigned* surv, int ns, c
     for (int s0 = wave * RESC_ROWS; s0 < ns; s0 += 4 * RESC_ROWS) {
         float acc;
         if (nsteps % 8 == 0) acc = rescore_rows<8>(surv, s0, ns, qrow, gallery, D, tl);
+        else if (nsteps % 10 == 0) acc = rescore_rows<10>(surv, s0, ns, qrow, gallery, D, tl);      // D = 640 (RN50x4): 20 steps, 40 loads in flight
         else if (nsteps % 4 == 0) acc = rescore_rows<4>(surv, s0, ns, qrow, gallery, D, tl);
         else acc = rescore_rows<2>(surv, s0, ns, qrow, gallery, D, tl);
         if (lane < RESC_ROWS && s0 + lane < ns) x_key[s0 + lane] = make_key(acc, surv[s0 + lane]);

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long sweeps (forced tile variants, one child process each): still part of `-m gpu`, but run LAST")
 
 
 def _have_gpu() -> bool:
@@ -21,6 +22,7 @@ def _have_gpu() -> bool:
 
 
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda it: 1 if "slow" in it.keywords else 0)      # stable: everything else keeps its order, the sweeps go last
     if _have_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
