@@ -65,9 +65,11 @@ def check_sorted_and_consistent(eng, q, g, s, i):
     assert (gs - s_c).abs().max().item() < 1e-5
 
 
-def test_c1_rn50x4_shape_fusion_and_rank():
+@pytest.mark.parametrize("precision", ["fp32", "f32x3"])
+def test_c1_rn50x4_shape_fusion_and_rank(precision):
     d, n, b = 640, 1000, 32
     eng, sd = fused_engine(d)
+    eng.set_precision(precision)
     raw, loc = torch.from_numpy(synth.global_feats(n, d, tag="c1")), torch.from_numpy(synth.local_feats(n, d, tag="c1l"))
     gal = eng.index_fuse(raw, loc, normalize_input=True)
     ref = ofusion.index_fuse(sd, F.normalize(raw, dim=-1), loc)
@@ -83,6 +85,9 @@ def test_c1_rn50x4_shape_fusion_and_rank():
     full = qr @ ref.T
     for row, col in zip(*np.nonzero((i.cpu() != ri).numpy())):       # only near-ties of the oracle itself may swap
         assert abs(full[row, i[row, col].item()].item() - full[row, ri[row, col]].item()) < 1e-5
+    ps, pi = eng.sim_topk(q, eng.prepare_gallery(gal), 50)           # the prepared form (bf16 pre-filter + exact rescoring): same bits
+    assert torch.equal(ps, s) and torch.equal(pi, i)
+    eng.set_precision("fp32")
 
 
 def test_c2_full_size_sweep_properties():
@@ -101,11 +106,15 @@ def test_c2_full_size_sweep_properties():
     assert_same_order_up_to_near_ties(q.cpu(), g.cpu(), i.cpu(), ri)
     cs, ci = chain.chain_topk(q.cpu().numpy(), g.cpu().numpy(), 50)        # the sweep's own summation order: no tolerance at all
     assert np.array_equal(i.cpu().numpy(), ci) and np.array_equal(s.cpu().numpy().view(np.uint32), cs.view(np.uint32))
+    ps, pi = eng.sim_topk(q, eng.prepare_gallery(g), 50)                    # the stage bench.py times: prepared gallery, same bits
+    assert torch.equal(ps, s) and torch.equal(pi, i)
 
 
-def test_c3_sharded_200k_gallery_matches_unsharded():
+@pytest.mark.parametrize("precision", ["fp32", "f32x3"])
+def test_c3_sharded_200k_gallery_matches_unsharded(precision):
     d, n, world = 640, 200_000, 8
     eng, sd = fused_engine(d)
+    eng.set_precision(precision)
     raw = torch.from_numpy(synth.global_feats(n, d, tag="c3")).cuda()
     loc = torch.from_numpy(synth.local_feats(25_000, d, tag="c3l")).cuda().repeat(8, 1, 1)   # 6.6 GB of local feats: reuse a 25k block
     full = eng.index_fuse(raw, loc, normalize_input=True)
@@ -122,6 +131,11 @@ def test_c3_sharded_200k_gallery_matches_unsharded():
     parts = [eng.sim_topk(q, shards[r], 50, idx_offset=r * per) for r in range(world)]
     ms, mi = eng.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     assert torch.equal(mi, i) and torch.equal(ms, s), "sharded ranking + merge must equal the single-GPU ranking"
+    ps, pi = eng.sim_topk(q, eng.prepare_gallery(full), 50)
+    assert torch.equal(ps, s) and torch.equal(pi, i), "prepared gallery (candidate-list form at this size) must rank identically"
+    pparts = [eng.sim_topk(q, eng.prepare_gallery(shards[r]), 50, idx_offset=r * per) for r in range(world)]
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(parts, pparts)), "prepared shards (dense form) likewise"
+    eng.set_precision("fp32")
 
 
 def test_c4_cirr_1024_queries_subset_and_global():
@@ -152,6 +166,11 @@ def test_c4_cirr_1024_queries_subset_and_global():
     order = np.argsort(-full, axis=1, kind="stable")[:, :k]
     assert np.array_equal(i[sub].cpu().numpy(), order.astype(np.int32))
     assert np.array_equal(s[sub].cpu().numpy().view(np.uint32), np.take_along_axis(full, order, axis=1).view(np.uint32))
+    pg = eng.prepare_gallery(g)                                               # prepared form, both the 1024-query and the per-GPU 128-query shape
+    for lo, hi in ((0, b), (128, 256)):
+        ps, pi = eng.sim_topk(q[lo:hi], pg, k, exclude_idx=ref_idx[lo:hi])
+        assert torch.equal(ps, s[lo:hi]) and torch.equal(pi, i[lo:hi])
+    assert torch.equal(eng.gather_scores(q, pg, members).cpu(), ms)
 
 
 def test_c5_one_million_row_gallery():

@@ -50,8 +50,11 @@ def build(kind, engine=None, device=DEV, precision="fp32"):
 @pytest.mark.parametrize("kind,fn", [("fiq", test_fiq.compute_fiq_val_metrics), ("cirr", test_cirr.compute_cirr_val_metrics),
                                      ("200k", test_200k.compute_200k_val_metrics), ("shoes", test_shoes.compute_shoes_val_metrics),
                                      ("val", test_val.compute_fiq_val_metrics)])
-def test_harness_on_hip_reproduces_reference_recalls(kind, fn):
-    clip, model, rel, feats, names, local, d = build(kind)
+@pytest.mark.parametrize("precision", PARITY_PRECISIONS)
+def test_harness_on_hip_reproduces_reference_recalls(kind, fn, precision):
+    """The recall tuples of the imported reference run (tests/golden/harness.json), in both arithmetic modes that claim north_star's
+    parity contract: the exact fp32 chain and f32x3."""
+    clip, model, rel, feats, names, local, d = build(kind, precision=precision)
     res = fn(rel, clip, feats, local, names, model, DEV, d, META["batch_size"], 0, "stub")
     assert list(res) == META["recalls"][kind], (res, META["recalls"][kind])
 
