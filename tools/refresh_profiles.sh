@@ -4,7 +4,7 @@
 # rocprofv3 needs the program itself after `--` (python3 ...), TMPDIR on /tmp, and --pmc in passes of its own; every profiled
 # command runs under `timeout` (a profiler hang must not eat the GPU budget).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh
 mkdir -p $O
@@ -47,6 +47,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python3 $R/bench.py --pmc-mode --steps 2 --lanes 1 > /tmp/pmc_$c.log 2>&1
 done
 python3 $R/tools/pmc_traffic.py $(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) 2 $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1
+# the same two passes on the c5 step (block-scaled encoder + 1M-row bf16 sweep): the mx8 / bf16 GEMM families as bytes
+for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc5_$c
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc5_$c -o p -- python3 $R/bench.py --pmc-mode --config c5 --steps 2 --lanes 1 > /tmp/pmc5_$c.log 2>&1
+done
+python3 $R/tools/pmc_traffic.py $(find /tmp/pmc5_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pmc5_WRITE_SIZE -name "*counter_collection.csv" | head -1) 2 $O/pmc_traffic_c5.json > $O/pmc_traffic_c5.log 2>&1
 unset FERN_GEMM_TILES
 timeout 300 python3 $R/tools/sweep_bench.py > $O/${TAG}_sweep_bench.txt 2>&1
 rm -rf /tmp/prof_sweep
@@ -54,9 +60,17 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sw
 python3 $R/tools/kstats.py /tmp/prof_sweep 16 $O/${TAG}_sweep_1M_kernel_stats.csv > $O/${TAG}_sweep_1M_kernel_stats_top.txt 2>&1
 timeout 200 python3 $R/tools/attn_bench.py > $O/${TAG}_attn_bench.txt 2>&1
 cd $R
-for c in c2 c3 c4 c5; do      # the c2 line is the driver's default command: it carries cpu_baseline and the c3 / c4 / c5 child runs (other_configs)
-    timeout 900 python3 bench.py --config $c $( [ $c = c2 ] || echo --no-cpu-baseline ) > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err
+# the driver's default command: it carries cpu_baseline, the harness / quality / PCIe legs and the c3 / c4 / c5 child runs (other_configs)
+timeout 1200 python3 bench.py > $O/${TAG}_bench_c2.json 2> $O/${TAG}_bench_c2.err
+# ranking stage: micro-benchmark of its three forms at the BASELINE shapes + kernel timelines of the forms the cost model picks
+timeout 300 python3 tools/rank_bench.py > $O/${TAG}_rank_bench.txt 2>&1
+cd /tmp
+for v in c2:prefiltered c2:fp32_sweep c3:prefiltered 1M:prefiltered; do
+    rm -rf /tmp/rtl_$v
+    timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/rtl_$v -o p -- python3 $R/tools/rank_bench.py --reps 10 --trace $v > /dev/null 2>&1
+    python3 $R/tools/step_timeline.py /tmp/rtl_$v 10 --list > $O/${TAG}_rank_timeline_${v/:/_}.txt 2>&1
 done
+cd $R
 # one-stream kernel sequence of a c2 / c5 step (what DESIGN.md's per-block attributions quote)
 cd /tmp
 for c in c2 c3 c5; do
