@@ -1784,10 +1784,14 @@ extern "C" int fern_sim_topk_prefiltered(fern_ctx* c, const float* q, const floa
                 HIP_TRY_PROF(le, c, slot);
                 FERN_TRY(prof_close(c, slot, s));
             }
+            // small galleries: a query without room is ranked by its own workgroup inside the kernel (one CU streams <= 128 MB of fp32 rows:
+            // <= ~2 ms in a case that almost never happens) and the gated exact-pass launch -- ~4.5 us of every call -- is not made
+            const bool inline_exact = (double)N * D * 4 <= 128e6;
             HIP_TRY(launch_topk_dense_rescore(approx, ld, N, q + o * D, gallery, D, meta, m, K, ex, idx_offset, idx_offset, out_scores + o * K,
-                                              out_idx + o * K, thr, flags, state, state + m, s));
-            HIP_TRY(launch_rank_exact(q + o * D, gallery, 0, m, N, D, K, state, thr, ex, idx_offset, idx_offset, partial, groups, state + m,
-                                      out_scores + o * K, out_idx + o * K, flags, s));
+                                              out_idx + o * K, thr, flags, state, state + m, s, inline_exact ? 1 : 0));
+            if (!inline_exact)
+                HIP_TRY(launch_rank_exact(q + o * D, gallery, 0, m, N, D, K, state, thr, ex, idx_offset, idx_offset, partial, groups, state + m,
+                                          out_scores + o * K, out_idx + o * K, flags, s));
             FERN_TRY(prof_close(c, stage, s));
             continue;
         }

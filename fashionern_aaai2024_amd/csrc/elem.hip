@@ -590,6 +590,13 @@ __global__ __launch_bounds__(256) void mean_rows_kernel(const float* x, long ldx
     const float* src = x + (row * group_stride + row_add) * ldx + c;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int p = 0;
+    for (; p + 32 <= P; p += 32) {      // round 5: 32 rows in flight (128 VGPRs) -- 77 tokens are 3 round trips instead of 10 (a round trip here is ~3 us:
+        f32x4 t[32];                    // the rows were just written from other XCDs); same summation order, same bits
+#pragma unroll
+        for (int u = 0; u < 32; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (long)(p + u) * ldx);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc += t[u];
+    }
     for (; p + 8 <= P; p += 8) {
         f32x4 t[8];
 #pragma unroll

@@ -393,9 +393,10 @@ hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S,
 // S = N, R = 1); one kernel does bound, collection, T~, survivors, exact rescoring and ranking per query.  Sets state[b] / done[b] and
 // (when a query has no room) thr_key[b] + flags[0] for launch_rank_exact; flags[0..1] must be zero before (launch_sweep_bf16's
 // zero_flags does it).
+// inline_exact != 0: a query without room is ranked exactly by its own workgroup (small galleries: no gated exact-pass launch needed).
 hipError_t launch_topk_dense_rescore(const float* approx, long ld, long N, const float* q, const float* gallery, int D, const float* meta,
                                      int B, int K, const int* exclude, long exclude_off, long idx_offset, float* out_scores,
-                                     int* out_idx, unsigned long long* thr_key, int* flags, int* state, int* done, hipStream_t s);
+                                     int* out_idx, unsigned long long* thr_key, int* flags, int* state, int* done, hipStream_t s, int inline_exact = 0);
 hipError_t launch_topk_rescore(const TopkFilter& f, const float* q, const float* gallery, int D, const float* margin, int B, int K, long idx_offset,
                                float* out_scores, int* out_idx, int* flags, int* state, hipStream_t s);
 // Fused sweep, final step: exact top-K of each query's candidate list -> out (idx = row + idx_offset; unfilled: -inf / -1).

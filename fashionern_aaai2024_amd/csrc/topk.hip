@@ -722,6 +722,51 @@ __global__ __launch_bounds__(256) void topk_rescore_kernel(TopkFilter f, const f
 // Without room (more than DENSE_CAP collected, more than RESC_MAX survivors) the query is flagged for the exact pass with the bound
 // it had reached (l0 - margin or T~ - margin: lower bounds of the exact K-th best).  Resets done[b] for that pass; flags[0] is
 // zeroed by the host launcher before the sweep.
+// Exact top-K of ONE query by its own workgroup (256 threads), for the dense form on SMALL galleries: a query the pre-filter has no room
+// for (near-tie floods, galleries smaller than ~K, NaN scores) is ranked right here -- every row's exact chain, streamed through the
+// waves' sorted lists (wave_offer: no capacity) -- instead of by the gated exact-pass launch, whose ~4.5 us of launch boundary every call
+// paid for a case that almost never happens.  One CU streams the whole fp32 gallery (~60 GB/s): the launcher allows it up to 128 MB.
+__device__ __forceinline__ void exact_topk_inline(const float* qrow, const float* gallery, long N, int D, long drop, int K, long idx_offset,
+                                                  float* os, int* oi, u64 (*wl)[64]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u64 best = 0;
+#pragma unroll 1
+    for (long n0 = (long)wave * 64; n0 < N; n0 += 256) {
+        const long n = n0 + lane;
+        u64 key = 0;
+        if (n < N && n != drop) {
+            const float* g = gallery + n * D;
+            float acc = 0.0f;
+            for (int k8 = 0; k8 < D; k8 += 8) {
+                const f32x4e g0 = *reinterpret_cast<const f32x4e*>(g + k8), g1 = *reinterpret_cast<const f32x4e*>(g + k8 + 4);
+                const f32x4e q0 = *reinterpret_cast<const f32x4e*>(qrow + k8), q1 = *reinterpret_cast<const f32x4e*>(qrow + k8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = __builtin_fmaf(q0[e], g0[e], acc);
+                    acc = __builtin_fmaf(q1[e], g1[e], acc);
+                }
+            }
+            key = make_key(acc, (unsigned)n);
+        }
+        wave_offer(best, key, K, lane);
+    }
+    wl[wave][lane] = best;
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll 1
+    for (int w = 1; w < 4; ++w) best = merge_sorted_desc(best, wl[w][lane], lane);
+    if (lane < K) {
+        float sc = -INFINITY;
+        int idx = -1;
+        if (best != 0) {
+            sc = unorderable((unsigned)(best >> 32));
+            idx = (int)((long)(0xFFFFFFFFu - (unsigned)best) + idx_offset);
+        }
+        os[lane] = sc;
+        oi[lane] = idx;
+    }
+}
+
 constexpr int DENSE_SEG = 1024;                 // collected keys per wave (4 segments)
 constexpr int DENSE_UB = 16;                    // 16-byte loads a thread keeps in flight while it walks the score row
 constexpr int DENSE_BATCH = 1024 * DENSE_UB;    // floats the workgroup covers per batch
@@ -730,7 +775,8 @@ constexpr int DENSE_BATCH = 1024 * DENSE_UB;    // floats the workgroup covers p
 template <int NB>
 __global__ __launch_bounds__(256) void topk_dense_rescore_kernel(const float* approx, long ld, long N, const float* q, const float* gallery, int D,
                                                                  BoundMargin mg, int K, const int* exclude, long exclude_off, long idx_offset,
-                                                                 float* out_scores, int* out_idx, u64* thr_key, int* flags, int* state, int* done, int stop) {
+                                                                 float* out_scores, int* out_idx, u64* thr_key, int* flags, int* state, int* done, int stop, int inline_exact) {
+    __shared__ u64 wlists[4][64];                                            // inline exact ranking: the waves' sorted lists
     __shared__ __attribute__((aligned(16))) u64 ckey[4][DENSE_SEG + 2];      // per wave: collected approximate keys (+ zero padding)
     __shared__ __attribute__((aligned(16))) float tiles[RESC_TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) u64 x_key[RESC_MAX + 4];
@@ -833,10 +879,11 @@ __global__ __launch_bounds__(256) void topk_dense_rescore_kernel(const float* ap
 #pragma unroll
     for (int w = 1; w < 4; ++w) l0 = wmax[w] < l0 ? wmax[w] : l0;
     // l0 == 0: some wave holds fewer than ceil(K / 4) rows (a gallery of < ~K rows), or met a NaN score
-    if (l0 == 0) {      // (uniform) no bound: flagged for the exact pass with "accept all" -- tiny galleries, where that pass is cheap, or NaN scores
-        if (tid == 0) { state[b] = 1; flags[0] = 1; thr_key[b] = 0ull; }
-        return;
-    }
+    // A query the pre-filter has no room for leaves the do-block with `fallback_thr` = the bound it had reached (a lower bound of the
+    // exact K-th best) and is ranked exactly behind it: ONE copy of that code, at the end.
+    u64 fallback_thr = 0;
+    do {
+    if (l0 == 0) break;      // (uniform) no bound -- tiny galleries, or NaN scores
     const float cut0 = unorderable(l0) - margin;
     if (stop == 2) { if (cut0 == 0.12345f) out_idx[0] = 1; return; }
     // (This kernel runs ONCE per CU on a cold instruction cache: its time follows the bytes of code it executes.  A second, never-taken
@@ -891,8 +938,8 @@ __global__ __launch_bounds__(256) void topk_dense_rescore_kernel(const float* ap
     const int nc = c0 + c1 + c2 + c3;
     if (stop == 3 || stop == 21) { if (tid == 0) out_idx[(long)b * K] = nc; return; }
     if (c0 > DENSE_SEG || c1 > DENSE_SEG || c2 > DENSE_SEG || c3 > DENSE_SEG) {
-        if (tid == 0) { state[b] = 1; flags[0] = 1; thr_key[b] = cut0 == cut0 ? (u64)orderable(cut0) << 32 : 0ull; }
-        return;
+        fallback_thr = cut0 == cut0 ? (u64)orderable(cut0) << 32 : 0ull;
+        break;
     }
     // the i-th collected key (segments in wave order)
     auto key_at = [&](int i) -> u64 {
@@ -937,10 +984,19 @@ __global__ __launch_bounds__(256) void topk_dense_rescore_kernel(const float* ap
     const int ns = nsurv;
     if (stop == 5) { if (tid == 0) out_idx[(long)b * K] = ns; return; }
     if (ns > RESC_MAX) {
-        if (tid == 0) { state[b] = 1; flags[0] = 1; thr_key[b] = cut == cut && khi != 0 ? (u64)orderable(cut) << 32 : 0ull; }
-        return;
+        fallback_thr = cut == cut && khi != 0 ? (u64)orderable(cut) << 32 : 0ull;
+        break;
     }
     rescore_and_rank(surv, ns, qrow, gallery, D, tiles, x_key, K, idx_offset, out_scores + (long)b * K, out_idx + (long)b * K);
+    return;
+    } while (0);
+    if (inline_exact) {      // small galleries: ranked exactly right here
+        exact_topk_inline(qrow, gallery, N, D, drop, K, idx_offset, out_scores + (long)b * K, out_idx + (long)b * K, wlists);
+    } else if (tid == 0) {   // flagged for the gated exact pass
+        state[b] = 1;
+        flags[0] = 1;
+        thr_key[b] = fallback_thr;
+    }
 }
 
 // ---- exact pass ---------------------------------------------------------------------------------------------------------------
@@ -1125,7 +1181,7 @@ hipError_t launch_topk_rescore(const TopkFilter& f, const float* q, const float*
 
 hipError_t launch_topk_dense_rescore(const float* approx, long ld, long N, const float* q, const float* gallery, int D, const float* meta,
                                      int B, int K, const int* exclude, long exclude_off, long idx_offset, float* out_scores,
-                                     int* out_idx, unsigned long long* thr_key, int* flags, int* state, int* done, hipStream_t s) {
+                                     int* out_idx, unsigned long long* thr_key, int* flags, int* state, int* done, hipStream_t s, int inline_exact) {
     if (B <= 0) return hipSuccess;
     if (K < 1 || K > 64 || D < 64 || D % 64 || D > 1024 || N < 1 || (ld & 3) || !meta) return hipErrorInvalidValue;
     const BoundMargin mg{q, D, meta, nullptr};
@@ -1134,7 +1190,7 @@ hipError_t launch_topk_dense_rescore(const float* approx, long ld, long N, const
     const long n4 = N & ~3L;
 #define FERN_DENSE_GO(NB)                                                                                                                       \
     FERN_LAUNCH(topk_dense_rescore_kernel<NB>, dim3(B), dim3(256), 0, s, approx, ld, N, q, gallery, D, mg, K, exclude, exclude_off, idx_offset, \
-                out_scores, out_idx, thr_key, flags, state, done, stop)
+                out_scores, out_idx, thr_key, flags, state, done, stop, inline_exact)
     if (n4 <= 1L * DENSE_BATCH) FERN_DENSE_GO(1);
     else if (n4 <= 2L * DENSE_BATCH) FERN_DENSE_GO(2);
     else if (n4 <= 3L * DENSE_BATCH) FERN_DENSE_GO(3);
