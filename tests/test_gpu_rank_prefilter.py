@@ -48,7 +48,8 @@ def _same_bits(s, i, cs, ci):
     return np.array_equal(i.cpu().numpy(), ci) and np.array_equal(s.cpu().numpy().view(np.uint32), cs.view(np.uint32))
 
 
-@pytest.mark.parametrize("B,N,D", [(3, 1000, 64), (64, 9001, 640), (130, 3000, 128), (1, 70_000, 512), (64, 46_000, 512), (5, 40, 64), (2, 7, 1024)])
+@pytest.mark.parametrize("B,N,D", [(3, 1000, 64), (64, 9001, 640), (130, 3000, 128), (1, 70_000, 512), (64, 46_000, 512), (5, 40, 64), (2, 7, 1024),
+                                   (9, 200_003, 128)])
 def test_prefiltered_ranking_is_bit_identical_to_the_fma_chain(engine, B, N, D):
     """Random operands at the shapes of test_sim_topk_bit_identical_to_the_fma_chain plus BASELINE C2's (64 x 46 000 x 512) and
     galleries smaller than K: same bits as the sequential fp32 fma chain, same ranking -- and the same as the plain fp32 stage."""
@@ -129,6 +130,22 @@ def test_exclusion_offsets_and_large_batches(engine):
         keep = [(sc, ix + 7000) for sc, ix in zip(cs[b], ci[b]) if ix + 7000 != int(ex[b])][:51]
         assert [x for _, x in keep] == i[b].cpu().tolist()
         assert np.array_equal(np.array([x for x, _ in keep], np.float32).view(np.uint32), s[b].cpu().numpy().view(np.uint32))
+
+
+def test_large_dense_gallery_with_exclusions_spread_over_the_row(engine):
+    """A gallery beyond the three register-held batches of the dense kernel (49 152 rows: the streaming path), the excluded row of each
+    query is its best row, spread over the whole row range; N is not a multiple of anything."""
+    n, d, k = 150_001, 64, 50
+    q, g = _rand(7, d, 61), _rand(n, d, 62, d ** -0.5)
+    ex_rows = [0, 37_000, 49_151, 49_152, 75_001, 120_000, 150_000]
+    for b, row in enumerate(ex_rows):
+        g[row] = q[b] * 3.0
+    ex = torch.tensor(ex_rows, dtype=torch.int32)
+    s, i = engine.sim_topk(q, engine.prepare_gallery(g), k, exclude_idx=ex)
+    s0, i0 = engine.sim_topk(q, g, k, exclude_idx=ex)
+    assert torch.equal(s, s0) and torch.equal(i, i0) and not (i.cpu() == ex[:, None]).any()
+    s, i = engine.sim_topk(q, engine.prepare_gallery(g), k)                  # ... and without the exclusion those rows rank first
+    assert i[:, 0].cpu().tolist() == ex_rows
 
 
 def test_excluded_row_is_the_best_row_and_a_sampled_row(engine):
