@@ -61,6 +61,7 @@ SIGNATURES = {
     "fern_sim_topk_prefiltered": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_i64,
                                           c_void_p, c_void_p]),
     "fern_rank_set_strategy": (c_int, [c_void_p, c_int]),
+    "fern_sweep_bf16_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
     "fern_gather_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fern_topk_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fern_gemm": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,

@@ -103,7 +103,11 @@ struct ClipW {
 
 enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_TOPK = 2, PROF_SWEEP = 3, PROF_STAGE = 4 };
 struct ProfRec { hipEvent_t a, b; int kind; double work; int m, n, k, tag; int dispatches;
-                 std::vector<hipEvent_t> kev; /* kernel-precise (start, stop) pairs of the launch's dispatches (kernels.h: LaunchTimer); empty: a, b are stream events */ };
+                 std::vector<hipEvent_t> kev; /* kernel-precise (start, stop) pairs of the launch's dispatches (kernels.h: LaunchTimer); empty: a, b are stream events */
+                 /* span records (the ranking stage, round 5): kev holds EVERY dispatch of the stage in launch order; the stage's time is first
+                    dispatch begin -> last dispatch end (launch boundaries between them included), the dispatches [sweep_lo, sweep_hi) are its
+                    full-gallery sweep(s), `work` their bytes */
+                 bool span = false; int sweep_lo = 0, sweep_hi = 0; };
 
 namespace fern {
 thread_local LaunchTimer* g_launch_timer = nullptr;
@@ -245,6 +249,45 @@ static void prof_abort(fern_ctx* c, int slot) {
         if (le__ != hipSuccess) prof_abort(c, slot); \
         HIP_TRY(le__);                              \
     } while (0)
+
+// The ranking stage timed by its dispatches' own timestamps (round 5): while a StageTimer is live every launch of the stage goes through
+// FERN_LAUNCH with an event pair; commit() turns them into ONE span record.  A stage that fails (or a stream being captured) leaves
+// nothing behind.  [The stream-marker interval of rounds 3-4 charged two marker packets + dispatch latencies, ~8 us, to a stage that is
+// now ~46 us of kernels.]
+struct StageTimer {
+    fern_ctx* c;
+    bool on = false, done = false;
+    int sweep_lo = 0, sweep_hi = 0;
+    double sweep_bytes = 0;
+    StageTimer(fern_ctx* ctx, hipStream_t s) : c(ctx) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (c->prof_on && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+            c->timer.events.clear();
+            c->timer.pool = &c->ev_pool;
+            g_launch_timer = &c->timer;
+            on = true;
+        }
+    }
+    void sweep_begin() { if (on) sweep_lo = (int)c->timer.events.size() / 2; }
+    void sweep_end(double bytes) { if (on) { sweep_hi = (int)c->timer.events.size() / 2; sweep_bytes += bytes; } }
+    void commit(int m, int n, int k) {
+        if (!on) return;
+        g_launch_timer = nullptr;
+        done = true;
+        if (c->timer.events.size() < 2) return;
+        ProfRec r{nullptr, nullptr, PROF_STAGE, sweep_bytes, m, n, k, 0, 1, {}};
+        r.span = true; r.sweep_lo = sweep_lo; r.sweep_hi = sweep_hi;
+        r.kev.swap(c->timer.events);
+        c->recs.push_back(std::move(r));
+    }
+    ~StageTimer() {
+        if (on && !done) {
+            g_launch_timer = nullptr;
+            for (hipEvent_t e : c->timer.events) c->ev_pool.push_back(e);
+            c->timer.events.clear();
+        }
+    }
+};
 
 static int run_gemm(fern_ctx* c, const GemmParams& p, hipStream_t s, int kind = PROF_GEMM, double work = -1.0) {
     int slot;
@@ -1680,24 +1723,22 @@ extern "C" int fern_sim_topk_bf16(fern_ctx* c, const float* q, const uint16_t* g
             if (f.exclude) f.exclude += b0;
             return f;
         };
-        int slot, stage;
-        FERN_TRY(prof_open(c, PROF_STAGE, 0, s, &stage));
+        StageTimer st(c, s);
         for (long b0 = 0; b0 < m; b0 += QBLK)
             HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery, P.sample + b0 * P.ld, P.ld, (int)std::min<long>(QBLK, m - b0), N, D, P.S, P.R,
                                       nullptr, nullptr, s));
         HIP_TRY(launch_topk_sample_bound(P.sample, P.ld, m, P.S, P.R, K, ex, idx_offset, P.thr, P.count, P.flags, P.state, s));
+        st.sweep_begin();
         for (long b0 = 0; b0 < m; b0 += QBLK) {
             const int mb = (int)std::min<long>(QBLK, m - b0);
             const TopkFilter f = block_filter(b0);
-            FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + (double)mb * D * 4 + (double)mb * K * 8, s, &slot, mb, (int)N, D, 16));
-            const hipError_t le = launch_sweep_bf16(q + (o + b0) * D, gallery, nullptr, 0, mb, N, D, 0, 1, &f, nullptr, s);
-            HIP_TRY_PROF(le, c, slot);
-            FERN_TRY(prof_close(c, slot, s));
+            HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery, nullptr, 0, mb, N, D, 0, 1, &f, nullptr, s));
+            st.sweep_end((double)N * D * 2 + (double)mb * D * 4 + (double)mb * K * 8);
         }
         HIP_TRY(launch_topk_candidates(P.filt, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, P.state, s));
         HIP_TRY(launch_rank_exact(q + o * D, gallery, 1, m, N, D, K, P.state, P.thr, ex, idx_offset, idx_offset, P.partial, P.groups, P.done,
                                   out_scores + o * K, out_idx + o * K, P.flags, s));
-        FERN_TRY(prof_close(c, stage, s));
+        st.commit(m, (int)N, D);
     }
     return FERN_OK;
 }
@@ -1713,6 +1754,19 @@ extern "C" int fern_gallery_prepare(fern_ctx* c, const float* gallery, int64_t N
     return FERN_OK;
 }
 
+// The bf16 sweep's score matrix and tile maxima on their own (include/fern.h): what the dense form of fern_sim_topk_prefiltered selects on.
+extern "C" int fern_sweep_bf16_scores(fern_ctx* c, const float* q, const uint16_t* gallery_bf16, int B, int64_t N, int D, float* scores, int64_t ld,
+                                      float* tile_max, int64_t ldt, void* stream) {
+    if (!c || B < 0 || N < 0 || D <= 0 || D % 64 || D > 768) return fail(FERN_ERR_ARG, "fern_sweep_bf16_scores: need D % 64 == 0, D <= 768");
+    if ((long)B * N && (!q || !gallery_bf16 || !scores || ld < N || (tile_max && ldt < (N + 31) / 32)))
+        return fail(FERN_ERR_ARG, "fern_sweep_bf16_scores: NULL argument or leading dimension too small");
+    HIP_TRY(hipSetDevice(c->device));
+    for (long b0 = 0; b0 < B; b0 += 64)
+        HIP_TRY(launch_sweep_bf16(q + b0 * D, gallery_bf16, scores + b0 * ld, ld, (int)std::min<long>(64, B - b0), N, D, N, 1, nullptr, nullptr,
+                                  (hipStream_t)stream, nullptr, tile_max ? tile_max + b0 * ldt : nullptr, ldt));
+    return FERN_OK;
+}
+
 static long prefilter_sample_rows(int64_t N) {
     // a denser sample than the plain plan's (1 in 32 instead of 1 in 64 beyond 131k rows): the margin lowers the bound by ~0.1 sigma of the
     // score distribution, a tighter sample bound pays that back; 32768 is what the bound kernel holds in registers
@@ -1724,15 +1778,19 @@ static long prefilter_sample_rows(int64_t N) {
 // galleries whose [B, N] score matrix would be real traffic); FERN_RANK_DENSE = bf16 sweep that stores its scores + one
 // select-and-rescore kernel (three launches; small galleries, where the stage is launch boundaries, not bytes).
 static int rank_strategy_for(const fern_ctx* c, int B, int64_t N, int D) {
-    const bool dense_ok = N <= 262144 && (double)B * N * 4 <= 256e6;      // the [B, N] fp32 score matrix stays small next to the gallery
+    const bool dense_ok = (double)std::min<long>(B, (long)kRankQueryChunk) * N * 4 <= 1.1e9;      // the [B, N] fp32 score matrix of a query chunk: workspace
     if (c->rank_strategy != FERN_RANK_AUTO) return (c->rank_strategy == FERN_RANK_DENSE && !dense_ok) ? (int)FERN_RANK_LISTS : c->rank_strategy;
-    const long QBLK = (D == 64 || D == 128 || D == 256 || D == 512) ? 128 : 64;
-    const double nblk = (double)((B + QBLK - 1) / QBLK), stream_us = (double)N * D * 2 / 4.5e6;      // one bf16 pass at ~4.5 TB/s
+    // microseconds, fitted to tools/rank_bench.py on MI355X (profiles/r05_rank_bench.txt): one bf16 pass streams at ~5.8 TB/s behind ~14 us of
+    // ramp; the dense sweep also writes its [B, N] scores (~4 TB/s); its select kernel reads N / 32 tile maxima per query when the sweep left
+    // them (one 64-query block per launch, >= 16 384 rows: fern_sim_topk_prefiltered), else walks the row twice with ONE workgroup (~60 GB/s)
+    const long QBLK2 = (D == 64 || D == 128 || D == 256 || D == 512) ? 128 : 64;
+    const bool tiles = N >= 16384 && (B <= 64 || QBLK2 == 64 || N >= 131072);
+    const long qblk = tiles ? 64 : QBLK2;
+    const double sweep_us = std::max(17.0, (double)N * D * 2 / 5.8e6 + 14.0), rounds = (double)((B + 255) / 256);
     const double plain = 38.0 + 2.0 * B * (double)N * D / 95e6;                                        // launches + fp32 MFMA at ~95 TFLOP/s (skinny M)
-    // dense: the sweep also writes its [B, N] scores, and the select kernel streams a query's row twice with ONE workgroup (~60 GB/s)
-    const double dense = nblk * (std::max(17.0, stream_us + 8.0) + (double)std::min<long>(B, QBLK) * N * 4 / 3e6) +
-                         ((B + 255) / 256) * (14.0 + (double)N * 8 / 6e4) + 5.0;
-    const double lists = nblk * (14.0 + std::max(17.0, stream_us + 8.0)) + 8.0 + 16.0 * ((B + 255) / 256) + 5.0;
+    const double dense = (double)((B + qblk - 1) / qblk) * (sweep_us + (double)std::min<long>(B, qblk) * N * 4 / 4e6) +
+                         rounds * (tiles ? 22.0 + (double)N * 3e-5 : 14.0 + (double)N * 8 / 6e4) + 5.0;
+    const double lists = (double)((B + QBLK2 - 1) / QBLK2) * (sweep_us + 25.0) + 16.0 * rounds + 45.0;
     int best = FERN_RANK_PLAIN;
     double t = plain;
     if (lists < t) { best = FERN_RANK_LISTS; t = lists; }
@@ -1758,41 +1816,45 @@ extern "C" int fern_sim_topk_prefiltered(fern_ctx* c, const float* q, const floa
         return fern_sim_topk(c, q, gallery, B, N, D, K, out_scores, out_idx, idx_offset, exclude_idx, stream);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    const long QBLK = (D == 64 || D == 128 || D == 256 || D == 512) ? 128 : 64;
+    const long QBLK2 = (D == 64 || D == 128 || D == 256 || D == 512) ? 128 : 64, QBLK = QBLK2;
     const double alg_bytes_per_q = (double)D * 4 + (double)K * 8;
     for (long o = 0; o < B; o += (long)kRankQueryChunk) {
         const int m = (int)std::min<long>((long)kRankQueryChunk, B - o);
         const int32_t* ex = exclude_idx ? exclude_idx + o : nullptr;
         FERN_TRY(ws_begin(c, s));
-        int slot, stage;
         if (strategy == FERN_RANK_DENSE) {
-            const long ld = (N + 3) & ~3L;
+            const long ld = (N + 31) & ~31L, ldt = (((N + 31) >> 5) + 3) & ~3L;      // whole 32-row tiles; one maximum per tile
+            // the sweep leaves tile maxima for the select kernel when it runs one 64-query block per launch; two-block sweeps (65..128
+            // queries, D a power of two) have no registers for it: kept below 131 072 rows, where walking the rows costs less than a second
+            // gallery pass
+            const long QBLK = (m > 64 && N < 131072) ? QBLK2 : 64;
+            const bool tiles = QBLK == 64 && N >= 16384;
             const int groups = (int)std::min<long>(256, std::max<long>(1, (N + 4095) / 4096));
-            float* approx; unsigned long long *thr, *partial; int *flags, *state;
+            float *approx, *tmax; unsigned long long *thr, *partial; int *flags, *state;
             FERN_TRY(ws_get(c, (size_t)m * ld, &approx));
+            FERN_TRY(ws_get(c, (size_t)m * ldt, &tmax));
             FERN_TRY(ws_get(c, (size_t)m, &thr));
             FERN_TRY(ws_get(c, (size_t)4, &flags));
             FERN_TRY(ws_get(c, (size_t)2 * m, &state));
             FERN_TRY(ws_get(c, (size_t)m * groups * 64, &partial));
-            FERN_TRY(prof_open(c, PROF_STAGE, 0, s, &stage));
+            StageTimer st(c, s);
+            st.sweep_begin();
             for (long b0 = 0; b0 < m; b0 += QBLK) {
                 const int mb = (int)std::min<long>(QBLK, m - b0);
+                HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery_bf16, approx + b0 * ld, ld, mb, N, D, N, 1, nullptr, nullptr, s,
+                                          b0 == 0 ? flags : nullptr, tiles ? tmax + b0 * ldt : nullptr, ldt));
                 // bytes this kernel moves: the bf16 copy once, the queries, its [mb, N] fp32 scores out
-                FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + (double)mb * D * 4 + (double)mb * N * 4, s, &slot, mb, (int)N, D, 17));
-                const hipError_t le = launch_sweep_bf16(q + (o + b0) * D, gallery_bf16, approx + b0 * ld, ld, mb, N, D, N, 1, nullptr, nullptr, s,
-                                                        b0 == 0 ? flags : nullptr);
-                HIP_TRY_PROF(le, c, slot);
-                FERN_TRY(prof_close(c, slot, s));
+                st.sweep_end((double)N * D * 2 + (double)mb * D * 4 + (double)mb * N * 4);
             }
             // small galleries: a query without room is ranked by its own workgroup inside the kernel (one CU streams <= 128 MB of fp32 rows:
             // <= ~2 ms in a case that almost never happens) and the gated exact-pass launch -- ~4.5 us of every call -- is not made
             const bool inline_exact = (double)N * D * 4 <= 128e6;
             HIP_TRY(launch_topk_dense_rescore(approx, ld, N, q + o * D, gallery, D, meta, m, K, ex, idx_offset, idx_offset, out_scores + o * K,
-                                              out_idx + o * K, thr, flags, state, state + m, s, inline_exact ? 1 : 0));
+                                              out_idx + o * K, thr, flags, state, state + m, s, inline_exact ? 1 : 0, tiles ? tmax : nullptr, ldt));
             if (!inline_exact)
                 HIP_TRY(launch_rank_exact(q + o * D, gallery, 0, m, N, D, K, state, thr, ex, idx_offset, idx_offset, partial, groups, state + m,
                                           out_scores + o * K, out_idx + o * K, flags, s));
-            FERN_TRY(prof_close(c, stage, s));
+            st.commit(m, (int)N, D);
             continue;
         }
         RankPlan P;
@@ -1805,25 +1867,24 @@ extern "C" int fern_sim_topk_prefiltered(fern_ctx* c, const float* q, const floa
             if (f.exclude) f.exclude += b0;
             return f;
         };
-        FERN_TRY(prof_open(c, PROF_STAGE, 0, s, &stage));
+        StageTimer st(c, s);
         for (long b0 = 0; b0 < m; b0 += QBLK)
             HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery_bf16, P.sample + b0 * P.ld, P.ld, (int)std::min<long>(QBLK, m - b0), N, D, P.S, P.R,
                                       nullptr, nullptr, s));
         HIP_TRY(launch_topk_sample_bound(P.sample, P.ld, m, P.S, P.R, K, ex, idx_offset, P.thr, P.count, P.flags, P.state, s, q + o * D, D, meta, margin));
+        st.sweep_begin();
         for (long b0 = 0; b0 < m; b0 += QBLK) {
             const int mb = (int)std::min<long>(QBLK, m - b0);
             const TopkFilter f = block_filter(b0);
+            HIP_TRY(launch_sweep_bf16(q + (o + b0) * D, gallery_bf16, nullptr, 0, mb, N, D, 0, 1, &f, nullptr, s));
             // bytes this kernel streams: the bf16 copy once, the queries, nothing stored (the STAGE's algorithmic bytes -- SURVEY 8d, an fp32
             // gallery: N D 4 -- are the caller's to quote against the stage time)
-            FERN_TRY(prof_open(c, PROF_SWEEP, (double)N * D * 2 + mb * alg_bytes_per_q, s, &slot, mb, (int)N, D, 16));
-            const hipError_t le = launch_sweep_bf16(q + (o + b0) * D, gallery_bf16, nullptr, 0, mb, N, D, 0, 1, &f, nullptr, s);
-            HIP_TRY_PROF(le, c, slot);
-            FERN_TRY(prof_close(c, slot, s));
+            st.sweep_end((double)N * D * 2 + mb * alg_bytes_per_q);
         }
         HIP_TRY(launch_topk_rescore(P.filt, q + o * D, gallery, D, margin, m, K, idx_offset, out_scores + o * K, out_idx + o * K, P.flags, P.state, s));
         HIP_TRY(launch_rank_exact(q + o * D, gallery, 0, m, N, D, K, P.state, P.thr, ex, idx_offset, idx_offset, P.partial, P.groups, P.done,
                                   out_scores + o * K, out_idx + o * K, P.flags, s));
-        FERN_TRY(prof_close(c, stage, s));
+        st.commit(m, (int)N, D);
     }
     return FERN_OK;
 }
@@ -2065,7 +2126,18 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
     FILE* dump = dump_path ? std::fopen(dump_path, "a") : nullptr;
     for (auto& r : c->recs) {
         float ms = 0.f;
-        if (!r.a) {                      // kernel-precise: the sum of the dispatches' own durations
+        if (r.span) {                    // the ranking stage: first dispatch begin -> last dispatch end; its sweep dispatches on their own
+            HIP_TRY(hipEventElapsedTime(&ms, r.kev.front(), r.kev.back()));
+            for (int i = r.sweep_lo; i < r.sweep_hi; ++i) {
+                float one = 0.f;
+                HIP_TRY(hipEventElapsedTime(&one, r.kev[2 * i], r.kev[2 * i + 1]));
+                out->sweep_ms += one;
+                out->sweep_launches++;
+            }
+            out->sweep_bytes += r.work;
+            for (hipEvent_t e : r.kev) c->ev_pool.push_back(e);
+            r.kev.clear();
+        } else if (!r.a) {               // kernel-precise: the sum of the dispatches' own durations
             for (size_t i = 0; i + 1 < r.kev.size(); i += 2) {
                 float one = 0.f;
                 HIP_TRY(hipEventElapsedTime(&one, r.kev[i], r.kev[i + 1]));
@@ -2087,7 +2159,7 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
                 break;
             case PROF_ATTN: out->attn_ms += ms; out->attn_flops += r.work; out->attn_launches++; break;
             case PROF_TOPK: out->topk_ms += ms; out->topk_launches++; break;
-            case PROF_STAGE: stage_ms += ms; out->topk_launches++; break;      // whole ranking stage of a query chunk (one marker pair)
+            case PROF_STAGE: stage_ms += ms; out->topk_launches++; break;      // whole ranking stage of a query chunk (a span record, or one marker pair)
             default: out->sweep_ms += ms; out->sweep_bytes += r.work; out->sweep_launches++; break;
         }
         if (r.a) { c->ev_pool.push_back(r.a); c->ev_pool.push_back(r.b); }

@@ -374,7 +374,7 @@ hipError_t launch_gallery_prepare(const float* x, unsigned short* y, long n, int
 // zero_flags (sample form only, may be null): two ints the first workgroup zeroes (the ranking stage's overflow flags, when no bound
 // kernel runs before the selection).
 hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
-                             const TopkFilter* filt, const int* gate, hipStream_t s, int* zero_flags = nullptr);
+                             const TopkFilter* filt, const int* gate, hipStream_t s, int* zero_flags = nullptr, float* tmax = nullptr, long ldt = 0);
 
 // ---- top-K (topk.hip) ------------------------------------------------------------------------
 // Fused sweep, step 2: per query the K-th best key of the sample scores [B, ld] (S valid columns; column c is gallery row
@@ -394,9 +394,12 @@ hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S,
 // (when a query has no room) thr_key[b] + flags[0] for launch_rank_exact; flags[0..1] must be zero before (launch_sweep_bf16's
 // zero_flags does it).
 // inline_exact != 0: a query without room is ranked exactly by its own workgroup (small galleries: no gated exact-pass launch needed).
+// tmax != null ([B, ldt]: launch_sweep_bf16's tile maxima, one per 32 gallery rows; ld must cover whole tiles): galleries of >= 16 384
+// rows select on the tile maxima and read only the listed tiles' scores (topk_tiles_rescore_kernel) -- same results.
 hipError_t launch_topk_dense_rescore(const float* approx, long ld, long N, const float* q, const float* gallery, int D, const float* meta,
                                      int B, int K, const int* exclude, long exclude_off, long idx_offset, float* out_scores,
-                                     int* out_idx, unsigned long long* thr_key, int* flags, int* state, int* done, hipStream_t s, int inline_exact = 0);
+                                     int* out_idx, unsigned long long* thr_key, int* flags, int* state, int* done, hipStream_t s, int inline_exact = 0,
+                                     const float* tmax = nullptr, long ldt = 0);
 hipError_t launch_topk_rescore(const TopkFilter& f, const float* q, const float* gallery, int D, const float* margin, int B, int K, long idx_offset,
                                float* out_scores, int* out_idx, int* flags, int* state, hipStream_t s);
 // Fused sweep, final step: exact top-K of each query's candidate list -> out (idx = row + idx_offset; unfilled: -inf / -1).

@@ -92,9 +92,51 @@ constexpr int QUEUE_BYTES = 4 * QCAP * 12 + 128 * 8 + 128 * 4;     // 4 waves x 
 // 0..63 keep their fragments in registers as before; the bf16 image of queries 64..127 stays in LDS (66 KB at D = 512) and their
 // fragments are read per k step -- 3 LDS reads per k step instead of 1, a fifth of the LDS bandwidth at the gallery's HBM rate -- and
 // the ring shrinks from 9 to 5 stages per wave to make room.  MFMA time per gallery byte doubles and stays far below the HBM time.
+// Lane exchange at distance STEP inside a 32-lane half (the lanes that hold one query's 32 gallery rows): DPP where the pattern exists
+// (quad permutes, row rotate by 8), ds_swizzle (no LDS memory touched) for 4 and 16.
+template <int STEP>
+__device__ __forceinline__ float lane_xchg(float x) {
+    int v = __float_as_int(x);
+    if (STEP == 1) v = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);             // quad_perm [1, 0, 3, 2]
+    else if (STEP == 2) v = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);        // quad_perm [2, 3, 0, 1]
+    else if (STEP == 8) v = __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);       // row_ror:8
+    else if (STEP == 4) v = __builtin_amdgcn_ds_swizzle(v, 0x101F);                          // bit mode: and 0x1f, xor 0x04
+    else v = __builtin_amdgcn_ds_swizzle(v, 0x401F);                                         // bit mode: and 0x1f, xor 0x10
+    return __int_as_float(v);
+}
+// The transposing reduction of a wave tile's scores (A = queries 0..31 of the block, Bv = 32..63, laid out like the MFMA accumulators):
+// in each step lanes l and l ^ STEP keep one half of their values each and receive the partner's copy of that half -- after the steps
+// (16 values, distance 1) (8, 2) (4, 8) (2, 4) (1, 16) every lane holds the maximum over the 32 lanes (= gallery rows) of ONE value: 31
+// exchanges instead of 32 x 5.  Ext-vector values with constant indices only: arrays indexed by the lane's half went to scratch.
+typedef float f32x8r __attribute__((ext_vector_type(8)));
+typedef float f32x4r __attribute__((ext_vector_type(4)));
+typedef float f32x2r __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float tile_row_max(const f32x16& A, const f32x16& Bv, int lane) {
+    const bool k1 = (lane & 1) == 0, k2 = (lane & 2) == 0, k8 = (lane & 8) == 0, k4 = (lane & 4) == 0, k16 = (lane & 16) == 0;
+    f32x16 r16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r16[i] = fmaxf(k1 ? A[i] : Bv[i], lane_xchg<1>(k1 ? Bv[i] : A[i]));
+    f32x8r r8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r8[i] = fmaxf(k2 ? r16[i] : r16[i + 8], lane_xchg<2>(k2 ? r16[i + 8] : r16[i]));
+    f32x4r r4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r4[i] = fmaxf(k8 ? r8[i] : r8[i + 4], lane_xchg<8>(k8 ? r8[i + 4] : r8[i]));
+    f32x2r r2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r2[i] = fmaxf(k4 ? r4[i] : r4[i + 2], lane_xchg<4>(k4 ? r4[i + 2] : r4[i]));
+    return fmaxf(k16 ? r2[0] : r2[1], lane_xchg<16>(k16 ? r2[1] : r2[0]));
+}
+// ... and which value that is: bit 4 of its index (A or Bv) is chosen by lane bit 0, bit 3 by lane bit 1, bit 2 by lane bit 3, bit 1 by lane
+// bit 2, bit 0 by lane bit 4; value i of lane half lh is query (i >> 4) * 32 + (i & 3) + 8 ((i & 15) >> 2) + 4 lh of the block.
+__device__ __forceinline__ int tile_row_max_query(int lane) {
+    const int i = ((lane & 1) << 4) | ((lane & 2) << 2) | ((lane & 8) >> 1) | ((lane & 4) >> 1) | ((lane & 16) >> 4);
+    return (i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2) + 4 * (lane >> 5);
+}
+
 template <int STAGES, bool FILTER, int KCH, int QB = 1>
 __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u16* g, float* scores, long ld, int B, long N, int D, long S, int R,
-                                                         TopkFilter filt, const int* gate, int* zero_flags) {
+                                                         TopkFilter filt, const int* gate, int* zero_flags, float* tmax, long ldt) {
     static_assert(QB == 1 || KCH > 0, "two query blocks need the register-resident form");
     if (gate && *gate == 0) return;
     if (!FILTER && zero_flags && blockIdx.x == 0 && threadIdx.x == 0) { zero_flags[0] = 0; zero_flags[1] = 0; }
@@ -278,8 +320,20 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
             }
         }
     };
+    // store form with a tile summary: tmax[query][tile] = the largest of the tile's 32 scores (what topk_tiles_rescore_kernel selects on).
+    // my_q = the query (of a 64-query block) whose maximum this lane holds after the reduction.
+    const int my_q = tile_row_max_query(lane);
     auto tile_done = [&](long t) {
         const long n = t * ROWS_T + l31;
+        if (!FILTER && QB == 1 && tmax) {                            // (rows past the gallery's end were loaded as its last row: the maximum is unchanged;
+                                                                     //  QB = 2 has no registers left for the reduction: the launcher refuses it)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float v0 = tile_row_max(acc[2 * qb], acc[2 * qb + 1], lane);
+                const int qi = qb * 64 + my_q;
+                if (qi < B) tmax[(long)qi * ldt + t] = v0;
+            }
+        }
         if (FILTER) {
 #pragma unroll
             for (int tm = 0; tm < 2 * QB; ++tm) {
@@ -349,7 +403,7 @@ hipError_t launch_bf16_to_f32(const unsigned short* x, float* y, long n, hipStre
 
 template <int STAGES, bool FILTER, int KCH, int QB = 1>
 static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
-                                    const TopkFilter& filt, const int* gate, hipStream_t s, int* zf) {
+                                    const TopkFilter& filt, const int* gate, hipStream_t s, int* zf, float* tmax, long ldt) {
     const size_t qbytes = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024;
     const size_t ringq = (size_t)4 * STAGES * STAGE_BYTES + QUEUE_BYTES;
     const size_t lds = (KCH > 0 && QB == 1) ? std::max(qbytes, ringq) : qbytes + ringq;
@@ -363,50 +417,51 @@ static hipError_t launch_sweep_inst(const float* q, const unsigned short* g, flo
     const long ntiles = ((FILTER ? N : S) + ROWS_T - 1) / ROWS_T;
     long blocks = (ntiles + 3) / 4;
     if (blocks > 256) blocks = 256;                                // one persistent workgroup per CU
-    FERN_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, s, q, g, scores, ld, B, N, D, S, R, filt, gate, zf);
+    FERN_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, s, q, g, scores, ld, B, N, D, S, R, filt, gate, zf, tmax, ldt);
     return hipGetLastError();
 }
 
 template <bool FILTER>
 static hipError_t launch_sweep_mode(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
-                                    const TopkFilter& filt, const int* gate, hipStream_t s, int* zf) {
+                                    const TopkFilter& filt, const int* gate, hipStream_t s, int* zf, float* tmax, long ldt) {
     static const bool regq = [] { const char* e = getenv("FERN_SWEEP_REGQ"); return !(e && e[0] == '0'); }();      // A/B switch
     if (B > 64) {    // 65..128 queries per gallery pass: second query block in LDS, 5-stage ring
         switch (D) {
-            case 64: return launch_sweep_inst<5, FILTER, 1, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
-            case 128: return launch_sweep_inst<5, FILTER, 2, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
-            case 256: return launch_sweep_inst<5, FILTER, 4, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
-            case 512: return launch_sweep_inst<5, FILTER, 8, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
+            case 64: return launch_sweep_inst<5, FILTER, 1, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);
+            case 128: return launch_sweep_inst<5, FILTER, 2, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);
+            case 256: return launch_sweep_inst<5, FILTER, 4, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);
+            case 512: return launch_sweep_inst<5, FILTER, 8, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);
             default: return hipErrorInvalidValue;
         }
     }
     if (regq) {      // register-resident queries, 9-stage ring
         switch (D) {
-            case 64: return launch_sweep_inst<9, FILTER, 1>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
-            case 128: return launch_sweep_inst<9, FILTER, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
-            case 256: return launch_sweep_inst<9, FILTER, 4>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
-            case 512: return launch_sweep_inst<9, FILTER, 8>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
-            case 640: return launch_sweep_inst<9, FILTER, 10>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);      // RN50x4 (C3): 320 fragment VGPRs of the 512
+            case 64: return launch_sweep_inst<9, FILTER, 1>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);
+            case 128: return launch_sweep_inst<9, FILTER, 2>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);
+            case 256: return launch_sweep_inst<9, FILTER, 4>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);
+            case 512: return launch_sweep_inst<9, FILTER, 8>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);
+            case 640: return launch_sweep_inst<9, FILTER, 10>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);      // RN50x4 (C3): 320 fragment VGPRs of the 512
             default: break;
         }
     }
     const size_t qbytes = ((size_t)64 * (D * 2 + 16) + 1023) / 1024 * 1024;
     const size_t room = (size_t)160 * 1024 - qbytes - QUEUE_BYTES;
     const int stages = (int)(room / (4 * STAGE_BYTES));
-    if (stages >= 5) return launch_sweep_inst<5, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
-    if (stages >= 4) return launch_sweep_inst<4, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
-    if (stages >= 3) return launch_sweep_inst<3, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf);
+    if (stages >= 5) return launch_sweep_inst<5, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);
+    if (stages >= 4) return launch_sweep_inst<4, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);
+    if (stages >= 3) return launch_sweep_inst<3, FILTER, 0>(q, g, scores, ld, B, N, D, S, R, filt, gate, s, zf, tmax, ldt);
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_sweep_bf16(const float* q, const unsigned short* g, float* scores, long ld, int B, long N, int D, long S, int R,
-                             const TopkFilter* filt, const int* gate, hipStream_t s, int* zero_flags) {
+                             const TopkFilter* filt, const int* gate, hipStream_t s, int* zero_flags, float* tmax, long ldt) {
     if (B <= 0 || N <= 0) return hipSuccess;
     if (B > 128 || (B > 64 && D != 64 && D != 128 && D != 256 && D != 512) || D % 64 || D > 1024 || R < 1) return hipErrorInvalidValue;
-    if (filt) return launch_sweep_mode<true>(q, g, nullptr, 0, B, N, D, 0, 1, *filt, gate, s, nullptr);
+    if (filt) return launch_sweep_mode<true>(q, g, nullptr, 0, B, N, D, 0, 1, *filt, gate, s, nullptr, nullptr, 0);
     if (S <= 0) return hipSuccess;
     if (!scores || (S - 1) * (long)R >= N) return hipErrorInvalidValue;      // every sample run must start inside the gallery
-    return launch_sweep_mode<false>(q, g, scores, ld, B, N, D, S, R, TopkFilter{}, gate, s, zero_flags);
+    if (tmax && (S != N || R != 1 || B > 64 || ldt < (N + ROWS_T - 1) / ROWS_T)) return hipErrorInvalidValue;      // tile maxima: store-all form, one query block
+    return launch_sweep_mode<false>(q, g, scores, ld, B, N, D, S, R, TopkFilter{}, gate, s, zero_flags, tmax, ldt);
 }
 
 }  // namespace fern

@@ -999,6 +999,217 @@ __global__ __launch_bounds__(256) void topk_dense_rescore_kernel(const float* ap
     }
 }
 
+// ---- dense form on tile maxima (galleries past TILES_MIN_N rows) -------------------------------------------------------------------
+// topk_dense_rescore_kernel walks a query's whole score row twice with ONE workgroup: 2 x 184 KB at C2 (13 us of its 24), 2 x 800 KB
+// at C3 (~60 of ~75).  Here the sweep also leaves tmax[b][t] = the largest score of gallery tile t (32 consecutive rows: one wave tile
+// of sweep_bf16_kernel, reduced across its lanes), and the kernel reads N / 32 numbers instead of N:
+//   bound   every thread's maximum over its strided share of the TILE maxima -> per wave the ceil(K' / 4)-th largest -> l0 = the
+//           smallest of the four: K' distinct tiles hold a score >= l0 (K' = K + 1 when a row is excluded: it may be one of them),
+//           so T~ (the K-th best approximate score) >= l0;
+//   tiles   the tiles with tmax >= l0 - margin (~one per collected row: ~130 of 1 438 at C2) are listed, per wave, by ballot;
+//   gather  only those tiles' scores are read (128 bytes each, all loads of the workgroup in flight at once) and the rows at or above
+//           l0 - margin collected -- the same set the row walk collected;
+//   then T~, survivors, exact rescoring and ranking exactly as topk_dense_rescore_kernel.
+// A margin that is not finite (NaN / inf anywhere in the query or the gallery: launch_gallery_prepare poisons meta) sends the query to
+// the exact ranking at once; with a finite margin every score is finite (|s~| <= ||q|| G~ (1 + D 2^-24)), so fmax loses nothing.
+constexpr int TILES_TB = 32;                    // tile maxima a thread holds per batch (8 192 tiles = 262 144 rows per batch)
+constexpr int TILES_SEG = 512;                  // listed tiles per wave
+constexpr long TILES_MIN_N = 16384;             // below: the row walk (a wave needs ceil(K' / 4) tiles of its own for the bound)
+template <bool HOLD>
+__global__ __launch_bounds__(256) void topk_tiles_rescore_kernel(const float* approx, long ld, const float* tmax, long ldt, long N, const float* q,
+                                                                 const float* gallery, int D, BoundMargin mg, int K, const int* exclude, long exclude_off,
+                                                                 long idx_offset, float* out_scores, int* out_idx, u64* thr_key, int* flags, int* state,
+                                                                 int* done, int inline_exact) {
+    __shared__ u64 wlists[4][64];
+    __shared__ __attribute__((aligned(16))) u64 ckey[4][DENSE_SEG + 2];
+    __shared__ __attribute__((aligned(16))) float tiles[RESC_TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) u64 x_key[RESC_MAX + 4];
+    __shared__ unsigned surv[RESC_MAX];
+    __shared__ __attribute__((aligned(16))) float qrow[1024];
+    __shared__ int tlist[4][TILES_SEG];
+    __shared__ int red[32];
+    __shared__ unsigned wmax[4];
+    __shared__ int wcnt[4], tcnt[4];
+    __shared__ int nsurv;
+    __shared__ unsigned kth_hi;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = approx + (long)b * ld;
+    const float* trow = tmax + (long)b * ldt;
+    const long ntiles = (N + 31) >> 5;
+    if (tid == 0) { nsurv = 0; kth_hi = 0; state[b] = 0; done[b] = 0; }
+    for (int i = tid; i < D; i += 256) qrow[i] = q[(long)b * D + i];
+    long drop = -1;
+    if (exclude) {
+        const long er = (long)exclude[b] - exclude_off;
+        if (er >= 0 && er < N) drop = er;
+    }
+    // tile maxima: TILES_TB unconditional loads on clamped addresses (topk_dense_rescore_kernel's note), masked afterwards
+    float tv[TILES_TB];
+    auto load_tiles = [&](long base) {
+#pragma unroll
+        for (int u = 0; u < TILES_TB; ++u) {
+            const long t = base + u * 256 + tid;
+            tv[u] = trow[t < ntiles ? t : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < TILES_TB; ++u) tv[u] = base + u * 256 + tid < ntiles ? tv[u] : -INFINITY;
+    };
+    float qa = 0.f, qe = 0.f;
+    for (int i = tid; i < D; i += 256) {
+        const float x = q[(long)b * D + i];
+        const float dd = x - bf16_bits_to_f32(f32_to_bf16_bits(x));
+        qa += x * x;
+        qe += dd * dd;
+    }
+    float fmax_t = -INFINITY;
+    for (long base = 0; base < (HOLD ? 1 : ntiles); base += 256 * TILES_TB) {
+        load_tiles(base);
+#pragma unroll
+        for (int u = 0; u < TILES_TB; u += 2) fmax_t = fmaxf(fmax_t, fmaxf(tv[u], tv[u + 1]));
+    }
+    const unsigned tmx = fmax_t == -INFINITY ? 0u : orderable(fmax_t);      // 0 = "no tile"
+    float margin;
+    {
+        float* fred = reinterpret_cast<float*>(red);
+#pragma unroll
+        for (int x = 32; x >= 1; x >>= 1) { qa += __shfl_xor(qa, x); qe += __shfl_xor(qe, x); }
+        if (lane == 0) { fred[wave] = qa; fred[4 + wave] = qe; }
+        __syncthreads();
+        const float a = fred[0] + fred[1] + fred[2] + fred[3], e = fred[4] + fred[5] + fred[6] + fred[7];
+        const float nq = sqrtf(a), eq = sqrtf(e);
+        const float E = mg.meta[0], Gt = mg.meta[1], G = mg.meta[2];
+        const float eps = (nq * E + eq * Gt) * 1.00390625f + (float)D * 4.76837158203125e-7f * nq * fmaxf(G, Gt);
+        margin = 2.0f * eps * 1.0009765625f;
+    }
+    const unsigned sorted = sort64_desc_u32(tmx, lane);
+    const int tw = (K + (drop >= 0 ? 1 : 0) + 3) / 4;
+    const unsigned vw = (unsigned)__builtin_amdgcn_readlane((int)sorted, tw - 1);
+    if (lane == 0) wmax[wave] = vw;
+    __syncthreads();
+    unsigned l0 = wmax[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) l0 = wmax[w] < l0 ? wmax[w] : l0;
+    u64 fallback_thr = 0;
+    do {
+    if (l0 == 0 || !(margin < INFINITY)) break;      // (uniform) no bound: a wave without ceil(K' / 4) tiles; or no certificate
+    const float cut0 = unorderable(l0) - margin;
+    // the tiles that can hold a row at or above cut0, per wave by ballot
+    int* tl = tlist[wave];
+    int tn = 0;                                      // wave-uniform
+    for (long base = 0; base < (HOLD ? 1 : ntiles); base += 256 * TILES_TB) {
+        if (!HOLD) load_tiles(base);
+#pragma unroll
+        for (int u = 0; u < TILES_TB; ++u) {
+            const bool hit = !(tv[u] < cut0);        // masked positions are -inf < cut0 (cut0 is finite)
+            const u64 m = __ballot(hit);
+            if (m) {
+                const int pos = tn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                if (hit && pos < TILES_SEG) tl[pos] = (int)(base + u * 256 + tid);
+                tn += __popcll(m);
+            }
+        }
+    }
+    if (lane == 0) tcnt[wave] = tn;
+    __syncthreads();
+    const int t0 = tcnt[0], t1 = tcnt[1], t2 = tcnt[2], t3 = tcnt[3];
+    if (t0 > TILES_SEG || t1 > TILES_SEG || t2 > TILES_SEG || t3 > TILES_SEG) {      // near-tie floods: the exact ranking, behind the bound
+        fallback_thr = (u64)orderable(cut0) << 32;
+        break;
+    }
+    const int p1 = t0, p2 = t0 + t1, p3 = p2 + t2, nt = p3 + t3;
+    // gather: 8 lanes x 16 bytes per listed tile, four rounds of loads in flight; hits go to the wave's segment as (score bits, row)
+    u64* seg = ckey[wave];
+    int wn = 0;
+    const int items = nt * 8;
+    for (int e0 = 0; e0 < items; e0 += 1024) {
+        f32x4e val[4];
+        long nn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256 + tid, ec = e < items ? e : 0, slot = ec >> 3;
+            const int w = (slot >= p1) + (slot >= p2) + (slot >= p3);
+            const int tile = tlist[w][slot - (w == 0 ? 0 : w == 1 ? p1 : w == 2 ? p2 : p3)];
+            nn[u] = (long)tile * 32 + (ec & 7) * 4;
+            val[u] = *reinterpret_cast<const f32x4e*>(row + nn[u]);      // ld covers whole tiles (launcher)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = e0 + u * 256 + tid < items;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long n = nn[u] + j;
+                const bool hit = in && n < N && n != drop && !(val[u][j] < cut0);
+                const u64 m = __ballot(hit);
+                if (m) {
+                    const int pos = wn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    if (hit && pos < DENSE_SEG) seg[pos] = make_key(val[u][j], (unsigned)n);
+                    wn += __popcll(m);
+                }
+            }
+        }
+    }
+    const int wkeep = wn < DENSE_SEG ? wn : DENSE_SEG;
+    if (lane < 2) seg[wkeep + lane] = 0;
+    if (lane == 0) wcnt[wave] = wn;
+    __syncthreads();
+    const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+    const int nc = c0 + c1 + c2 + c3;
+    if (c0 > DENSE_SEG || c1 > DENSE_SEG || c2 > DENSE_SEG || c3 > DENSE_SEG) {
+        fallback_thr = (u64)orderable(cut0) << 32;
+        break;
+    }
+    auto key_at = [&](int i) -> u64 {
+        if (i < c0) return ckey[0][i];
+        i -= c0;
+        if (i < c1) return ckey[1][i];
+        i -= c1;
+        if (i < c2) return ckey[2][i];
+        return ckey[3][i - c2];
+    };
+    unsigned khi = 0;
+    if (nc > K) {
+        for (int i = tid; i < nc; i += 256) {
+            const u64 key = key_at(i);
+            int rank = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int cw = w == 0 ? c0 : w == 1 ? c1 : w == 2 ? c2 : c3;
+                for (int j0 = 0; j0 < cw; j0 += 2) {
+                    const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(&ckey[w][j0]);
+                    rank += (a.x > key) + (a.y > key);
+                }
+            }
+            if (rank == K - 1) kth_hi = (unsigned)(key >> 32);
+        }
+        __syncthreads();
+        khi = kth_hi;
+    }
+    const float cut = khi != 0 ? unorderable(khi) - margin : -INFINITY;
+    for (int i = tid; i < nc; i += 256) {
+        const u64 key = key_at(i);
+        if (!(unorderable((unsigned)(key >> 32)) < cut)) {
+            const int p = atomicAdd(&nsurv, 1);
+            if (p < RESC_MAX) surv[p] = 0xFFFFFFFFu - (unsigned)key;
+        }
+    }
+    __syncthreads();
+    const int ns = nsurv;
+    if (ns > RESC_MAX) {
+        fallback_thr = khi != 0 ? (u64)orderable(cut) << 32 : 0ull;
+        break;
+    }
+    rescore_and_rank(surv, ns, qrow, gallery, D, tiles, x_key, K, idx_offset, out_scores + (long)b * K, out_idx + (long)b * K);
+    return;
+    } while (0);
+    if (inline_exact) {
+        exact_topk_inline(qrow, gallery, N, D, drop, K, idx_offset, out_scores + (long)b * K, out_idx + (long)b * K, wlists);
+    } else if (tid == 0) {
+        state[b] = 1;
+        flags[0] = 1;
+        thr_key[b] = fallback_thr;
+    }
+}
+
 // ---- exact pass ---------------------------------------------------------------------------------------------------------------
 // Runs (gated on flags[0]) for the queries the select kernel sent here.  One launch of `groups` workgroups; workgroup g, wave w
 // owns the 32-row gallery tiles (4g + w) + j * 4 * groups.  The flagged queries are compacted (in query order) and taken 32 AT A
@@ -1154,7 +1365,7 @@ hipError_t launch_topk_sample_bound(const float* scores, long ld, int B, long S,
     if (K < 1 || K > 64 || S < 0 || R < 1 || (q && (!meta || !margin_out || D <= 0))) return hipErrorInvalidValue;
     const BoundMargin mg{q, D, meta, margin_out};
     // keys per thread of the bisection (registers): the plan caps S at 32768 (api.hip: rank_plan)
-    auto go = [&](auto kern, int nt) { hipLaunchKernelGGL(kern, dim3(B), dim3(nt), 0, s, scores, ld, S, R, K, exclude, exclude_off, thr_key, count, flags, state, mg); };
+    auto go = [&](auto kern, int nt) { FERN_LAUNCH(kern, dim3(B), dim3(nt), 0, s, scores, ld, S, R, K, exclude, exclude_off, thr_key, count, flags, state, mg); };
     if (S <= 1024) go(topk_sample_bound_kernel<4, 256>, 256);
     else if (S <= 4096) go(topk_sample_bound_kernel<16, 256>, 256);
     else if (S <= 16 * 1024) go(topk_sample_bound_kernel<16, 1024>, 1024);
@@ -1167,7 +1378,7 @@ hipError_t launch_topk_candidates(const TopkFilter& f, int B, int K, long idx_of
                                   int* state, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (K < 1 || K > 64 || f.cap < 1 || f.cap > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(topk_candidates_kernel, dim3(B), dim3(256), 0, s, f, K, idx_offset, out_scores, out_idx, flags, state);
+    FERN_LAUNCH(topk_candidates_kernel, dim3(B), dim3(256), 0, s, f, K, idx_offset, out_scores, out_idx, flags, state);
     return hipGetLastError();
 }
 
@@ -1181,10 +1392,21 @@ hipError_t launch_topk_rescore(const TopkFilter& f, const float* q, const float*
 
 hipError_t launch_topk_dense_rescore(const float* approx, long ld, long N, const float* q, const float* gallery, int D, const float* meta,
                                      int B, int K, const int* exclude, long exclude_off, long idx_offset, float* out_scores,
-                                     int* out_idx, unsigned long long* thr_key, int* flags, int* state, int* done, hipStream_t s, int inline_exact) {
+                                     int* out_idx, unsigned long long* thr_key, int* flags, int* state, int* done, hipStream_t s, int inline_exact,
+                                     const float* tmax, long ldt) {
     if (B <= 0) return hipSuccess;
     if (K < 1 || K > 64 || D < 64 || D % 64 || D > 1024 || N < 1 || (ld & 3) || !meta) return hipErrorInvalidValue;
     const BoundMargin mg{q, D, meta, nullptr};
+    if (tmax && N >= TILES_MIN_N) {                  // selection on the sweep's tile maxima
+        if (ld < ((N + 31) & ~31L) || ldt < (N + 31) / 32) return hipErrorInvalidValue;
+        if ((N + 31) / 32 <= 256L * TILES_TB)
+            FERN_LAUNCH(topk_tiles_rescore_kernel<true>, dim3(B), dim3(256), 0, s, approx, ld, tmax, ldt, N, q, gallery, D, mg, K, exclude, exclude_off,
+                        idx_offset, out_scores, out_idx, thr_key, flags, state, done, inline_exact);
+        else
+            FERN_LAUNCH(topk_tiles_rescore_kernel<false>, dim3(B), dim3(256), 0, s, approx, ld, tmax, ldt, N, q, gallery, D, mg, K, exclude, exclude_off,
+                        idx_offset, out_scores, out_idx, thr_key, flags, state, done, inline_exact);
+        return hipGetLastError();
+    }
     // lab switch (tools/rank_bench.py): FERN_DENSE_STOP=k ends the kernel after phase k (results are then garbage) to attribute its time
     static const int stop = [] { const char* e = getenv("FERN_DENSE_STOP"); return e ? atoi(e) : 0; }();
     const long n4 = N & ~3L;
@@ -1206,11 +1428,11 @@ hipError_t launch_rank_exact(const float* q, const void* gallery, int gallery_bf
     if (B <= 0 || N <= 0) return hipSuccess;
     if (K < 1 || K > 64 || groups < 1 || B > 1024 || D % (gallery_bf16 ? 16 : 8)) return hipErrorInvalidValue;
     if (gallery_bf16)
-        hipLaunchKernelGGL(rank_exact_kernel<true>, dim3(groups), dim3(256), 0, s, q, gallery, B, N, D, K, state, thr_key, exclude, exclude_off,
-                           idx_offset, partial, done, out_scores, out_idx, gate);
+        FERN_LAUNCH(rank_exact_kernel<true>, dim3(groups), dim3(256), 0, s, q, gallery, B, N, D, K, state, thr_key, exclude, exclude_off,
+                    idx_offset, partial, done, out_scores, out_idx, gate);
     else
-        hipLaunchKernelGGL(rank_exact_kernel<false>, dim3(groups), dim3(256), 0, s, q, gallery, B, N, D, K, state, thr_key, exclude, exclude_off,
-                           idx_offset, partial, done, out_scores, out_idx, gate);
+        FERN_LAUNCH(rank_exact_kernel<false>, dim3(groups), dim3(256), 0, s, q, gallery, B, N, D, K, state, thr_key, exclude, exclude_off,
+                    idx_offset, partial, done, out_scores, out_idx, gate);
     return hipGetLastError();
 }
 

@@ -319,6 +319,20 @@ class FernEngine:
                                           int(idx_offset), _ptr(ex), _stream()), "fern_sim_topk")
         return scores, idx
 
+    def sweep_bf16_scores(self, q, pg: "PreparedGallery", tile_max: bool = True):
+        """The pre-filter's approximate scores [B,N] (bf16 operands, fp32 accumulation) and, with `tile_max`, the largest score of
+        every 32 consecutive gallery rows [B, ceil(N/32)] -- what the dense form of the ranking stage selects on
+        (include/fern.h: fern_sweep_bf16_scores)."""
+        q = self._f32(q)
+        n, d = pg.shape
+        b = q.shape[0]
+        scores = self._empty(b, n)
+        nt = (n + 31) // 32
+        tmax = self._empty(b, nt) if tile_max else None
+        _lib.check(self.lib.fern_sweep_bf16_scores(self._h, _ptr(q), _ptr(pg.bf16), b, n, d, _ptr(scores), n, _ptr(tmax), nt, _stream()),
+                   "fern_sweep_bf16_scores")
+        return (scores, tmax) if tile_max else scores
+
     def set_rank_strategy(self, strategy) -> None:
         """Form of the PreparedGallery ranking stage: "auto" (cost model), "plain" (fp32 sweep), "lists", "dense" -- identical results
         (include/fern.h: fern_rank_strategy); a tuning / test knob."""

@@ -139,10 +139,12 @@ typedef struct {
     double attn_ms;        /* attention launches, per-dispatch begin -> end timestamps like gemm_ms */
     double attn_flops;
     int64_t attn_launches;
-    double topk_ms;        /* the rest of the ranking stage: sample pass, bound, candidate selection, gated exact pass and every launch
-                              boundary of the stage = (one stream-marker interval around the whole stage) - sweep_ms */
+    double topk_ms;        /* the rest of the ranking stage: sample pass, bound, candidate selection / rescoring, gated exact pass and every
+                              launch boundary between them = (the stage's interval) - sweep_ms.  The interval is the stage's first dispatch
+                              begin -> last dispatch end (dispatch timestamps, like gemm_ms) for fern_sim_topk_prefiltered and
+                              fern_sim_topk_bf16, one stream-marker interval for the plain fern_sim_topk */
     int64_t topk_launches;
-    double sweep_ms;       /* the filtered similarity sweep inside fern_sim_topk / fern_sim_topk_bf16: the kernel's own duration */
+    double sweep_ms;       /* the full-gallery similarity sweep inside fern_sim_topk / _bf16 / _prefiltered: the kernel's own duration */
     double sweep_bytes;    /* algorithmic bytes of those sweeps: N*D*s_g + B*D*4 + B*K*8 */
     int64_t sweep_launches;
     double gemm_fp8_ms;    /* fp8-operand GEMM launches (FERN_PREC_FP8, fern_gemm_fp8): not included in gemm_* / gemm_bf16_* */
@@ -288,6 +290,13 @@ typedef enum {
     FERN_RANK_DENSE = 3    /* bf16 sweep storing its [B, N] scores -> one select + rescore kernel: small galleries (N <= 262144) */
 } fern_rank_strategy;
 FERN_API int fern_rank_set_strategy(fern_ctx* ctx, int strategy);
+/* The bf16 sweep on its own: scores[b * ld + n] = the fp32-accumulated dot product of bf16(q[b]) and gallery_bf16[n] (v_mfma_f32_32x32x16_bf16,
+ * k ascending) for every n < N -- the APPROXIMATE score the pre-filter selects on; tile_max (may be NULL) [B, ldt]: per 32 consecutive
+ * gallery rows the largest of those scores (one wave tile of the sweep, reduced across its lanes), which is what the dense form of
+ * fern_sim_topk_prefiltered reads instead of the rows.  ld >= N, ldt >= ceil(N / 32); D % 64 == 0, D <= 768.  For tests of the
+ * certificate (|exact - approximate| <= eps_b) and for callers that want the whole approximate score matrix. */
+FERN_API int fern_sweep_bf16_scores(fern_ctx* c, const float* q, const uint16_t* gallery_bf16, int B, int64_t N, int D, float* scores, int64_t ld,
+                                    float* tile_max, int64_t ldt, void* stream);
 /* scores of explicitly named gallery rows (CIRR subset ranking, run/test/test_cirr.py:64-66);
  * idx < 0 -> -inf */
 FERN_API int fern_gather_scores(fern_ctx* ctx, const float* q /*[B,D]*/, const float* gallery /*[N,D]*/,

@@ -187,3 +187,85 @@ def test_prepared_gallery_is_refilled_in_place_and_feeds_the_pipeline_entry_poin
     assert torch.equal(engine.gather_scores(q, pg2, idx), engine.gather_scores(q, g2, idx))
     s, i = engine.sim_topk(q, engine.prepare_gallery(g2[:0]), 10)        # an empty shard
     assert (i.cpu() == -1).all()
+
+
+# ---- dense form on the sweep's tile maxima (galleries of >= 16 384 rows, one 64-query block per sweep) ---------------------------------
+@pytest.mark.parametrize("B,N,D", [(64, 46_000, 512), (5, 16_411, 640), (64, 100_001, 64), (3, 31, 128)])
+def test_sweep_scores_are_the_bf16_products_and_tile_maxima_the_maxima_of_32_rows(_session_engine, B, N, D):
+    """fern_sweep_bf16_scores: every approximate score is the bf16 operands' dot product (fp32 accumulation: compared with float64 of
+    the same rounded operands), inside the certified eps_b of the exact score; tile_max[b][t] is bit for bit the largest of
+    scores[b][32 t : 32 t + 32] -- the dense form reads those instead of the rows."""
+    eng = _session_engine
+    q, g = _rand(B, D, seed=3 * B + N), _rand(N, D, seed=N - D, scale=D ** -0.5)
+    pg = eng.prepare_gallery(g)
+    scores, tmax = eng.sweep_bf16_scores(q, pg)
+    scores, tmax = scores.cpu(), tmax.cpu()
+    ref = (q.bfloat16().double() @ g.bfloat16().double().T)
+    assert (scores.double() - ref).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
+    pad = torch.full((B, (-N) % 32), -float("inf"))
+    want = torch.cat([scores, pad], dim=1).view(B, -1, 32).max(dim=2).values
+    assert torch.equal(tmax, want)
+    meta = pg.meta.cpu().double()
+    eps = q.double().norm(dim=1) * meta[0] + (q - q.bfloat16().float()).double().norm(dim=1) * meta[1]
+    exact = q.double() @ g.double().T
+    assert ((scores.double() - exact).abs().max(dim=1).values <= eps * 1.01 + 1e-6).all()
+
+
+@pytest.mark.parametrize("B,N,D", [(5, 300_017, 64), (70, 140_000, 64), (1, 16_384, 64), (33, 262_145, 64)])
+def test_tile_maxima_form_beyond_one_register_batch_and_with_split_query_blocks(engine, B, N, D):
+    """N / 32 beyond the 8 192 tile maxima a workgroup holds in registers (the re-reading instance); 65..128 queries on a gallery of
+    >= 131 072 rows (the sweep runs one 64-query block per launch so that it can leave tile maxima); the smallest gallery of the form;
+    excluded rows = each query's best row, in tiles spread over the whole gallery.  Bits of the fp32 stage, every time."""
+    q, g = _rand(B, D, seed=B + N), _rand(N, D, seed=N + D, scale=D ** -0.5)
+    ex_rows = [(b * 7919 * 31 + 5) % N for b in range(B)]
+    for b, row in enumerate(ex_rows):
+        g[row] = q[b] * 2.0
+    ex = torch.tensor(ex_rows, dtype=torch.int32)
+    pg = engine.prepare_gallery(g)
+    for exclude in (ex, None):
+        s, i = engine.sim_topk(q, pg, 50, exclude_idx=exclude)
+        s0, i0 = engine.sim_topk(q, g, 50, exclude_idx=exclude)
+        assert torch.equal(s, s0) and torch.equal(i, i0)
+    assert i[:, 0].cpu().tolist() == ex_rows
+    nq = min(B, 6)
+    cs, ci = chain.chain_topk(q[:nq].numpy(), g.numpy(), 50)
+    assert _same_bits(s[:nq], i[:nq], cs, ci)
+
+
+def test_more_listed_tiles_than_the_kernel_holds_takes_the_exact_ranking(engine):
+    """6 000 rows within 1e-4 of each other spread over ~2 700 of the gallery's 3 125 tiles: every wave lists more than its 512 tiles and
+    the query is ranked exactly behind the bound it had reached -- the chain's result, bit for bit."""
+    d, n, k, near = 128, 100_000, 50, 6000
+    base = torch.nn.functional.normalize(_rand(1, d, 7), dim=-1)
+    q = torch.nn.functional.normalize(base + 0.02 * _rand(4, d, 8) * d ** -0.5, dim=-1)
+    g = torch.nn.functional.normalize(_rand(n, d, 9), dim=-1)
+    rows = torch.randperm(n, generator=torch.Generator().manual_seed(10))[:near]
+    g[rows] = torch.nn.functional.normalize(base + 0.03 * _rand(near, d, 11) * d ** -0.5, dim=-1)
+    assert len(set((rows // 32).tolist())) > 2048
+    cs, ci = chain.chain_topk(q.numpy(), g.numpy(), k)
+    s, i = engine.sim_topk(q, engine.prepare_gallery(g), k)
+    assert _same_bits(s, i, cs, ci)
+
+
+def test_gallery_past_the_inline_exact_limit_sends_floods_to_the_gated_exact_pass(engine):
+    """300 000 x 128 fp32 = 154 MB: beyond what one workgroup may stream by itself, so a query without room (all rows equal: every tile is
+    listed) is flagged for the gated exact-pass launch instead; ties break by index."""
+    d, k, n = 128, 50, 300_000
+    q = _int_unit(3, d, 5)
+    g = _int_unit(1, d, 6).repeat(n, 1)
+    g[123_456] = torch.sign(q[1]) / 8.0 + (q[1] == 0) * 0.125           # one row stands out for query 1
+    rs, ri = orank.cosine_topk(q, g, k)
+    s, i = engine.sim_topk(q, engine.prepare_gallery(g), k)
+    assert torch.equal(i.cpu(), ri) and torch.equal(s.cpu(), rs)
+
+
+def test_non_finite_rows_leave_no_certificate_and_the_stage_falls_back_to_the_exact_ranking(engine):
+    """An inf / NaN gallery row makes the margin non-finite: nothing is certified, every query takes the exact ranking -- the same bits as
+    the fp32 stage on that gallery."""
+    n, d, k = 40_000, 64, 50
+    q, g = _rand(6, d, 1), _rand(n, d, 2, d ** -0.5)
+    g[777, 3] = float("inf")
+    pg = engine.prepare_gallery(g)
+    s, i = engine.sim_topk(q, pg, k)
+    s0, i0 = engine.sim_topk(q, g, k)
+    assert torch.equal(i, i0) and torch.equal(s.view(torch.int32), s0.view(torch.int32))
