@@ -142,8 +142,16 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
     if (!FILTER && zero_flags && blockIdx.x == 0 && threadIdx.x == 0) { zero_flags[0] = 0; zero_flags[1] = 0; }
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int q_stride = D * 2 + 16;                               // bytes; +16 spreads rows over the banks
-    // KCH > 0, QB = 1: the ring overlays the query image; QB = 2: the image of queries 64..127 stays, the ring follows it
-    unsigned char* ring_base = (KCH > 0 && QB == 1) ? smem : smem + ((64 * q_stride + 1023) & ~1023);
+    // KCH > 0, QB = 1: the ring overlays the query image; QB = 2: the image of queries 64..127 stays, the ring follows it.
+    // The ring is SLOT-major (slot s of wave w at (4 s + w) stages) and, in the overlay form, the image sits on the LAST slots: the first
+    // EARLY slots of every wave are free from the start, so the gallery's first stages are requested BEFORE the queries are staged
+    // (their HBM round trip, ~2-4 us at C2's 33 MB burst, used to begin only after the ~4 us of query staging).
+    constexpr bool OVERLAY = KCH > 0 && QB == 1;
+    constexpr int QIMG = OVERLAY ? ((64 * (128 * KCH + 16) + 1023) & ~1023) : 0;
+    constexpr int EARLY_ROOM = OVERLAY ? (4 * STAGES * STAGE_BYTES + QUEUE_BYTES - QIMG) / (4 * STAGE_BYTES) : 0;
+    constexpr int EARLY = EARLY_ROOM > STAGES - 1 ? STAGES - 1 : EARLY_ROOM;
+    unsigned char* img = smem + (OVERLAY ? EARLY * 4 * STAGE_BYTES : 0);
+    unsigned char* ring_base = OVERLAY ? smem : smem + ((64 * q_stride + 1023) & ~1023);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,24 +168,27 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = (short)f32_to_bf16_rne(a[e]); v[4 + e] = (short)f32_to_bf16_rne(b[e]); }
             }
-            *reinterpret_cast<bf16x8*>(smem + row * q_stride + c8 * 2) = v;
+            *reinterpret_cast<bf16x8*>(img + row * q_stride + c8 * 2) = v;
         }
     };
-    stage_queries(0);
-    __syncthreads();
     constexpr int NFR = KCH > 0 ? 8 * KCH : 1;
     bf16x8 afr[NFR];
-    if (KCH > 0) {
+    // (the register-resident form stages its queries further down, behind the first gallery requests)
+    if (!OVERLAY) {
+        stage_queries(0);
+        __syncthreads();
+        if (KCH > 0) {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int kidx = 0; kidx < 4 * KCH; ++kidx)
-                afr[tm * 4 * KCH + kidx] = *reinterpret_cast<const bf16x8*>(smem + (tm * 32 + l31) * q_stride + (kidx * 16 + lh * 8) * 2);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();                                           // every wave holds its fragments: the image may be overwritten
-        if (QB == 2) {                                             // ... by the second query block, which stays in LDS
-            stage_queries(64);
-            __syncthreads();
+                for (int kidx = 0; kidx < 4 * KCH; ++kidx)
+                    afr[tm * 4 * KCH + kidx] = *reinterpret_cast<const bf16x8*>(img + (tm * 32 + l31) * q_stride + (kidx * 16 + lh * 8) * 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();                                       // every wave holds its fragments: the image may be overwritten
+            if (QB == 2) {                                         // ... by the second query block, which stays in LDS
+                stage_queries(64);
+                __syncthreads();
+            }
         }
     }
 
@@ -189,17 +200,6 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
     unsigned long long* qkey = reinterpret_cast<unsigned long long*>(qbase + wave * QCAP * 12);
     int* qq = reinterpret_cast<int*>(qbase + wave * QCAP * 12 + QCAP * 8);
     int qlen = 0;                                                  // wave-uniform
-    if (FILTER) {
-        if (tid < 64 * QB) thr_lds[tid] = tid < B ? filt.thr_key[tid] : ~0ull;
-        if (QB == 2 && tid < 128) thr_f[tid] = filter_bound(tid < B ? filt.thr_key[tid] : ~0ull);
-        __syncthreads();
-        if (QB == 1) {
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) bound[tm][r] = filter_bound(thr_lds[tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]);
-        }
-    }
     // append the queued survivors to their lists: one batch of returning atomics per <= 64 entries
     auto flush = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the queue writes of every lane have landed
@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
         }
     };
 
-    unsigned char* ring = ring_base + wave * (STAGES * STAGE_BYTES);
+    constexpr int SLOT_BYTES = 4 * STAGE_BYTES;                     // slot-major: the four waves' stages of one slot are adjacent
+    unsigned char* ring = ring_base + wave * STAGE_BYTES;
     const int kchunks = KCH > 0 ? KCH : D / KSTAGE;                // stages per tile (a compile-time power of two on the register path)
     const long rows_total = FILTER ? N : S;
     const long ntiles = (rows_total + ROWS_T - 1) / ROWS_T;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
         lane_off[p] = (unsigned)((row * D + (((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2);      // bytes; 32 rows x D <= 64 KiB
     }
     auto issue_next = [&]() {
-        unsigned char* dst = ring + slot_issue * STAGE_BYTES;
+        unsigned char* dst = ring + slot_issue * SLOT_BYTES;
         if ((FILTER || R == 1) && (t_issue + 1) * ROWS_T <= (FILTER ? N : S)) {      // whole tile of consecutive rows (the full sweep; the store-all form S = N, R = 1)
             const unsigned char* base = reinterpret_cast<const unsigned char*>(g) + (t_issue * ROWS_T * D + (long)kc_issue * KSTAGE) * 2;
 #pragma unroll
@@ -294,7 +295,52 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    for (int i = 0; i < STAGES - 1 && i < nstages; ++i) issue_next();
+    int pre = 0;
+    if (OVERLAY) {
+        // the queries' loads go out FIRST (vmcnt retires in order: behind the gallery requests they would wait for those too), then
+        // the gallery's first EARLY stages, then the queries are rounded into the image and every wave takes its fragments
+        constexpr int NQ = KCH > 0 ? 2 * KCH : 1;                   // 64 rows x D / 8 chunks over 256 threads
+        f32x4 qa[NQ][2];
+#pragma unroll
+        for (int it = 0; it < NQ; ++it) {
+            const int i = tid + 256 * it, row = i / (8 * KCH), c8 = (i % (8 * KCH)) * 8;
+            const float* src = q + (long)(row < B ? row : B - 1) * D + c8;      // unconditional (clamped) loads: a guarded load waits for itself
+            qa[it][0] = *reinterpret_cast<const f32x4*>(src);
+            qa[it][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+        for (; pre < EARLY && pre < nstages; ++pre) issue_next();
+#pragma unroll
+        for (int it = 0; it < NQ; ++it) {
+            const int i = tid + 256 * it, row = i / (8 * KCH), c8 = (i % (8 * KCH)) * 8;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = row < B ? (short)f32_to_bf16_rne(qa[it][0][e]) : (short)0;
+                v[4 + e] = row < B ? (short)f32_to_bf16_rne(qa[it][1][e]) : (short)0;
+            }
+            *reinterpret_cast<bf16x8*>(img + row * q_stride + c8 * 2) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int kidx = 0; kidx < 4 * KCH; ++kidx)
+                afr[tm * 4 * KCH + kidx] = *reinterpret_cast<const bf16x8*>(img + (tm * 32 + l31) * q_stride + (kidx * 16 + lh * 8) * 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                           // every wave holds its fragments: the image's slots may be filled
+    }
+    if (FILTER) {
+        if (tid < 64 * QB) thr_lds[tid] = tid < B ? filt.thr_key[tid] : ~0ull;
+        if (QB == 2 && tid < 128) thr_f[tid] = filter_bound(tid < B ? filt.thr_key[tid] : ~0ull);
+        __syncthreads();
+        if (QB == 1) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bound[tm][r] = filter_bound(thr_lds[tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]);
+        }
+    }
+    for (; pre < STAGES - 1 && pre < nstages; ++pre) issue_next();
     const int sw = (l31 >> 1) & 7;
     int slot_read = 0;                                             // ring slot of the stage being consumed
     // one ring stage: refill the slot that was just read, wait for this stage (the newer ones stay in flight), 4 k-steps of MFMAs
@@ -306,7 +352,7 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const unsigned char* st = ring + slot_read * STAGE_BYTES;
+        const unsigned char* st = ring + slot_read * SLOT_BYTES;
         slot_read = slot_read + 1 == STAGES ? 0 : slot_read + 1;
 #pragma unroll
         for (int ks = 0; ks < KSTAGE / 16; ++ks) {
