@@ -819,8 +819,11 @@ def main():
                         "the [B, N] score matrix is never stored")
     else:
         sweep_kernel = ("certified bf16 pre-filter + exact fp32 rescoring of an fp32 gallery (fern_sim_topk_prefiltered): sweep_bf16_kernel over the "
-                        "prepared bf16 copy, then topk_dense_rescore_kernel (small galleries: the sweep stores its [B, N] approximate scores) or "
-                        "sample bound - margin + candidate lists + topk_rescore_kernel (large ones); scores and order are the fp32 fma chain's")
+                        "prepared bf16 copy, then one select-and-rescore kernel (dense form: the sweep stores its [B, N] approximate scores and, per "
+                        "32 gallery rows, their maximum -- topk_tiles_rescore_kernel selects on those maxima from 16 384 rows up, "
+                        "topk_dense_rescore_kernel walks the rows below) or sample bound - margin + candidate lists + topk_rescore_kernel (galleries "
+                        "whose score matrix would be real traffic); scores and order are the fp32 fma chain's.  stage_us = first dispatch begin -> "
+                        "last dispatch end of the stage (dispatch timestamps)")
     alg_rank_bytes = float(n_gal) * D * (2 if w["bf16_gallery"] else 4) + B * D * 4 + B * K * 8
     rank_roof = sweep_block(st, prof_steps, sweep_kernel, alg_rank_bytes)
     rank_plain_roof = None

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
     constexpr bool OVERLAY = KCH > 0 && QB == 1;
     constexpr int QIMG = OVERLAY ? ((64 * (128 * KCH + 16) + 1023) & ~1023) : 0;
     constexpr int EARLY_ROOM = OVERLAY ? (4 * STAGES * STAGE_BYTES + QUEUE_BYTES - QIMG) / (4 * STAGE_BYTES) : 0;
-    constexpr int EARLY = EARLY_ROOM > STAGES - 1 ? STAGES - 1 : EARLY_ROOM;
+    constexpr int EARLY = !OVERLAY ? STAGES - 1 : EARLY_ROOM > STAGES - 1 ? STAGES - 1 : EARLY_ROOM;      // (ring next to the image: every slot is free)
     unsigned char* img = smem + (OVERLAY ? EARLY * 4 * STAGE_BYTES : 0);
     unsigned char* ring_base = OVERLAY ? smem : smem + ((64 * q_stride + 1023) & ~1023);
 
@@ -173,23 +173,10 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
     };
     constexpr int NFR = KCH > 0 ? 8 * KCH : 1;
     bf16x8 afr[NFR];
-    // (the register-resident form stages its queries further down, behind the first gallery requests)
-    if (!OVERLAY) {
+    // (the register-resident forms stage their queries further down, behind the first gallery requests)
+    if (KCH == 0) {
         stage_queries(0);
         __syncthreads();
-        if (KCH > 0) {
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int kidx = 0; kidx < 4 * KCH; ++kidx)
-                    afr[tm * 4 * KCH + kidx] = *reinterpret_cast<const bf16x8*>(img + (tm * 32 + l31) * q_stride + (kidx * 16 + lh * 8) * 2);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __syncthreads();                                       // every wave holds its fragments: the image may be overwritten
-            if (QB == 2) {                                         // ... by the second query block, which stays in LDS
-                stage_queries(64);
-                __syncthreads();
-            }
-        }
     }
 
     // per-query bounds of the filter, laid out like the accumulator registers (query = tm*32 + (r&3) + 8(r>>2) + 4 lh)
@@ -296,7 +283,7 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
     int pre = 0;
-    if (OVERLAY) {
+    if (KCH > 0) {
         // the queries' loads go out FIRST (vmcnt retires in order: behind the gallery requests they would wait for those too), then
         // the gallery's first EARLY stages, then the queries are rounded into the image and every wave takes its fragments
         constexpr int NQ = KCH > 0 ? 2 * KCH : 1;                   // 64 rows x D / 8 chunks over 256 threads
@@ -327,7 +314,11 @@ __global__ __launch_bounds__(256) void sweep_bf16_kernel(const float* q, const u
             for (int kidx = 0; kidx < 4 * KCH; ++kidx)
                 afr[tm * 4 * KCH + kidx] = *reinterpret_cast<const bf16x8*>(img + (tm * 32 + l31) * q_stride + (kidx * 16 + lh * 8) * 2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();                                           // every wave holds its fragments: the image's slots may be filled
+        __syncthreads();                                           // every wave holds its fragments: the image's slots may be filled ...
+        if (QB == 2) {                                             // ... or the image overwritten by the second query block, which stays in LDS
+            stage_queries(64);
+            __syncthreads();
+        }
     }
     if (FILTER) {
         if (tid < 64 * QB) thr_lds[tid] = tid < B ? filt.thr_key[tid] : ~0ull;

@@ -32,7 +32,7 @@ def is_filter_gemm(name):      # gemm_f32_glds_kernel<BM, BN, WM, WN, BKT, MINW,
 
 
 RANK_KERNELS = ("sweep_bf16_kernel", "topk_sample_bound_kernel", "topk_candidates_kernel", "topk_rescore_kernel", "topk_dense_rescore_kernel",
-                "rank_exact_kernel")
+                "topk_tiles_rescore_kernel", "rank_exact_kernel")
 
 
 def summarise(rows, scale):
@@ -49,9 +49,9 @@ def summarise(rows, scale):
         if is_filter_gemm(name):
             sweep_ids.add(r[0])
         if "sweep_bf16_kernel" in name:
-            # the full pass of a call: the filter form, or the store-all form (the dense pre-filter: followed by topk_dense_rescore_kernel)
+            # the full pass of a call: the filter form, or the store-all form (the dense pre-filter: followed by topk_dense_rescore_kernel / topk_tiles_rescore_kernel)
             nxt = rows[i + 1][1] if i + 1 < len(rows) else ""
-            if re.search(r"sweep_bf16_kernel<\d+,\s*true", name) or "topk_dense_rescore_kernel" in nxt or "sweep_bf16_kernel" in nxt:
+            if re.search(r"sweep_bf16_kernel<\d+,\s*true", name) or "topk_dense_rescore_kernel" in nxt or "topk_tiles_rescore_kernel" in nxt or "sweep_bf16_kernel" in nxt:
                 sweep_ids.add(r[0])
     fam = lambda key: [r for r in rows if key in r[1] and r[0] not in rank_ids]  # noqa: E731
     gemm, mx8, b16 = fam("gemm_f32"), fam("gemm_mx8_kernel"), fam("gemm_bf16_glds_kernel")
