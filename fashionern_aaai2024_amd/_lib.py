@@ -89,6 +89,7 @@ SIGNATURES = {
     "fern_tuner_export": (c_i64, [C.c_char_p, c_i64]),
     "fern_tuner_import": (c_int, [C.c_char_p]),
     "fern_tuner_set_concurrency": (c_int, [c_int]),
+    "fern_tuner_force_config": (c_int, [C.c_char_p, c_int]),
     "fern_ws_generation": (C.c_uint64, [c_void_p]),
 }
 

@@ -2110,6 +2110,16 @@ extern "C" int fern_tuner_set_concurrency(int lanes) {
     return FERN_OK;
 }
 
+// Force ONE tile configuration of a GEMM family, process-wide, until released (cfg < 0): what FERN_GEMM_CFG / FERN_GEMM_SPLIT_CFG /
+// FERN_GEMM_BF16_CFG / FERN_GEMM_FP8_CFG / FERN_GEMM_MX8_CFG do from the environment, switchable at run time so that a test process can walk
+// every variant.  A configuration that cannot serve a call (k tile does not divide K, ...) falls back to the family's own choice.
+extern "C" int fern_tuner_force_config(const char* family, int cfg) {
+    static const char* names[] = {"f32", "f32x3", "bf16", "fp8", "mx8"};
+    for (int f = 0; family && f < 5; ++f)
+        if (!std::strcmp(family, names[f])) return (f < 2 ? gemm_force_cfg(f, cfg) : gemm_bf16_force_cfg(f, cfg)) ? FERN_OK : fail(FERN_ERR_ARG, "fern_tuner_force_config");
+    return fail(FERN_ERR_ARG, "fern_tuner_force_config: family is one of f32, f32x3, bf16, fp8, mx8");
+}
+
 extern "C" int fern_prof_enable(fern_ctx* c, int on) {
     if (!c) return fail(FERN_ERR_ARG, "fern_prof_enable: ctx is NULL");
     c->prof_on = on != 0;

@@ -15,6 +15,7 @@
 //     ds_read_b128 feeds four MFMAs; both operands use the same permutation, so the sum is unchanged;
 //   * workgroup ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
 #include "kernels.h"
+#include <atomic>
 #include "gemm_epilogue.h"
 
 #include <algorithm>
@@ -818,12 +819,23 @@ static const TileCfg kCfgs[] = {
 constexpr int kNumAuto = 4;      // configs the heuristic may pick
 constexpr int kNumCfgs = 16;
 
-static int forced_cfg() {
-    static int v = [] {
-        const char* e = getenv("FERN_GEMM_CFG");
-        return e ? atoi(e) : -1;
-    }();
+// A forced tile configuration per family: the environment's value (read on first use) unless gemm_force_cfg has set one at run time
+// (fern_tuner_force_config: the test suite walks every variant inside one process).  -2 = not read yet.
+static std::atomic<int> g_force_f32{-2}, g_force_split{-2};
+static int forced_value(std::atomic<int>& slot, const char* var) {
+    int v = slot.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char* e = getenv(var);
+        v = e ? atoi(e) : -1;
+        slot.store(v, std::memory_order_relaxed);
+    }
     return v;
+}
+static int forced_cfg() { return forced_value(g_force_f32, "FERN_GEMM_CFG"); }
+bool gemm_force_cfg(int family, int cfg) {      // family 0: fp32 tiles, 1: f32x3 tiles; cfg < 0: back to the environment's value
+    if (family != 0 && family != 1) return false;
+    (family == 0 ? g_force_f32 : g_force_split).store(cfg < 0 ? -2 : cfg, std::memory_order_relaxed);
+    return true;
 }
 
 static int best_of(int M, int N, int first, int last) {
@@ -1214,10 +1226,7 @@ static hipError_t launch_cfg_split(int c, const GemmParams& p, hipStream_t s) {
 }
 static std::map<ShapeKey, Plan> g_tuned_s;      // guarded by g_tuned_mu; Plan{cfg, 0, cfg} or a mixed plan {20|21, ra, rb}
 static std::map<ShapeKey, Plan>& tuned_split_map() { return g_tuned_s; }
-static int forced_cfg_split() {
-    static int v = [] { const char* e = getenv("FERN_GEMM_SPLIT_CFG"); return e ? atoi(e) : -1; }();
-    return v;
-}
+static int forced_cfg_split() { return forced_value(g_force_split, "FERN_GEMM_SPLIT_CFG"); }
 static int heuristic_split(const GemmParams& p) {
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     return t128 >= 1024 ? 1 : t128 >= 384 ? 0 : 5;

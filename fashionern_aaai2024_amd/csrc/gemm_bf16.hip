@@ -14,6 +14,7 @@
 #include "gemm_epilogue.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -461,12 +462,22 @@ static hipError_t launch_cfg_mx(int c, const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-static int forced_cfg_b() {
-    static int v = [] {
-        const char* e = getenv("FERN_GEMM_BF16_CFG");
-        return e ? atoi(e) : -1;
-    }();
+// forced tile configuration per family (gemm.hip: forced_value has the scheme): environment on first use, gemm_bf16_force_cfg at run time
+static std::atomic<int> g_force_b{-2}, g_force_f8{-2}, g_force_mx{-2};
+static int forced_value_b(std::atomic<int>& slot, const char* var) {
+    int v = slot.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char* e = getenv(var);
+        v = e ? atoi(e) : -1;
+        slot.store(v, std::memory_order_relaxed);
+    }
     return v;
+}
+static int forced_cfg_b() { return forced_value_b(g_force_b, "FERN_GEMM_BF16_CFG"); }
+bool gemm_bf16_force_cfg(int family, int cfg) {      // family 2: bf16, 3: fp8 (per-row scales), 4: block-scaled fp8; cfg < 0: environment
+    if (family < 2 || family > 4) return false;
+    (family == 2 ? g_force_b : family == 3 ? g_force_f8 : g_force_mx).store(cfg < 0 ? -2 : cfg, std::memory_order_relaxed);
+    return true;
 }
 
 // Per-shape tile selection, as in gemm.hip: every configuration produces bit-identical results, so the choice is purely a
@@ -631,8 +642,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
         if (p.epi == EPI_BIAS_RESIDUAL && (p.out_bf16 ? !p.Rb : !p.R)) return hipErrorInvalidValue;
         if (p.out_mx8 && (!p.mxc || p.mxc_rows < p.M || (p.N & 31) || (p.ldc & 15) || ((uintptr_t)p.C & 15) || (p.epi != EPI_BIAS && p.epi != EPI_BIAS_GELU)))
             return hipErrorInvalidValue;
-        static int forced = [] { const char* e = getenv("FERN_GEMM_MX8_CFG"); return e ? atoi(e) : -1; }();
-        int c = forced;
+        int c = forced_value_b(g_force_mx, "FERN_GEMM_MX8_CFG");
         if (c < 0 || c >= kNumCfgsMx) {
             c = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) >= 256 ? 0 : 6;
             if (2.0 * p.M * (double)p.N * p.K >= 2.5e8) {
@@ -643,8 +653,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
         return launch_cfg_mx(c, p, s);
     }
     if (p.fp8) {
-        static int forced = [] { const char* e = getenv("FERN_GEMM_FP8_CFG"); return e ? atoi(e) : -1; }();
-        int c = forced;
+        int c = forced_value_b(g_force_f8, "FERN_GEMM_FP8_CFG");
         if (c < 0 || c >= kNumCfgsF8) {
             c = 0;
             if (2.0 * p.M * (double)p.N * p.K >= 2.5e8) {

@@ -190,6 +190,10 @@ void gemm_tuner_import(const std::string& text);
 void gemm_bf16_tuner_import(const std::string& text);
 // reduced-precision families: score trials for a pipeline that keeps `n` batches in flight on separate streams (gemm_bf16.hip)
 void gemm_bf16_tuner_set_concurrency(int n);
+// Force one tile configuration of a family at run time (family 0 fp32, 1 f32x3: gemm.hip; 2 bf16, 3 fp8, 4 block-scaled fp8: gemm_bf16.hip);
+// cfg < 0 returns to the environment's value (FERN_GEMM_CFG, ...).  Every configuration of a family gives the same bits.
+bool gemm_force_cfg(int family, int cfg);
+bool gemm_bf16_force_cfg(int family, int cfg);
 
 #ifdef __HIPCC__
 // 64-bit ranking keys: orderable(score) << 32 | ~index, so "score descending, index ascending" is one unsigned compare

@@ -559,5 +559,10 @@ class FernEngine:
         fern_tuner_set_concurrency): shapes tuned afterwards are scored for pipeline throughput, not stand-alone latency."""
         _lib.check(self.lib.fern_tuner_set_concurrency(int(lanes)), "fern_tuner_set_concurrency")
 
+    def tuner_force_config(self, family: str, cfg: int) -> None:
+        """Force one tile configuration of a GEMM family ("f32", "f32x3", "bf16", "fp8", "mx8") process-wide; cfg < 0 releases it
+        (include/fern.h: fern_tuner_force_config).  Results never depend on it."""
+        _lib.check(self.lib.fern_tuner_force_config(family.encode(), int(cfg)), "fern_tuner_force_config")
+
     def sync(self) -> None:
         _lib.check(self.lib.fern_sync(self._h, _stream()), "fern_sync")

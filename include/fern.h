@@ -378,6 +378,10 @@ FERN_API int fern_tuner_import(const char* text);
  * to the pipeline than its own latency says.  Call before the first launch of a shape; tuned shapes keep their
  * choice.  The fp32 family is not affected.  Never changes a result.  No reference counterpart. */
 FERN_API int fern_tuner_set_concurrency(int lanes);
+/* Force ONE tile configuration of a GEMM family ("f32", "f32x3", "bf16", "fp8", "mx8"), process-wide, until cfg < 0 releases it (the
+ * value of FERN_GEMM_CFG / _SPLIT_CFG / _BF16_CFG / _FP8_CFG / _MX8_CFG then applies again).  Every configuration of a family returns the
+ * same bits, so this never changes a result: it exists so that one test process can walk all variants. */
+FERN_API int fern_tuner_force_config(const char* family, int cfg);
 
 /* Workspace generation of a context: incremented each time the context frees workspace memory it had handed to kernels before
  * (it consolidates its arena at the start of the next call after one that had to grow it).  A hipGraph captured from calls on

@@ -219,28 +219,56 @@ def test_topk_large_gallery_many_segments(engine):
 
 
 # ---- forced tile variants ---------------------------------------------------------------------------------------------------------
-# A tile configuration is forced by an environment variable the library reads once per process, so every variant is its own pytest
-# child process over the family's shape suite: 37 children, 5-17 s each (mostly interpreter + torch start-up), ~400 s of the GPU
-# suite.  They are marked `slow` and tests/conftest.py runs `slow` tests LAST: `pytest -m gpu -x` reaches a failure of any parity
-# test within the first ~150 s, and a box too slow for the whole suite loses only these sweeps.  (Round 5 tried to run the
-# children four and eight at a time: the batch hung on the GPU box both times -- 13 + 40 GPU-minutes -- and was taken out again.)
-def _forced_variant_result(var, cfg, key):
-    import os
+# Every tile configuration of a family gives the same bits, and the launcher picks (or tunes) one per shape -- so each variant is also
+# FORCED over its family's whole shape / epilogue suite.  One pytest child process per family walks all of that family's variants:
+# FERN_TEST_FORCE="family:c0,c1,..." makes the autouse fixture below parametrise every selected test over the configurations and force
+# each through fern_tuner_force_config (rounds 2-4 forced them through environment variables the library read once per process: 37
+# children, ~400 s of interpreter start-up).  Marked `slow`; tests/conftest.py runs `slow` tests last.
+_FORCE = os.environ.get("FERN_TEST_FORCE", "")
+
+
+def pytest_generate_tests(metafunc):
+    if _FORCE and "forced_tile" in metafunc.fixturenames:
+        family, cfgs = _FORCE.split(":")
+        metafunc.parametrize("forced_tile", [(family, int(c)) for c in cfgs.split(",")], indirect=True,
+                             ids=[f"{family}{c}" for c in cfgs.split(",")])
+
+
+@pytest.fixture(autouse=True)
+def forced_tile(request):
+    param = getattr(request, "param", None)
+    if param is None:
+        yield None
+        return
+    from fashionern_aaai2024_amd import _lib
+    lib = _lib.load()
+    family, cfg = param
+    _lib.check(lib.fern_tuner_force_config(family.encode(), cfg), "fern_tuner_force_config")
+    try:
+        yield param
+    finally:
+        lib.fern_tuner_force_config(family.encode(), -1)
+
+
+def _forced_family_result(family, cfgs, key):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **{var: str(cfg)})
-    return subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "-m", "gpu", "-q", "-x", "-k", key, "-p", "no:cacheprovider"],
-                          cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, FERN_TEST_FORCE=f"{family}:{','.join(str(c) for c in cfgs)}")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "-m", "gpu and not slow", "-q", "-x", "-k", key,
+                        "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    import re
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-3000:]
+    assert int(m.group(1)) >= 10 * len(cfgs), f"the suite was not walked once per configuration: {r.stdout[-500:]}"
+    return r
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13, 14, 15])
-def test_every_gemm_tile_variant_passes_the_shape_suite(cfg):
-    """The launcher autotunes the tile per shape, so each variant is also forced (FERN_GEMM_CFG, read once per process) over
-    the whole GEMM shape / epilogue suite, incl. the integer-exactness test: all variants must agree bit for bit."""
-    r = _forced_variant_result("FERN_GEMM_CFG", cfg, "test_gemm")
-    assert r.returncode == 0, r.stdout[-3000:]
+def test_every_gemm_tile_variant_passes_the_shape_suite():
+    """fp32 family: the whole GEMM shape / epilogue suite, incl. the integer-exactness test, under each of the 13 forced configurations."""
+    r = _forced_family_result("f32", [0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13, 14, 15], "test_gemm and not bf16 and not fp8 and not mx8")
+    assert r.returncode == 0
 
 
 @pytest.mark.parametrize("m,n,k", [(3000, 768, 768), (2500, 700, 256), (4100, 1536, 512)])
@@ -555,13 +583,11 @@ def test_tuner_concurrency_score_never_changes_a_result(engine):
 
 @pytest.mark.gpu
 @pytest.mark.slow
-@pytest.mark.parametrize("var,cfg", [("FERN_GEMM_BF16_CFG", c) for c in range(7)] + [("FERN_GEMM_FP8_CFG", c) for c in range(6)] +
-                         [("FERN_GEMM_MX8_CFG", c) for c in range(11)])
-def test_every_reduced_precision_gemm_tile_variant(var, cfg):
-    """The bf16 / fp8 launchers pick (or tune) a tile per shape; each variant is also forced over its shape suite."""
-    key = {"FERN_GEMM_BF16_CFG": "test_gemm_bf16", "FERN_GEMM_FP8_CFG": "test_gemm_fp8", "FERN_GEMM_MX8_CFG": "test_gemm_mx8"}[var]
-    r = _forced_variant_result(var, cfg, key)
-    assert r.returncode == 0, r.stdout[-3000:]
+@pytest.mark.parametrize("family,n,key", [("bf16", 7, "test_gemm_bf16"), ("fp8", 6, "test_gemm_fp8"), ("mx8", 11, "test_gemm_mx8")])
+def test_every_reduced_precision_gemm_tile_variant(family, n, key):
+    """The bf16 / fp8 / block-scaled launchers pick (or tune) a tile per shape; each variant is also forced over its family's suite."""
+    r = _forced_family_result(family, list(range(n)), key)
+    assert r.returncode == 0
 
 
 @pytest.mark.gpu

@@ -498,3 +498,15 @@ def test_clip_bpe_algorithm_agrees_with_the_tokenizers_library_clip_pipeline():
         want = other(html.unescape(html.unescape(t)))["input_ids"]
         got = [mine.sot] + mine.encode(t) + [mine.eot]
         assert got == want, (t, got[:16], want[:16])
+
+
+def test_tuner_force_config_names_its_families():
+    """fern_tuner_force_config (the switch the tile-variant sweeps use): known families accept and release a configuration without a GPU,
+    anything else is an argument error with a message."""
+    from fashionern_aaai2024_amd import _lib
+    lib = _lib.load()
+    for fam in ("f32", "f32x3", "bf16", "fp8", "mx8"):
+        assert lib.fern_tuner_force_config(fam.encode(), 3) == 0
+        assert lib.fern_tuner_force_config(fam.encode(), -1) == 0
+    assert lib.fern_tuner_force_config(b"int4", 0) != 0
+    assert b"family" in lib.fern_last_error()
