@@ -57,7 +57,10 @@ def summarise(rows, scale):
     gemm, mx8, b16 = fam("gemm_f32"), fam("gemm_mx8_kernel"), fam("gemm_bf16_glds_kernel")
     rank = [r for r in rows if r[0] in rank_ids]
     sweep = [r for r in rows if r[0] in sweep_ids]
-    calls = sum(1 for r in rows if "rank_exact_kernel" in r[1])   # one gated exact-pass launch closes every ranking call
+    # one select kernel per ranking call (the gated exact-pass launch no longer closes every call: the dense form on small galleries ranks
+    # a query without room inside its select kernel)
+    calls = sum(1 for r in rows if any(k in r[1] for k in ("topk_candidates_kernel", "topk_rescore_kernel", "topk_dense_rescore_kernel",
+                                                            "topk_tiles_rescore_kernel")))
     tot = lambda rs: sum(r[4] for r in rs) * 1024 * scale  # noqa: E731
     return {"gemm_launches": len(gemm), "gemm_bytes": tot(gemm), "mx8_launches": len(mx8), "mx8_bytes": tot(mx8), "bf16_launches": len(b16),
             "bf16_bytes": tot(b16), "rank_calls": calls, "rank_bytes": tot(rank), "sweep_bytes": tot(sweep)}
