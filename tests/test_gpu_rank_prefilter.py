@@ -269,3 +269,21 @@ def test_non_finite_rows_leave_no_certificate_and_the_stage_falls_back_to_the_ex
     s, i = engine.sim_topk(q, pg, k)
     s0, i0 = engine.sim_topk(q, g, k)
     assert torch.equal(i, i0) and torch.equal(s.view(torch.int32), s0.view(torch.int32))
+
+
+def test_prepared_shards_with_offsets_merge_to_the_unsharded_ranking(engine):
+    """The multi-GPU layout (distributed.sharded_topk): every rank ranks its own PREPARED shard of the gallery with its row
+    offset and the queries' global exclusions, the per-shard top-K lists are merged (fern_topk_merge).  Shards of very different sizes
+    take different forms of the stage (row walk, tile maxima, lists) -- the merged result is the unsharded fp32 ranking, bit for bit."""
+    n, d, k = 120_000, 128, 50
+    q, g = _rand(40, d, 71), _rand(n, d, 72, d ** -0.5)
+    ex = torch.randint(0, n, (40,), generator=torch.Generator().manual_seed(7), dtype=torch.int32)
+    for b in range(40):
+        g[int(ex[b])] = q[b] * 1.5                                     # the excluded row would rank first
+    cuts = [0, 700, 9_000, 60_000, n]                                  # 700 / 8 300 / 51 000 / 60 000 rows
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        parts.append(engine.sim_topk(q, engine.prepare_gallery(g[lo:hi].contiguous()), k, idx_offset=lo, exclude_idx=ex))
+    ms, mi = engine.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    s0, i0 = engine.sim_topk(q, g, k, exclude_idx=ex)
+    assert torch.equal(ms, s0) and torch.equal(mi, i0) and not (mi.cpu() == ex[:, None]).any()
