@@ -211,11 +211,12 @@ def test_sweep_scores_are_the_bf16_products_and_tile_maxima_the_maxima_of_32_row
     assert ((scores.double() - exact).abs().max(dim=1).values <= eps * 1.01 + 1e-6).all()
 
 
-@pytest.mark.parametrize("B,N,D", [(5, 300_017, 64), (70, 140_000, 64), (1, 16_384, 64), (33, 262_145, 64)])
+@pytest.mark.parametrize("B,N,D", [(5, 300_017, 64), (70, 140_000, 64), (1, 16_384, 64), (33, 262_145, 64), (7, 20_011, 768), (66, 17_000, 192)])
 def test_tile_maxima_form_beyond_one_register_batch_and_with_split_query_blocks(engine, B, N, D):
     """N / 32 beyond the 8 192 tile maxima a workgroup holds in registers (the re-reading instance); 65..128 queries on a gallery of
     >= 131 072 rows (the sweep runs one 64-query block per launch so that it can leave tile maxima); the smallest gallery of the form;
-    excluded rows = each query's best row, in tiles spread over the whole gallery.  Bits of the fp32 stage, every time."""
+    excluded rows = each query's best row, in tiles spread over the whole gallery; D = 768 / 192: the sweep's generic form (queries in
+    LDS, no compile-time D), the second with more than 64 queries.  Bits of the fp32 stage, every time."""
     q, g = _rand(B, D, seed=B + N), _rand(N, D, seed=N + D, scale=D ** -0.5)
     ex_rows = [(b * 7919 * 31 + 5) % N for b in range(B)]
     for b, row in enumerate(ex_rows):
