@@ -288,3 +288,21 @@ def test_prepared_shards_with_offsets_merge_to_the_unsharded_ranking(engine):
     ms, mi = engine.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     s0, i0 = engine.sim_topk(q, g, k, exclude_idx=ex)
     assert torch.equal(ms, s0) and torch.equal(mi, i0) and not (mi.cpu() == ex[:, None]).any()
+
+
+@pytest.mark.parametrize("k", [1, 2, 63, 64])
+def test_smallest_and_largest_k_with_exclusions(engine, k):
+    """K = 1 and K = 64 (the ABI's limits) with an excluded best row: the tile-maxima bound needs ceil((K + 1) / 4) tiles per wave."""
+    n, d = 33_000, 64
+    q, g = _rand(9, d, 5 + k), _rand(n, d, 6 + k, d ** -0.5)
+    ex_rows = [(b * 3671 + 11) % n for b in range(9)]
+    for b, row in enumerate(ex_rows):
+        g[row] = q[b] * 2.0
+    ex = torch.tensor(ex_rows, dtype=torch.int32)
+    pg = engine.prepare_gallery(g)
+    for exclude in (ex, None):
+        s, i = engine.sim_topk(q, pg, k, exclude_idx=exclude)
+        s0, i0 = engine.sim_topk(q, g, k, exclude_idx=exclude)
+        assert torch.equal(s, s0) and torch.equal(i, i0)
+    cs, ci = chain.chain_topk(q.numpy(), g.numpy(), k)
+    assert _same_bits(s, i, cs, ci) and i[:, 0].cpu().tolist() == ex_rows
