@@ -1337,6 +1337,18 @@ static int clip_block_cls_only(fern_ctx* c, const ClipBlockW& Bk, const float* X
     FERN_TRY(run_gemm(c, gemm_desc(T0, width, Bk.fc, H, Bk.fc.out, batch, EPI_BIAS_GELU), s));
     GemmParams p2 = gemm_desc(H, Bk.fc.out, Bk.proj, CLS, width, batch, EPI_BIAS_RESIDUAL);
     p2.R = CLS;
+    // The class rows' c_proj is M = batch with an unsplit k chain of 3072 (ViT-B): 24 workgroups walking 48 k tiles each, 58 us.  Like
+    // the query-side combiners' hidden layer (CombinerW.ksplit) K is cut into 512-wide slices at THIS call site, for every batch size
+    // (kernels.h: GemmParams.ksplit): 144 workgroups, ~12 us + a 5 us reduce that adds the slices in ascending order.
+    const int ks = (Bk.fc.out >= 2048 && Bk.fc.out % 512 == 0 && (width & 3) == 0) ? Bk.fc.out / 512 : 1;
+    if (ks > 1) {
+        float* kpart;
+        FERN_TRY(ws_get(c, (size_t)ks * batch * width, &kpart));
+        p2.ksplit = ks; p2.kpart = kpart; p2.epi = EPI_BIAS; p2.R = nullptr;      // slices store raw sums; bias + residual happen in the reduce
+        FERN_TRY(run_gemm(c, p2, s));
+        HIP_TRY(launch_splitk_bias_residual(kpart, ks, batch, width, Bk.proj.b, CLS, width, CLS, width, s));
+        return FERN_OK;
+    }
     return run_gemm(c, p2, s);
 }
 

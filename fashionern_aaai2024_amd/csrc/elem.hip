@@ -1028,6 +1028,26 @@ __global__ __launch_bounds__(256) void splitk_relu_dot_kernel(const float* kpart
     v += __shfl_xor(v, 1);
     if ((threadIdx.x & 31) == 0 && col < N) partial[row * (N / 32) + col / 32] = v;
 }
+// Split-K tail of a bias + residual GEMM (kernels.h): C[row][col] = (sum of the S slices, ascending) + bias[col] + R[row][col]
+__global__ __launch_bounds__(256) void splitk_bias_residual_kernel(const float* kpart, int S, long M, int N, const float* bias, const float* R,
+                                                                   long ldr, float* C, long ldc) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const long row = blockIdx.y;
+    if (col >= N) return;
+    const float* src = kpart + row * N + col;
+    float v = 0.0f;
+    for (int sl = 0; sl < S; ++sl) v += src[(long)sl * M * N];          // slices in ascending order, always
+    v += bias ? bias[col] : 0.0f;
+    if (R) v += R[row * ldr + col];
+    C[row * ldc + col] = v;
+}
+hipError_t launch_splitk_bias_residual(const float* kpart, int S, long M, int N, const float* bias, const float* R, long ldr, float* C, long ldc,
+                                       hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    if (S < 1 || N < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(splitk_bias_residual_kernel, dim3((N + 255) / 256, (unsigned)M), dim3(256), 0, s, kpart, S, M, N, bias, R, ldr, C, ldc);
+    return hipGetLastError();
+}
 hipError_t launch_splitk_relu_dot(const float* kpart, int S, long M, int N, const float* bias, const float* w2, float* partial, hipStream_t s) {
     if (M <= 0) return hipSuccess;
     if (S < 1 || (N & 31)) return hipErrorInvalidValue;

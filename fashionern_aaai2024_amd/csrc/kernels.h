@@ -358,6 +358,9 @@ hipError_t launch_gather_scores(const float* q, const float* gallery, const int*
 // split-K tail of the CombinerSimple hidden layer: partial[row][g] = sum over the 32 columns of group g of
 // relu(sum_s kpart[s][row][col] + bias[col]) * w2[col]  -- the layout launch_combiner_finalize reads (N % 32 == 0)
 hipError_t launch_splitk_relu_dot(const float* kpart, int S, long M, int N, const float* bias, const float* w2, float* partial, hipStream_t s);
+// ... and of a bias (+ residual) GEMM: C = (slices of kpart [S][M][N], added in ascending order) + bias + R (R may be null / alias C)
+hipError_t launch_splitk_bias_residual(const float* kpart, int S, long M, int N, const float* bias, const float* R, long ldr, float* C, long ldc,
+                                       hipStream_t s);
 
 // ---- 8-bit image resampling / tensor conversion (image.hip) -------------------------------------------------------
 hipError_t launch_resample_h(const unsigned char* src, long src_ld, int x0, int y0, int rows, unsigned char* dst, int ow, const int* bounds,
