@@ -530,6 +530,78 @@ static hipError_t launch_hd(const AttnParams& p, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// ---- ONE query per (batch, head) (the class token of the last ViT block: clip_block_cls_only) ------------------------------------------
+// The tiled kernels stage the head's whole K / V image in LDS and then use one query row of one MFMA tile: 47.9 us for 64 x 12 heads of
+// 197 keys (77 MB of fp32 K / V at 1.6 TB/s).  Here a workgroup (4 waves) reads K and V straight from memory, lane = head dimension:
+// wave w takes keys w, w + 4, ...; a key's score is a 64-lane product + xor-tree sum, its weight exp(score - max) over all keys, the output
+// sum_j weight_j v_j[d] per lane, the four waves' partial outputs added in wave order.  UNR row loads stay in flight per wave.
+constexpr int SQ1_MAX_KEYS = 1024;
+template <int UNR>
+__global__ __launch_bounds__(256) void attn_f32_single_query_kernel(AttnParams p) {
+    __shared__ float sc[SQ1_MAX_KEYS];
+    __shared__ float red[4][64];
+    __shared__ float wred[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.heads, h = blockIdx.x % p.heads, hd = p.hd;
+    const int lc = lane < hd ? lane : 0;                                     // clamped: every load is unconditional
+    const float* kb = p.k + (long)b * p.s_k * p.ldk + (long)h * hd + lc;
+    const float* vb = p.v + (long)b * p.s_k * p.ldv + (long)h * hd + lc;
+    const float qd = lane < hd ? p.q[(long)b * p.ldq + (long)h * hd + lane] * p.scale : 0.0f;      // s_q == 1
+    for (int j0 = wave; j0 < p.s_k; j0 += 4 * UNR) {
+        float kv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int j = j0 + 4 * u;
+            kv[u] = kb[(long)(j < p.s_k ? j : p.s_k - 1) * p.ldk];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            float sdot = qd * kv[u];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) sdot += __shfl_xor(sdot, m);
+            const int j = j0 + 4 * u;
+            if (lane == 0 && j < p.s_k) sc[j] = sdot;
+        }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = tid; j < p.s_k; j += 256) mx = fmaxf(mx, sc[j]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+    if (lane == 0) wred[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    float sum = 0.0f;
+    for (int j = tid; j < p.s_k; j += 256) {
+        const float e = __expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+    if (lane == 0) wred[4 + wave] = sum;
+    __syncthreads();
+    sum = (wred[4] + wred[5]) + (wred[6] + wred[7]);
+    float acc = 0.0f;
+    for (int j0 = wave; j0 < p.s_k; j0 += 4 * UNR) {
+        float vv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int j = j0 + 4 * u;
+            vv[u] = vb[(long)(j < p.s_k ? j : p.s_k - 1) * p.ldv];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int j = j0 + 4 * u;
+            acc = __builtin_fmaf(j < p.s_k ? sc[j] : 0.0f, vv[u], acc);
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && lane < hd)
+        p.out[(long)b * p.ldo + (long)h * hd + lane] = (((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]) * (1.0f / sum);
+}
+
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.batch <= 0 || p.heads <= 0 || p.s_q <= 0 || p.s_k <= 0) return hipErrorInvalidValue;
     if (p.qb || p.kb || p.vb) {
@@ -542,6 +614,10 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     }
     if ((p.hd & 3) || (p.ldq & 3) || (p.ldk & 3) || (p.ldv & 3) || (p.ldo & 3)) return hipErrorInvalidValue;
     if (p.causal && p.s_q != p.s_k) return hipErrorInvalidValue;
+    if (p.s_q == 1 && !p.causal && p.hd <= 64 && p.s_k <= SQ1_MAX_KEYS && !p.out_b) {      // one query per head: no K / V image, no MFMA tile
+        FERN_LAUNCH(attn_f32_single_query_kernel<25>, dim3(p.batch * p.heads), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     if (p.hd <= 32) return launch_hd<32>(p, s);
     if (p.hd <= 64) return launch_hd<64>(p, s);
     if (p.hd <= 96) return launch_hd<96>(p, s);

@@ -87,7 +87,9 @@ ATTN_CASES = [  # batch, heads, hd, s_q, s_k, causal
     (3, 8, 16, 91, 91, False), (2, 8, 64, 13, 13, False), (2, 8, 80, 13, 13, False), (2, 4, 32, 17, 17, False),
     (2, 3, 64, 10, 10, False), (2, 4, 32, 77, 77, True), (1, 2, 64, 77, 77, True), (2, 10, 64, 77, 77, True),
     (1, 1, 32, 33, 33, True), (2, 2, 16, 5, 40, False), (1, 12, 64, 224, 224, False), (2, 8, 16, 13, 13, False),
-    (1, 3, 64, 77, 77, True), (2, 2, 96, 70, 70, True), (2, 10, 80, 77, 77, True)]      # odd head count, head dims 96 / 80 on the causal 3-tile shape
+    (1, 3, 64, 77, 77, True), (2, 2, 96, 70, 70, True), (2, 10, 80, 77, 77, True),      # odd head count, head dims 96 / 80 on the causal 3-tile shape
+    (2, 12, 64, 1, 197, False), (3, 8, 32, 1, 40, False), (1, 2, 64, 1, 1000, False), (2, 3, 16, 1, 1, False),      # one query per head (the class token's block)
+    (1, 2, 80, 1, 50, False), (1, 2, 96, 1, 224, False)]                                 # ... and beyond its head dimension: the tiled kernels
 
 
 @pytest.mark.parametrize("b,heads,hd,sq,sk,causal", ATTN_CASES)
