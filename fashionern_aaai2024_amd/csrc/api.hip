@@ -1287,9 +1287,11 @@ static int clip_block_mxmlp(fern_ctx* c, const ClipBlockW& Bk, float* X, float* 
 // Last ViT block: only the class token is consumed afterwards (ln_post on token 0, modeling_clip.py:876-877), so
 // K/V are projected for every token but Q, the attention output, out_proj and the MLP run for the class rows only.
 // Bit-identical to the full block on the rows that are read.
+// Xb (FERN_PREC_MX8 with its bf16 residual stream): the stream itself -- the token-level LayerNorm reads it as the full blocks do and
+// only the class rows are widened to fp32 (X is then not read: round 5 dropped the 58 MB bf16 -> fp32 pass over the whole stream).
 static int clip_block_cls_only(fern_ctx* c, const ClipBlockW& Bk, const float* X, float* XN, float* QKV, float* CLS /*[b,width] out*/,
                                float* T0 /*[b,width]*/, float* T1 /*[b,width]*/, float* H /*[b,mlp]*/, int batch, int S, int width,
-                               int heads, hipStream_t s) {
+                               int heads, hipStream_t s, const unsigned short* Xb = nullptr) {
     const long R = (long)batch * S;
     const int hd = width / heads;
     LinearW kv{Bk.qkv.w + (size_t)width * width, Bk.qkv.b + width, 2 * width, width, Bk.qkv.wb + (size_t)width * width,
@@ -1299,9 +1301,11 @@ static int clip_block_cls_only(fern_ctx* c, const ClipBlockW& Bk, const float* X
         // MX mode: block-scaled K/V projection of all tokens (fp32 output); the class-row chain below stays fp32
         unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
         unsigned char* SM = reinterpret_cast<unsigned char*>(XN + ((size_t)R * width / 4 + 63) / 64 * 64);
-        HIP_TRY(launch_layernorm_mx8(X, Bk.ln1.g, Bk.ln1.b, XN8, SM, R, R, width, width, width, 1e-5f, s));
+        if (Xb) HIP_TRY(launch_layernorm_mx8(nullptr, Bk.ln1.g, Bk.ln1.b, XN8, SM, R, R, width, width, width, 1e-5f, s, Xb));
+        else HIP_TRY(launch_layernorm_mx8(X, Bk.ln1.g, Bk.ln1.b, XN8, SM, R, R, width, width, width, 1e-5f, s));
         FERN_TRY(run_gemm_b(c, gemm_desc_mx(XN8, SM, R, width, kv, QKV + width, 3 * width, (int)R, EPI_BIAS, false), s));
-        HIP_TRY(launch_gather_rows(X, width, T1, width, batch, width, 1, S, 0, nullptr, s));
+        if (Xb) HIP_TRY(launch_gather_rows_bf16(Xb, width, T1, width, batch, width, S, s));
+        else HIP_TRY(launch_gather_rows(X, width, T1, width, batch, width, 1, S, 0, nullptr, s));
         HIP_TRY(launch_layernorm(T1, nullptr, Bk.ln1.g, Bk.ln1.b, T0, batch, width, width, width, 1e-5f, s));
     } else if (c->precision == FERN_PREC_FP8) {
         // fp8 mode: quantised K/V projection of all tokens (fp32 output); the class-row chain below stays fp32
@@ -1329,7 +1333,8 @@ static int clip_block_cls_only(fern_ctx* c, const ClipBlockW& Bk, const float* X
     AttnParams a{T1, QKV + width, QKV + 2 * width, T0, (long)width, 3L * width, 3L * width, (long)width,
                  batch, heads, hd, 1, S, 0, 1.0f / std::sqrt((float)hd)};
     FERN_TRY(run_attention(c, a, s));
-    HIP_TRY(launch_gather_rows(X, width, CLS, width, batch, width, 1, S, 0, nullptr, s));              // residual x[:, 0]
+    if (Xb) HIP_TRY(launch_gather_rows_bf16(Xb, width, CLS, width, batch, width, S, s));               // residual x[:, 0]
+    else HIP_TRY(launch_gather_rows(X, width, CLS, width, batch, width, 1, S, 0, nullptr, s));
     GemmParams po = gemm_desc(T0, width, Bk.out, CLS, width, batch, EPI_BIAS_RESIDUAL);
     po.R = CLS;
     FERN_TRY(run_gemm(c, po, s));
@@ -1416,9 +1421,10 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
         else
             FERN_TRY(clip_block(c, W.vblocks[l], X, XN, QKV, ATT, H, b, S, vw, cf.v_heads, 0, s));
     }
-    if (mx_stream) HIP_TRY(launch_bf16_to_f32(Xb, X, R * vw, s));      // the class-row chain of the last block is fp32 (exact widening)
-    // ATT / H are free after the last full block: reuse their heads as the [b, width] / [b, mlp] temporaries
-    FERN_TRY(clip_block_cls_only(c, W.vblocks[cf.v_layers - 1], X, XN, QKV, CLS, ATT, ATT + (size_t)b * vw, H, b, S, vw, cf.v_heads, s));
+    // ATT / H are free after the last full block: reuse their heads as the [b, width] / [b, mlp] temporaries.  The class-row chain of the
+    // last block is fp32; with the bf16 stream only the class rows are widened (exactly), inside the block
+    FERN_TRY(clip_block_cls_only(c, W.vblocks[cf.v_layers - 1], X, XN, QKV, CLS, ATT, ATT + (size_t)b * vw, H, b, S, vw, cf.v_heads, s,
+                                 mx_stream ? Xb : nullptr));
     HIP_TRY(launch_layernorm(CLS, nullptr, W.ln_post.g, W.ln_post.b, CLS, b, vw, vw, vw, 1e-5f, s));
     LinearW proj{W.vproj_t, nullptr, cf.embed_dim, vw};
     return run_gemm(c, gemm_desc(CLS, vw, proj, out, cf.embed_dim, b, EPI_BIAS), s);

@@ -621,6 +621,20 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* x, long l
     row_store(r, y + row * ldy, d, lane);
 }
 
+// y[i] (fp32) = widen(x[i * row_stride]) for a bf16 source (the class rows of the block-scaled mode's bf16 residual stream): one thread per
+// four columns, exact widening
+__global__ __launch_bounds__(256) void gather_rows_bf16_kernel(const unsigned short* x, long ldx, float* y, long ldy, long n, int d, long row_stride) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int d4 = d >> 2;
+    if (i >= n * d4) return;
+    const long row = i / d4;
+    const int c = (int)(i % d4) * 4;
+    const ushort4 v = *reinterpret_cast<const ushort4*>(x + row * row_stride * ldx + c);
+    float4 o;
+    o.x = bf16_bits_to_f32(v.x); o.y = bf16_bits_to_f32(v.y); o.z = bf16_bits_to_f32(v.z); o.w = bf16_bits_to_f32(v.w);
+    *reinterpret_cast<float4*>(y + row * ldy + c) = o;
+}
+
 __global__ __launch_bounds__(256) void bert_embed_kernel(const float* cls, const float* local, const float* seq, const float* type_emb,
                                                          const float* pos_emb, const float* gamma, const float* beta, float* X,
                                                          int B, int P, int T, int d, float eps) {
@@ -999,6 +1013,12 @@ hipError_t launch_gather_rows(const float* x, long ldx, float* y, long ldy, long
     if (n <= 0) return hipSuccess;
     if (bad_width(d) || (ldx & 3) || (ldy & 3) || group < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gather_rows_kernel, row_grid(n), dim3(256), 0, s, x, ldx, y, ldy, n, d, group, group_stride, row_add, idx);
+    return hipGetLastError();
+}
+hipError_t launch_gather_rows_bf16(const unsigned short* x, long ldx, float* y, long ldy, long n, int d, long row_stride, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if ((d & 3) || (ldx & 3) || (ldy & 3) || row_stride < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3((unsigned)((n * (d >> 2) + 255) / 256)), dim3(256), 0, s, x, ldx, y, ldy, n, d, row_stride);
     return hipGetLastError();
 }
 hipError_t launch_bert_embed(const float* cls, const float* local, const float* seq, const float* type_emb, const float* pos_emb,

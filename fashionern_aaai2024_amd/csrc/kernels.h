@@ -328,6 +328,8 @@ hipError_t launch_mean_rows(const float* x, long ldx, float* y, long ldy, long n
 hipError_t launch_ce_diag_mean(const float* logits, long ld, int n, float scale, float* row_loss, float* out, hipStream_t s);
 hipError_t launch_gather_rows(const float* x, long ldx, float* y, long ldy, long n, int d, int group, long group_stride, long row_add,
                               const int* idx, hipStream_t s);
+// y[i] (fp32, ldy) = the bf16 row i * row_stride of x (ldx elements per row), widened exactly
+hipError_t launch_gather_rows_bf16(const unsigned short* x, long ldx, float* y, long ldy, long n, int d, long row_stride, hipStream_t s);
 // BERT embeddings of the fusion encoder: X[b,s] = LN(cat(cls, local, seq)[b,s] + type[s >= P+1] + pos[s]) (eps 1e-12)
 hipError_t launch_bert_embed(const float* cls, const float* local, const float* seq, const float* type_emb,
                              const float* pos_emb, const float* gamma, const float* beta, float* X,
