@@ -36,6 +36,27 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+_T0 = time.perf_counter()
+_STAMPS = {}
+
+
+def stamp(name):
+    """Wall-clock seconds since the process started, per phase of the run (`timing_s` of the record: where a default run's minute goes)."""
+    _STAMPS[name] = round(time.perf_counter() - _T0, 1)
+
+
+def csrc_sha16() -> str:
+    """sha256 over the kernel sources: the PMC traffic file is stamped with it (tools/pmc_traffic.py) and `roofline.traffic` is reported
+    only when the stamp equals THIS tree's -- a counter figure measured on other kernels is omitted, not labelled stale (VERDICT r5 item 8;
+    there is no .git on the GPU box to compare heads with)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fashionern_aaai2024_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 F32X3_BOUND_TFLOPS = 157.3 * 128.0 / 48.0      # f32x3: six 32-cycle bf16 MFMAs (192 cycles) do the work of two 64-cycle fp32 MFMAs -> 419.5 fp32-equivalent TFLOP/s
@@ -81,6 +102,11 @@ def parse_args():
     ap.add_argument("--rank-plain", action="store_true",
                     help="rank the fp32 gallery with the fp32-MFMA sweep (fern_sim_topk) instead of its prepared form (certified bf16 pre-filter + "
                          "exact fp32 rescoring, fern_sim_topk_prefiltered): same results, the round-4 stage")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="cpu_baseline: also time ONE query with torch's pool on every schedulable core (256 threads on the GPU box: ~70 s, a "
+                         "documented pathology of the pool -- not part of the default run since round 6)")
+    ap.add_argument("--full-record", type=str, default=os.path.join(ROOT, "bench_full.json"),
+                    help="where rank 0 writes the FULL record (every leg, notes, tile table); stdout carries the compact line (< 4 KB)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default c2 run at N = 1: do not also run the c3 / c4 / c5 workloads (short child runs of this script, reported "
                          "under `other_configs`)")
@@ -104,16 +130,23 @@ def other_config_lines(steps: int) -> dict:
     """The BASELINE.json workloads other than the headline, measured on the same box by short child runs of this script (a child
     process, started after this one is done with its timed region; never an exec): one compact record per config so that the
     driver's single default run carries a c3 / c4 / c5 number too.  `value` of the main line is untouched."""
+    import tempfile
     out = {}
     keep = ("value", "unit", "ms_per_step", "dtype", "encoder_precision", "accuracy_vs_fp32_encoder", "reduced_modes")
     for name in ("c3", "c4", "c5"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "4", "--no-cpu-baseline", "--no-other-configs"]
+        t0 = time.perf_counter()
+        fd_, full_path = tempfile.mkstemp(prefix=f"fern_bench_{name}_", suffix=".json")
+        os.close(fd_)
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "4", "--no-cpu-baseline", "--no-other-configs",
+               "--full-record", full_path]
         if name != "c5":
             cmd.append("--headline-only")      # c5 keeps its secondary leg: the ranking agreement of the fp8 encoder with the fp32 one
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-            j = json.loads(line)
+            if r.returncode != 0:
+                raise RuntimeError(f"rc {r.returncode}: {r.stderr[-200:]}")
+            with open(full_path) as f:
+                j = json.load(f)
             rec = {k: j.get(k) for k in keep}
             rec["workload"] = j["config"]["workload"]
             rec["roofline"] = {k: j["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "gemm_ms_per_step", "step_level")}
@@ -122,9 +155,15 @@ def other_config_lines(steps: int) -> dict:
             if j.get("roofline_sim_sweep"):
                 rec["rank_stage_us"] = j["roofline_sim_sweep"].get("stage_us")
                 rec["rank_stage_frac_of_hbm"] = j["roofline_sim_sweep"].get("frac")
+            rec["wall_s"] = time.perf_counter() - t0
             out[name] = rec
         except Exception as e:      # a failed side run must not take the headline line down with it
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            try:
+                os.unlink(full_path)
+            except OSError:
+                pass
     return out
 
 
@@ -227,7 +266,7 @@ def order_parity(o_scores_full, g_idx, o_idx):
             "max_oracle_score_gap_at_mismatching_positions": gap}
 
 
-def cpu_baseline(clip_sd, fusion_sd, cfg, w, images, tokens, loc, gallery, sample, gpu_topk, repeats=3, extra_topk=None):
+def cpu_baseline(clip_sd, fusion_sd, cfg, w, images, tokens, loc, gallery, sample, gpu_topk, repeats=3, extra_topk=None, all_cores_leg=False):
     """The CPU oracle (kind "port": this repo's restatement, pinned against the imported reference by tests/golden) timed on the
     host cores, on bounded samples of the same workload; it is also the checker of the HIP result (parity_vs_hip).
       * end to end: `sample` composed queries -- encode image + text, fuse, rank against the same fused gallery;
@@ -279,15 +318,15 @@ def cpu_baseline(clip_sd, fusion_sd, cfg, w, images, tokens, loc, gallery, sampl
                 "rank_ms": t_rank * 1e3, "fuse_plus_rank_queries_per_s": b / (t_test + t_rank)}
 
     cpu_model, host_cores = _host_cpu()
-    # the same path with torch's intra-op pool on EVERY schedulable core (BASELINE.md 3 planned os.cpu_count()): on a 256-logical-core
-    # host the pool's fork / join per small op dominates and the rate collapses, which is why `value` is quoted at 32 threads; a
-    # 1-query sample, one run (~20 s)
+    # --cpu-all-cores only: the same path with torch's intra-op pool on EVERY schedulable core (BASELINE.md 3 planned os.cpu_count()): on
+    # a 256-logical-core host the pool's fork / join per small op dominates and the rate collapses (0.015 queries/s measured in round 5,
+    # 67 s of the default run), which is why `value` is quoted at 32 threads and why this leg is no longer part of the default command
     all_cores = None
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    if avail > threads:
+    if all_cores_leg and avail > threads:
         torch.set_num_threads(avail)
         ns = 1                                                # ~20 s at the 0.05 queries/s this pool size reaches: one query, one run
         im4, tk4, lc4 = im[:ns], tk[:ns], lc[:ns]
@@ -449,9 +488,15 @@ def harness_leg(torch, eng, clip, model, cfg, D, device, n_gal, lookup_qps, enc_
                                       "note": "query loop + mode=index fusion of the whole gallery + ranking + recall arithmetic, per call as the reference does"}
     out["engine_lookup_variant_queries_per_s"] = lookup_qps
     out["predictions_vs_engine_lookup"] = (queries / t_pred) / lookup_qps if lookup_qps else None
+    prev_lanes = os.environ.get("FERN_HARNESS_LANES")      # a value the user exported survives the toggle
     os.environ["FERN_HARNESS_LANES"] = "0"
-    t_serial, _ = timed(lambda: generate_fiq_val_predictions(clip, rel, model, index_names, index_features, device, D, 64, nw, "bench-clip-bpe"), reps=1)
-    os.environ.pop("FERN_HARNESS_LANES")
+    try:
+        t_serial, _ = timed(lambda: generate_fiq_val_predictions(clip, rel, model, index_names, index_features, device, D, 64, nw, "bench-clip-bpe"), reps=1)
+    finally:
+        if prev_lanes is None:
+            os.environ.pop("FERN_HARNESS_LANES", None)
+        else:
+            os.environ["FERN_HARNESS_LANES"] = prev_lanes
     out["generate_fiq_val_predictions_call_by_call"] = {"wall_s": t_serial, "queries_per_s": queries / t_serial,
                                                         "note": "FERN_HARNESS_LANES=0: the round-4 loop (one stream, two encode_text calls served by one pass)"}
     pool_im = torch.from_numpy(synth.images(32, cfg, 9))
@@ -464,6 +509,112 @@ def harness_leg(torch, eng, clip, model, cfg, D, device, n_gal, lookup_qps, enc_
                                              "memory, one host -> device copy of 19 MB per batch, encode_image"}
     del index_features, index_local
     torch.cuda.empty_cache()
+    return out
+
+
+COMPACT_CAP_BYTES = 4000      # the driver reads ONE stdout line; round 5's 24.6 KB line came back unparsed
+
+
+def _r(x, sig=5):
+    """Round a float to `sig` significant digits (the compact line is a summary; bench_full.json keeps every digit)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{sig}g}")
+
+
+def _pick(d, *keys, sig=5):
+    return {k: _r(d[k], sig) for k in keys if isinstance(d, dict) and d.get(k) is not None}
+
+
+def compact_record(full: dict, cap: int = COMPACT_CAP_BYTES) -> dict:
+    """The ONE stdout line the driver parses: the contract keys, `roofline` and `cpu_baseline` without their prose, and one number per
+    extra leg (other configs, harness, PCIe-inclusive rate, reduced modes).  Everything else stays in the full record (bench_full.json +
+    stderr).  Extras are dropped from the back until the line fits `cap` bytes; the contract keys, `roofline` and `cpu_baseline` never are."""
+    out = {k: _r(full.get(k), 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                           "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    out["config"] = {k: cfg[k] for k in ("workload", "name", "clip", "query_batch_per_gpu", "gallery_rows", "gallery_dtype", "feature_dim", "top_k",
+                                         "batches_in_flight") if k in cfg}
+    out["config"]["parallelism"] = str(cfg.get("parallelism", "")).split(";")[0]
+    out["encoder_precision"] = full.get("encoder_precision")
+    roof = full.get("roofline") or {}
+    r = _pick(roof, "bound", "achieved", "peak", "unit", "frac")
+    r["traffic"] = roof.get("traffic")                      # HBM counter bytes per launch; None unless measured at this HEAD
+    r["kernel"] = str(roof.get("kernel", "")).split(" (")[0][:60]
+    r.update(_pick(roof, "algorithmic_bytes_per_launch", "gemm_ms_per_step", "gemm_gflop_per_step"))
+    if isinstance(roof.get("step_level"), dict):
+        r["step_level"] = _pick(roof["step_level"], "achieved", "frac")
+    out["roofline"] = r
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, "value", "unit", "cores", "host_cores", "cpu_model", "kind")
+        c["sample"] = str(cb.get("sample", ""))[:120]
+        if isinstance(cb.get("parity_vs_hip"), dict):
+            c["parity_vs_hip"] = _pick(cb["parity_vs_hip"], "queries", "rows_with_identical_order", "max_abs_cosine_diff",
+                                       "max_oracle_score_gap_at_mismatching_positions", sig=3)
+        out["cpu_baseline"] = c
+    extras = []                                             # (key, value) in the order they are dropped LAST -> FIRST
+    lat = full.get("latency_ms_per_batch")
+    if lat:
+        extras.append(("latency_ms_per_batch", _pick(lat, "p50", "p99", sig=4)))
+    rs = full.get("roofline_sim_sweep")
+    if rs:
+        extras.append(("rank_stage", _pick(rs, "stage_us", "frac", "sweep_only_us", "sweep_only_GBs", sig=4)))
+    oc = full.get("other_configs")
+    if oc:
+        o = {}
+        for name, rec in oc.items():
+            if "error" in rec:
+                o[name] = {"error": rec["error"][:80]}
+                continue
+            e = {"value": _r(rec.get("value"), 5), "precision": rec.get("encoder_precision"),
+                 "roofline_frac": _r((rec.get("roofline") or {}).get("frac"), 4), "rank_stage_us": _r(rec.get("rank_stage_us"), 4),
+                 "rank_frac": _r(rec.get("rank_stage_frac_of_hbm"), 3)}
+            rcl = (rec.get("accuracy_vs_fp32_encoder") or {}).get("recall") or {}
+            if rcl:
+                e["dR50_pp"] = _r(rcl.get("delta_recall_at_50_pp"), 3)
+                e["top50_overlap"] = _r(rcl.get("top50_overlap"), 3)
+            o[name] = e
+        extras.append(("other_configs", o))
+    h = full.get("harness")
+    if h:
+        extras.append(("harness", {"generate_fiq_val_predictions_qps": _r(h["generate_fiq_val_predictions"]["queries_per_s"]),
+                                   "compute_fiq_val_metrics_qps": _r(h["compute_fiq_val_metrics"]["queries_per_s"]),
+                                   "extract_index_features_ips": _r(h["extract_index_features"]["images_per_s"])}))
+    if full.get("pcie_inclusive"):
+        extras.append(("pcie_inclusive", _pick(full["pcie_inclusive"], "value", "vs_resident_inputs")))
+    if full.get("lookup_variant"):
+        extras.append(("lookup_variant", _pick(full["lookup_variant"], "value")))
+    modes = {}
+    q = (full.get("reduced_modes") or {}).get("modes") or {}
+    for m in ("f32x3", "bf16", "mx8mlp", "fp8", "mx8"):
+        info = full.get("encoder_" + m)
+        if info or m in q:
+            e = {}
+            if info:
+                e.update({"qps": _r(info.get("value")), "gemm_frac": _r(info.get("gemm_frac"), 3)})
+            if m in q:
+                e.update({"dR50_pp": _r(q[m].get("delta_recall_at_50_pp"), 3), "top50_overlap": _r(q[m].get("top50_overlap"), 3)})
+            modes[m] = e
+    if modes:
+        extras.append(("modes", modes))
+    if full.get("roofline_sim_sweep_bf16_1M"):
+        extras.append(("rank_stage_bf16_1M", _pick(full["roofline_sim_sweep_bf16_1M"], "stage_us", "frac", sig=4)))
+    if full.get("sharded_merge"):
+        extras.append(("sharded_merge", _pick(full["sharded_merge"], "value", "identical_to_replicated")))
+    ag = full.get("all_gather")
+    if ag and full.get("n_gpus", 1) > 1:
+        extras.append(("all_gather", _pick(ag, "ms", "GBs_per_rank", "frac_of_xgmi", sig=4)))
+    if full.get("timing_s"):
+        extras.append(("timing_s", full["timing_s"]))
+    out["full_record"] = full.get("full_record")
+    for k, v in extras:
+        out[k] = v
+    while len(json.dumps(out)) > cap and extras:
+        k, _ = extras.pop()
+        out.pop(k, None)
     return out
 
 
@@ -939,15 +1090,19 @@ def main():
     result = None
     if rank == 0:
         traffic = traffic_src = alg_bytes = sweep_traffic = None
-        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(traffic_file) and precision == "fp32" and args.config == "c2":
+        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic_c5.json" if args.config == "c5" else "pmc_traffic.json")
+        if os.path.exists(traffic_file) and args.config in ("c2", "c5") and precision == w["precision"]:
             tr = json.load(open(traffic_file))
-            traffic = tr.get("gemm", {}).get("hbm_bytes_per_launch")
-            alg_bytes = tr.get("gemm", {}).get("algorithmic_bytes_per_launch")
-            sweep_traffic = tr.get("sweep", {}).get("hbm_bytes_per_launch")
-            traffic_src = ("STALE -- not measured in this run: read from profiles/pmc_traffic.json (measured " + json.dumps(tr.get("measured")) +
-                           "), produced by separate `rocprofv3 --pmc "
-                           "FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `bench.py --pmc-mode` (" + str(tr.get("source")) + ")")
+            fam = "gemm_mx8" if args.config == "c5" and "gemm_mx8" in tr else "gemm"
+            if (tr.get("measured") or {}).get("csrc_sha16") == csrc_sha16():
+                traffic = tr.get(fam, {}).get("hbm_bytes_per_launch")
+                alg_bytes = tr.get(fam, {}).get("algorithmic_bytes_per_launch")
+                sweep_traffic = tr.get("sweep", {}).get("hbm_bytes_per_launch")
+                traffic_src = ("profiles/" + os.path.basename(traffic_file) + ": separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of "
+                               "`bench.py --pmc-mode` on THESE kernel sources (csrc_sha16 " + csrc_sha16() + "; " + str(tr.get("source")) + ")")
+            else:
+                traffic_src = ("omitted: " + os.path.basename(traffic_file) + " was measured on other kernel sources (" +
+                               json.dumps(tr.get("measured")) + "), this tree is csrc_sha16 " + csrc_sha16())
         result = {
             "metric": "composed queries/sec", "value": value, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -1043,15 +1198,29 @@ def main():
                 extra_topk["f32x3"] = eng.sim_topk(eng.dvr_fuse(rf3, lc, tg3, ts3), gallery[:n_cpu], K)
                 torch.cuda.synchronize()
                 pipe.set_precision("fp32")
-            result["cpu_baseline"] = cpu_baseline(clip_sd, fusion_sd, cfg, w, im, tk, lc, gallery[:n_cpu], args.cpu_sample, gpu_topk, extra_topk=extra_topk)
+            result["cpu_baseline"] = cpu_baseline(clip_sd, fusion_sd, cfg, w, im, tk, lc, gallery[:n_cpu], args.cpu_sample, gpu_topk, extra_topk=extra_topk,
+                                                  all_cores_leg=args.cpu_all_cores)
             gap = result["cpu_baseline"]["parity_vs_hip"]["max_oracle_score_gap_at_mismatching_positions"]
             if gap > 2e-6 and not w["bf16_gallery"]:
                 raise SystemExit(f"bench: the HIP top-{K} differs from the CPU oracle's beyond near-ties (oracle score gap {gap:.3e} > 2e-6)")
         if world == 1 and args.config == "c2" and not args.headline_only and not args.no_other_configs and not args.pmc_mode:
             pipe.close()
             torch.cuda.synchronize()
+            stamp("cpu_baseline_done")
             result["other_configs"] = other_config_lines(min(args.steps, 20))
-        print(json.dumps(result), flush=True)
+        stamp("end")
+        result["timing_s"] = dict(_STAMPS)
+        result["full_record"] = os.path.basename(args.full_record) + " (+ stderr)"
+        # The FULL record (every leg with its notes, the tile table, per-config child records) goes to a side file and to stderr; the
+        # LAST stdout line -- the one the driver parses -- is its compact form (< 4 KB: contract keys, roofline, cpu_baseline, one number
+        # per extra leg).  Round 5's single 24.6 KB line came back unparsed.
+        try:
+            with open(args.full_record, "w") as f:
+                json.dump(result, f)
+        except OSError as e:
+            print(f"[bench] could not write {args.full_record}: {e}", file=sys.stderr)
+        print("[bench full record] " + json.dumps(result), file=sys.stderr, flush=True)
+        print(json.dumps(compact_record(result)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1286,7 +1286,8 @@ static int clip_block_mxmlp(fern_ctx* c, const ClipBlockW& Bk, float* X, float* 
 
 // Last ViT block: only the class token is consumed afterwards (ln_post on token 0, modeling_clip.py:876-877), so
 // K/V are projected for every token but Q, the attention output, out_proj and the MLP run for the class rows only.
-// Bit-identical to the full block on the rows that are read.
+// Equal to the full block on the rows that are read only to TOLERANCE since round 5: the single-query attention kernel and the
+// 512-wide split-K c_proj add their products in another order than the full block's kernels (fp32 parity mode included).
 // Xb (FERN_PREC_MX8 with its bf16 residual stream): the stream itself -- the token-level LayerNorm reads it as the full blocks do and
 // only the class rows are widened to fp32 (X is then not read: round 5 dropped the 58 MB bf16 -> fp32 pass over the whole stream).
 static int clip_block_cls_only(fern_ctx* c, const ClipBlockW& Bk, const float* X, float* XN, float* QKV, float* CLS /*[b,width] out*/,

@@ -55,6 +55,13 @@ class FusedResult:
         self.fused.record_stream(cur)
         return self.fused
 
+    def release(self) -> None:
+        """Drop the host staging buffers of the batch once its uploads have run (the lane's event has completed): a long query loop
+        must not hold every batch's pinned memory until its end (gigabytes at 200k queries)."""
+        if self._keep is not None:
+            self._event.synchronize()
+            self._keep = None
+
 
 class _LaneGraph:
     """One captured step of one lane: static input buffers, the hipGraph, the tensors it writes."""

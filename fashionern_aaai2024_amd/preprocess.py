@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from functools import lru_cache
 from typing import List, Tuple
 
@@ -81,14 +82,16 @@ def pil_coeffs(in_size: int, out_size: int, flt: str) -> Tuple[np.ndarray, np.nd
 
 
 _dev_cache = {}
+_dev_cache_lock = threading.Lock()      # dataset transforms run on ThreadedLoader's worker threads (include/fern.h: the image entry points are thread-safe)
 
 
 def _dev_coeffs(engine: FernEngine, in_size: int, out_size: int, flt: str):
     key = (engine.device, in_size, out_size, flt)
-    if key not in _dev_cache:
-        b, k = pil_coeffs(in_size, out_size, flt)
-        _dev_cache[key] = (torch.from_numpy(b).to(engine.device), torch.from_numpy(k).to(engine.device), k.shape[1])
-    return _dev_cache[key]
+    with _dev_cache_lock:
+        if key not in _dev_cache:
+            b, k = pil_coeffs(in_size, out_size, flt)
+            _dev_cache[key] = (torch.from_numpy(b).to(engine.device), torch.from_numpy(k).to(engine.device), k.shape[1])
+        return _dev_cache[key]
 
 
 def resize_u8(engine: FernEngine, img: torch.Tensor, out_w: int, out_h: int, flt: str = "bicubic", box=None) -> torch.Tensor:

@@ -113,9 +113,17 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
                             continue
                     if stop.is_set():
                         return
-                q.put(None)
+                last = None
             except BaseException as e:      # noqa: BLE001 -- handed to the consumer, which re-raises it
-                q.put(e)
+                last = e
+            # the terminal item obeys the same stop / timeout protocol as the batches: a consumer that has gone away while the queue
+            # is full must not leave this thread (and the loader, its worker pool and the pinned batches it holds) blocked forever
+            while not stop.is_set():
+                try:
+                    q.put(last, timeout=0.1)
+                    return
+                except queue.Full:
+                    continue
 
         t = threading.Thread(target=produce, name="fern-harness-producer", daemon=True)
         t.start()
@@ -132,8 +140,13 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
 
     with host_threads():
         if pipe is not None:
+            window = 4 * len(pipe.engines)      # results older than this are collected: their pinned host batches (B x 13 x D fp32) go back
             for ref_names, batch_targets, members, text_inputs, ref_patch, rows in prepared_batches():
                 pending.append(_submit_fuse(pipe_box, clip_model, model, device, text_inputs, ref_patch, rows, index_features))
+                if len(pending) - len(predicted) > window:
+                    done = pending[len(predicted)]
+                    predicted.append(done.wait())
+                    done.release()
                 target_names.extend(batch_targets)
                 reference_names.extend(ref_names)
                 if members is not None:
@@ -157,7 +170,9 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
                 if members is not None:
                     group_members.extend(members)
     if pipe is not None:
-        predicted = [p.wait() for p in pending]
+        for p in pending[len(predicted):]:
+            predicted.append(p.wait())
+            p.release()
     pred = torch.cat(predicted, dim=0) if predicted else torch.empty((0, feature_dim), device=device)
     if world > 1:       # every rank returns all Q predictions in dataset order, like the single-process loop
         per_row = [(t, r, group_members[i] if group_members else None) for i, (t, r) in enumerate(zip(target_names, reference_names))]
@@ -184,6 +199,12 @@ def _query_pipeline(clip_model, model, device):
         if pipe is not None:
             pipe.close()
         pipe = eng._harness_pipe = ComposedQueryPipeline(eng, lanes=lanes)
+    # A fork copies the parent's precision when it is MADE and fern_set_precision changes only the context it is called on: a caller
+    # that switched the engine's precision since the last harness call (FernCLIP.set_precision / engine.set_precision) would get two of
+    # every three batches at the old one.  The parent is the statement of what the caller wants.
+    want = eng.precision
+    if any(e.precision != want for e in pipe.engines[1:]):
+        pipe.set_precision(want)
     return pipe
 
 

@@ -236,7 +236,10 @@ FERN_API int fern_l2_normalize(fern_ctx* ctx, const float* x, float* out, int64_
  * and by torchvision `Resize(dim, BICUBIC)` in dataloader/dataset.py:73-87.  One separable pass each; `bounds` [out,2] =
  * (first tap, tap count) and `coeffs` [out,ksize] = fixed-point (2^-22) weights are DEVICE arrays computed by the host
  * exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do.  src is HWC u8 with `src_ld` pixels per row; (x0, y0)
- * is the origin of the region being resampled (`Image.crop`).  Bit-identical to PIL. */
+ * is the origin of the region being resampled (`Image.crop`).  Bit-identical to PIL.
+ * THREAD SAFETY (the one exception to "a context is not thread-safe"): these three entry points read only `ctx->device`, touch no
+ * workspace, tuner or error state of the context beyond the calling thread's last-error slot, and launch on the stream they are
+ * given -- dataset transforms may call them from loader worker threads (utils.ThreadedLoader) while another thread encodes. */
 FERN_API int fern_resample_u8_horizontal(fern_ctx* ctx, const uint8_t* src, int64_t src_ld, int x0, int y0, int rows, uint8_t* dst /*[rows,ow,3]*/,
                                          int ow, const int32_t* bounds, const int32_t* coeffs, int ksize, void* stream);
 FERN_API int fern_resample_u8_vertical(fern_ctx* ctx, const uint8_t* src, int64_t src_ld, int x0, int y0, int cols, uint8_t* dst /*[oh,cols,3]*/,
@@ -287,7 +290,8 @@ typedef enum {
     FERN_RANK_AUTO = 0,
     FERN_RANK_PLAIN = 1,   /* fern_sim_topk's fp32-MFMA sweep (the pre-filter copy is not read) */
     FERN_RANK_LISTS = 2,   /* bf16 sample pass -> bound - margin -> filtered bf16 sweep into candidate lists -> rescoring: large galleries */
-    FERN_RANK_DENSE = 3    /* bf16 sweep storing its [B, N] scores -> one select + rescore kernel: small galleries (N <= 262144) */
+    FERN_RANK_DENSE = 3    /* bf16 sweep storing its [B, N] scores -> one select + rescore kernel; offered while min(B, 1024) * N * 4 bytes of scores stay <= 1.1e9
+                            * (~4.3M rows at B <= 64; up to 1.1 GB of workspace per lane) -- the cost model picks it up to ~600k rows at B = 64 */
 } fern_rank_strategy;
 FERN_API int fern_rank_set_strategy(fern_ctx* ctx, int strategy);
 /* The bf16 sweep on its own: scores[b * ld + n] = the fp32-accumulated dot product of bf16(q[b]) and gallery_bf16[n] (v_mfma_f32_32x32x16_bf16,
@@ -390,8 +394,9 @@ FERN_API uint64_t fern_ws_generation(const fern_ctx* ctx);
 
 /* profiling ----------------------------------------------------------------------------- */
 /* While on, GEMM / attention / sweep launches are dispatched with a (start, stop) event pair each and timed by the dispatch's own begin /
- * end timestamps; the ranking STAGE (sample, bound, sweep, select, exact gate and the boundaries between them) is one stream-marker
- * interval.  A launch that fails while instrumented leaves no record behind. */
+ * end timestamps; the ranking STAGE (sample, bound, sweep, select, exact gate and the boundaries between them) is, for
+ * fern_sim_topk_prefiltered / fern_sim_topk_bf16, the span first dispatch begin -> last dispatch end from those same timestamps, and for the
+ * plain fern_sim_topk one stream-marker interval.  A launch that fails while instrumented leaves no record behind. */
 FERN_API int fern_prof_enable(fern_ctx* ctx, int on);
 FERN_API int fern_prof_collect(fern_ctx* ctx, fern_prof_stats* out);  /* synchronises, sums, resets */
 

@@ -105,6 +105,41 @@ def test_full_pipeline_with_hip_clip_matches_oracle_pipeline():
         assert abs(full[row, i0[row, col]].item() - full[row, i1[row, col]].item()) < 1e-4
 
 
+def test_precision_switch_between_two_harness_calls_reaches_every_lane():
+    """the harness caches a 3-lane pipeline on the engine and a forked context copies the parent's precision only when it is
+    made.  Switching the engine's precision BETWEEN two `generate_fiq_val_predictions` calls must change all lanes: the second call
+    equals a call-by-call run (FERN_HARNESS_LANES=0, the parent context alone) at the new precision, batch by batch."""
+    cfg = synth.CLIP_CONFIGS["tiny-w256"]
+    d = cfg.embed_dim
+    register_tokenizer("tiny", sdata.stub_tokenizer)
+    gal = sdata.Gallery(200, d, seed=31, image_size=cfg.image_size)
+    rel = sdata.RelativeDataset(gal, 96, "fiq", seed=32)           # 6 batches of 16: two per lane
+    clip = create_model(cfg, device=DEV, seed=9)
+    model = ERN(clip, d, DEV, engine=clip.engine).init_random(4)
+    eng = model.engine
+    feats, names, _ = extract_index_features(sdata.ClassicDataset(gal), clip, 13, DEV, d, num_workers=0)
+
+    def predictions():
+        return test_fiq.generate_fiq_val_predictions(clip, rel, model, names, feats, DEV, d, 16, 0, "tiny")[0].clone()
+
+    eng.set_precision("fp32")
+    p_fp32 = predictions()                                          # builds and caches the pipeline at fp32
+    assert len(eng._harness_pipe.engines) == 3
+    eng.set_precision("bf16")                                       # the parent context only
+    p_bf16 = predictions()
+    assert [e.precision for e in eng._harness_pipe.engines] == ["bf16"] * 3
+    os.environ["FERN_HARNESS_LANES"] = "0"
+    try:
+        p_bf16_serial = predictions()
+    finally:
+        os.environ.pop("FERN_HARNESS_LANES")
+    eng.set_precision("fp32")
+    assert torch.equal(p_bf16, p_bf16_serial), "a lane kept the precision it was forked with"
+    for lo in range(0, 96, 16):                                     # every batch (= every lane) moved away from its fp32 bits
+        assert not torch.equal(p_bf16[lo:lo + 16], p_fp32[lo:lo + 16])
+    assert torch.equal(predictions(), p_fp32)                       # and back
+
+
 def test_standalone_modules_on_hip():
     d = 128
     gold = np.load(os.path.join(GOLD, "fusion.npz"))

@@ -71,10 +71,13 @@ def main():
     write = summarise(per_dispatch(sys.argv[2], "WRITE_SIZE"), 1.0)
     steps = int(sys.argv[3])
     calls = max(1, fetch["rank_calls"])
-    # when / at which tree the counters were collected: bench.py quotes the figure as STALE (it cannot collect PMC counters inside
-    # the driver's run) and repeats this stamp.  FERN_HEAD: `git rev-parse --short HEAD` of the dev container (no .git on the GPU box).
+    # when / on which kernel sources the counters were collected: bench.py cannot collect PMC counters inside the driver's run, so it
+    # reports `roofline.traffic` from this file ONLY when `csrc_sha16` (sha256 over csrc/*.hip, *.h -- bench.csrc_sha16) equals its own
+    # tree's, and omits it otherwise.  FERN_HEAD: `git rev-parse --short HEAD` of the dev container (no .git on the GPU box).
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_sha16
     out = {
-        "measured": {"date": datetime.date.today().isoformat(), "head": os.environ.get("FERN_HEAD", "unknown")},
+        "measured": {"date": datetime.date.today().isoformat(), "head": os.environ.get("FERN_HEAD", "unknown"), "csrc_sha16": csrc_sha16()},
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --pmc-mode`; FETCH_SIZE x2 (gfx950), KiB -> B",
         "steps": steps,
         "gemm": {"launches_per_step": fetch["gemm_launches"] / steps,

@@ -4,7 +4,7 @@
 # rocprofv3 needs the program itself after `--` (python3 ...), TMPDIR on /tmp, and --pmc in passes of its own; every profiled
 # command runs under `timeout` (a profiler hang must not eat the GPU budget).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh
 mkdir -p $O
@@ -26,7 +26,7 @@ cd /tmp && export TMPDIR=/tmp
 run_stats() {   # name, bench args...
     local name=$1; shift
     rm -rf /tmp/prof_$name
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o p -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/${name}_under_rocprof.json 2> /tmp/${name}.err
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o p -- python3 $R/bench.py --no-cpu-baseline --full-record $O/${name}_under_rocprof_full.json "$@" > $O/${name}_under_rocprof.json 2> /tmp/${name}.err
     python3 $R/tools/kstats.py /tmp/prof_$name 16 $O/${name}_kernel_stats.csv > $O/${name}_kernel_stats_top.txt 2>&1
 }
 # tile choices of this box first; the profiled runs are pinned to them (FERN_GEMM_TILES), so their dispatch averages hold no tuner trials
@@ -61,7 +61,7 @@ python3 $R/tools/kstats.py /tmp/prof_sweep 16 $O/${TAG}_sweep_1M_kernel_stats.cs
 timeout 200 python3 $R/tools/attn_bench.py > $O/${TAG}_attn_bench.txt 2>&1
 cd $R
 # the driver's default command: it carries cpu_baseline, the harness / quality / PCIe legs and the c3 / c4 / c5 child runs (other_configs)
-timeout 1200 python3 bench.py > $O/${TAG}_bench_c2.json 2> $O/${TAG}_bench_c2.err
+timeout 1200 python3 bench.py --full-record $O/${TAG}_bench_c2_full.json > $O/${TAG}_bench_c2.json 2> $O/${TAG}_bench_c2.err
 # ranking stage: micro-benchmark of its three forms at the BASELINE shapes + kernel timelines of the forms the cost model picks
 timeout 300 python3 tools/rank_bench.py > $O/${TAG}_rank_bench.txt 2>&1
 cd /tmp
@@ -79,8 +79,8 @@ for c in c2 c3 c5; do
     python3 $R/tools/step_timeline.py /tmp/tl_$c 3 --list > $O/${TAG}_timeline_$c.txt 2>&1
 done
 cd $R
-# (the world = 8 one-GPU rehearsal of round 3, tools/r03_rehearsal.sh, is not repeated: its artefacts are profiles/r03_bench_c*_8ranks_one_gpu_gloo.json;
-#  round 4 covers the multi-rank paths with the world-8 gloo test and the bench pre-flight)
+# (the world = 8 one-GPU rehearsal of round 3 is not repeated: its artefacts are profiles/r03_bench_c*_8ranks_one_gpu_gloo.json; the multi-rank
+#  paths are covered by the world-8 gloo test and the bench pre-flight)
 # fp32 GEMM: per-wave timeline of the two dominant shapes + PMC view, MFMA issue-rate probe
 for shp in "12608 2304 768 8 0" "12608 2304 768 12 0" "12608 768 3072 12 3"; do set -- $shp; timeout 120 tools/probe/gemm_timeline $1 $2 $3 $4 $5 /tmp/tl.csv; python3 tools/gemm_timeline.py /tmp/tl.csv; done > $O/${TAG}_gemm_timeline.txt 2>&1
 timeout 60 tools/probe/mfma_issue_probe > $O/${TAG}_mfma_issue_probe.txt 2>&1
