@@ -96,7 +96,7 @@ def test_bench_line_has_the_contract_keys(config, tmp_path):
     assert d["metric"] == "composed queries/sec" and d["unit"] == "queries/sec"
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert d["value"] > 0 and abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    assert d["value"] > 0 and abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-4      # the compact line rounds to 6 digits
     assert d["dtype"] == ("f32" if config == "c2" else "fp8")
     assert "workload" in d["config"] and "model" not in d["config"]
     roof = d["roofline"]

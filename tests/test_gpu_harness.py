@@ -109,9 +109,9 @@ def test_precision_switch_between_two_harness_calls_reaches_every_lane():
     """the harness caches a 3-lane pipeline on the engine and a forked context copies the parent's precision only when it is
     made.  Switching the engine's precision BETWEEN two `generate_fiq_val_predictions` calls must change all lanes: the second call
     equals a call-by-call run (FERN_HARNESS_LANES=0, the parent context alone) at the new precision, batch by batch."""
-    cfg = synth.CLIP_CONFIGS["tiny-w256"]
+    cfg = synth.CLIP_CONFIGS["tiny-hd64"]
     d = cfg.embed_dim
-    register_tokenizer("tiny", sdata.stub_tokenizer)
+    register_tokenizer("tiny-hd64", lambda texts, context_length=77: sdata.stub_tokenizer(texts, context_length, vocab=cfg.vocab_size))
     gal = sdata.Gallery(200, d, seed=31, image_size=cfg.image_size)
     rel = sdata.RelativeDataset(gal, 96, "fiq", seed=32)           # 6 batches of 16: two per lane
     clip = create_model(cfg, device=DEV, seed=9)
@@ -120,7 +120,7 @@ def test_precision_switch_between_two_harness_calls_reaches_every_lane():
     feats, names, _ = extract_index_features(sdata.ClassicDataset(gal), clip, 13, DEV, d, num_workers=0)
 
     def predictions():
-        return test_fiq.generate_fiq_val_predictions(clip, rel, model, names, feats, DEV, d, 16, 0, "tiny")[0].clone()
+        return test_fiq.generate_fiq_val_predictions(clip, rel, model, names, feats, DEV, d, 16, 0, "tiny-hd64")[0].clone()
 
     eng.set_precision("fp32")
     p_fp32 = predictions()                                          # builds and caches the pipeline at fp32
