@@ -17,8 +17,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libfern.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_bf16.hip", "attn.hip", "elem.hip", "topk.hip", "image.hip", "sweep_bf16.hip"]
-HEADERS = ["kernels.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "fern.h")]
+SOURCES = ["api.hip", "gemm.hip", "gemm_bf16.hip", "gemm_pp.hip", "attn.hip", "elem.hip", "topk.hip", "image.hip", "sweep_bf16.hip"]
+HEADERS = ["kernels.h", "gemm_epilogue.h", "gemm_pp.h", os.path.join("..", "..", "include", "fern.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DFERN_BUILD"]
 
 

@@ -393,8 +393,9 @@ static const TileCfgB kCfgsB[] = {
     {128, 64, 32, 4},    // 4: 4 waves of 64x32, 2 stages
     {64, 64, 32, 8},     // 5: 4 waves of 32x32, 2 stages
     {128, 128, 64, 2},   // 6: as 0 with 128-byte rows (64-element k tiles): whole 128-byte lines per request, half the barriers, 2 per CU
+    {256, 256, 32, 1},   // 7: round 6, gemm_pp.h: 8 waves of 128x64 in two groups half a phase apart, 4-slot ring of 64-byte-row k tiles (128 KiB)
 };
-constexpr int kNumCfgsB = 7;
+constexpr int kNumCfgsB = 8;
 
 static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsB[c].bm - 1) / kCfgsB[c].bm) * ((p.N + kCfgsB[c].bn - 1) / kCfgsB[c].bn);
@@ -406,6 +407,7 @@ static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
         case 4: FERN_LAUNCH((gemm_bf16_glds_kernel<128, 64, 64, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
         case 5: FERN_LAUNCH((gemm_bf16_glds_kernel<64, 64, 32, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
         case 6: FERN_LAUNCH((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
+        case 7: return launch_gemm_pp(false, p, s);
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -441,8 +443,9 @@ static const TileCfgB kCfgsMx[] = {
     {128, 128, 64, 3},    // 8: as 0 with 64-byte rows (one MFMA step per barrier), 3 stages: 50 KiB, 3 workgroups per CU
     {256, 128, 64, 2},    // 9: as 1 with 64-byte rows, 3 stages: 75 KiB, 2 workgroups per CU (needs <= 128 VGPRs)
     {256, 256, 64, 1},    // 10: 8 waves of 128x64, 64-byte rows, 4 stages (136 KiB): fewest staged bytes per FLOP, deep prefetch instead of occupancy
+    {256, 256, 64, 1},    // 11: round 6, gemm_pp.h: the ping-pong form of 10 (two wave groups half a phase apart, one 16 KiB unit staged per phase)
 };
-constexpr int kNumCfgsMx = 11;
+constexpr int kNumCfgsMx = 12;
 static hipError_t launch_cfg_mx(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsMx[c].bm - 1) / kCfgsMx[c].bm) * ((p.N + kCfgsMx[c].bn - 1) / kCfgsMx[c].bn);
     switch (c) {
@@ -457,6 +460,7 @@ static hipError_t launch_cfg_mx(int c, const GemmParams& p, hipStream_t s) {
         case 8: FERN_LAUNCH((gemm_mx8_kernel<128, 128, 64, 64, 3, 3, 64>), dim3(nb), dim3(256), 0, s, p); break;
         case 9: FERN_LAUNCH((gemm_mx8_kernel<256, 128, 64, 64, 3, 4, 64>), dim3(nb), dim3(512), 0, s, p); break;
         case 10: FERN_LAUNCH((gemm_mx8_kernel<256, 256, 128, 64, 4, 2, 64>), dim3(nb), dim3(512), 0, s, p); break;
+        case 11: return launch_gemm_pp(true, p, s);
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

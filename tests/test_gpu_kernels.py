@@ -585,7 +585,7 @@ def test_tuner_concurrency_score_never_changes_a_result(engine):
 
 @pytest.mark.gpu
 @pytest.mark.slow
-@pytest.mark.parametrize("family,n,key", [("bf16", 7, "test_gemm_bf16"), ("fp8", 6, "test_gemm_fp8"), ("mx8", 11, "test_gemm_mx8")])
+@pytest.mark.parametrize("family,n,key", [("bf16", 8, "test_gemm_bf16"), ("fp8", 6, "test_gemm_fp8"), ("mx8", 12, "test_gemm_mx8")])
 def test_every_reduced_precision_gemm_tile_variant(family, n, key):
     """The bf16 / fp8 / block-scaled launchers pick (or tune) a tile per shape; each variant is also forced over its family's suite."""
     r = _forced_family_result(family, list(range(n)), key)
@@ -611,6 +611,46 @@ def test_reduced_precision_gemms_are_batch_invariant(engine):
         assert torch.equal(engine.gemm_mx8(am[lo:hi].contiguous(), sam[:, lo:hi].contiguous(), wq, swm, b, epilogue=0).cpu(), fullm[lo:hi])
         assert torch.equal(engine.gemm_bf16(ab[lo:hi].contiguous(), wb, b, epilogue=1, out_bf16=True).cpu(), full[lo:hi])
         assert torch.equal(engine.gemm_fp8(a8[lo:hi].contiguous(), sa[lo:hi].contiguous(), w8, sw, b, epilogue=0).cpu(), full8[lo:hi])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(300, 320, 128), (1000, 260, 256), (257, 480, 384), (64, 512, 512), (2049, 1000, 1536), (12608, 768, 768)])
+def test_ping_pong_tile_is_bit_identical_to_the_family(engine, m, n, k):
+    """csrc/gemm_pp.h (round 6): the 256 x 256 ping-pong tile -- cfg 7 of the bf16 family, 11 of the block-scaled fp8 family -- against
+    configuration 0 of its family, bit for bit: ragged M / N edges, K shorter than the 4-slot ring (1 .. 3 k tiles), every stored
+    epilogue incl. the bf16 residual stream and the quantising epilogue."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * k ** -0.5
+    b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g)
+    ab, wb, rb = engine.to_bf16(a), engine.to_bf16(w), engine.to_bf16(r)
+    (a8, sa), (w8, sw) = engine.quantize_mx8(a), engine.quantize_mx8(w)
+
+    def outputs(family, cfg):
+        engine.tuner_force_config(family, cfg)
+        try:
+            outs = []
+            if family == "bf16":
+                for epi, res, ob in ((0, None, True), (1, None, True), (2, None, False), (3, r, False), (0, None, False)):
+                    outs.append(engine.gemm_bf16(ab, wb, b, residual=res, epilogue=epi, out_bf16=ob))
+            else:
+                for epi, res, ob in ((0, None, True), (1, None, True), (3, r, False), (3, rb, True), (0, None, False)):
+                    outs.append(engine.gemm_mx8(a8, sa, w8, sw, b, residual=res, epilogue=epi, out_bf16=ob))
+                if n % 128 == 0:
+                    for epi in (0, 1):
+                        outs.extend(engine.gemm_mx8_quant(a8, sa, w8, sw, b, epilogue=epi))
+            torch.cuda.synchronize()
+            return [o.cpu().view(torch.uint8) if o.dtype != torch.float32 else o.cpu() for o in outs]
+        finally:
+            engine.tuner_force_config(family, -1)
+
+    for family, new in (("bf16", 7), ("mx8", 11)):
+        ref, got = outputs(family, 0), outputs(family, new)
+        assert len(ref) == len(got) and len(ref) >= 5
+        for i, (x, y) in enumerate(zip(ref, got)):
+            assert torch.equal(x, y), (family, i)
+        assert all(torch.isfinite(x.float()).all() for x in ref if x.dtype == torch.float32)
 
 
 @pytest.mark.gpu
