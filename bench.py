@@ -704,14 +704,28 @@ def main():
             block[o - start:o - start + m] = eng.gallery_to_bf16(fused) if w["bf16_gallery"] else fused
         return block
 
-    def gather(block):
-        return fd.all_gather_shards(block, n_gal, out=gallery_store)      # bytes on the wire; the gloo debug backend is staged through the host in there
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # fp32 galleries are ranked through their PREPARED form (engine.prepare_gallery: bf16 pre-filter copy + the norms that certify it;
+    # built once, like the index itself): the same exact fp32 scores and ordering, one HBM-bound bf16 pass + rescoring of the few rows
+    # that can still be in the top-K instead of an fp32-MFMA-bound sweep.  Round 6: every rank prepares ONLY ITS SHARD; the fp32 and the
+    # bf16 blocks are all-gathered and the norms MAX-reduced (distributed.all_gather_prepared) -- round 5 prepared the whole gathered
+    # gallery on every rank.  --rank-plain keeps the round-4 stage (plain fp32 gallery) for comparison.
+    use_prepared = not w["bf16_gallery"] and not args.rank_plain
+    prep_store = None
+    if use_prepared:
+        from fashionern_aaai2024_amd.engine import PreparedGallery
+        prep_store = PreparedGallery(gallery_store, torch.empty((world * _per, D), dtype=torch.bfloat16, device=device),
+                                     torch.zeros(4, dtype=torch.float32, device=device))
+
+    def gather(block):
+        if use_prepared:
+            return fd.all_gather_prepared(eng, block, n_gal, out=prep_store)
+        return fd.all_gather_shards(block, n_gal, out=gallery_store)      # bytes on the wire; the gloo debug backend is staged through the host in there
 
     shard = build_shard()
     gallery = gather(shard)                    # warm (RCCL connection setup, workspaces)
@@ -720,6 +734,13 @@ def main():
     shard = build_shard()
     torch.cuda.synchronize()
     fuse_s = time.perf_counter() - t0
+    prepare_ms = None
+    if use_prepared:                           # this rank's share of the preparation (its shard), timed on its own
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.prepare_gallery(shard)
+        torch.cuda.synchronize()
+        prepare_ms = (time.perf_counter() - t0) * 1e3
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
@@ -727,20 +748,9 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     ag_ms = ev0.elapsed_time(ev1)
-    ag_bytes = (world - 1) * per * D * shard.element_size()      # bytes this rank receives
+    ag_bytes = (world - 1) * per * D * (shard.element_size() + (2 if use_prepared else 0))      # bytes this rank receives (fp32 rows + their bf16 copy)
     shard_start = start
-    # fp32 galleries are ranked through their PREPARED form (engine.prepare_gallery: bf16 pre-filter copy + the norms that certify it;
-    # built once, like the index itself): the same exact fp32 scores and ordering, one HBM-bound bf16 pass + rescoring of the few rows
-    # that can still be in the top-K instead of an fp32-MFMA-bound sweep.  --rank-plain keeps the round-4 stage for comparison.
-    gallery_raw = gallery
-    prepare_ms = None
-    if not w["bf16_gallery"] and not args.rank_plain:
-        eng.prepare_gallery(gallery)                          # warm
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        gallery = eng.prepare_gallery(gallery)
-        torch.cuda.synchronize()
-        prepare_ms = (time.perf_counter() - t0) * 1e3
+    gallery_raw = gallery.f32 if use_prepared else gallery
 
     # CIRR extras (c4): one excluded gallery index (the reference image) and 6 img_set members per query
     ex_idx = members = None
@@ -1120,7 +1130,7 @@ def main():
                            "GBs_per_rank": (ag_bytes / (ag_ms * 1e-3) / 1e9) if world > 1 and ag_ms > 0 else None,
                            "xgmi_peak_GBs_per_gpu": XGMI_PEAK_GBS,
                            "frac_of_xgmi": (ag_bytes / (ag_ms * 1e-3) / 1e9 / XGMI_PEAK_GBS) if world > 1 and ag_ms > 0 else None,
-                           "shard_rows": per, "collective": "all_gather_into_tensor of the fused [rows/rank, D] blocks"},
+                           "shard_rows": per, "collective": "all_gather_into_tensor of the fused [rows/rank, D] fp32 blocks" + (" + of their bf16 pre-filter copies (each rank prepares only its shard), all_reduce(MAX) of the 4 norms" if use_prepared else "")},
             "roofline": {"bound": "mfma", "achieved": gemm_tflops, "peak": gemm_peak, "unit": "TFLOP/s",
                          "frac": gemm_tflops / gemm_peak, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": st["gemm_alg_bytes"] / max(1, st["gemm_launches"]) if precision == "fp32" else alg_bytes,

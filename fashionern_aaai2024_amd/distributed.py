@@ -70,9 +70,11 @@ def shard_rows(n: int, rank: int, world: int) -> Tuple[int, int, int]:
     return start, min(n, start + per), per
 
 
-def build_gallery(engine, index_features: torch.Tensor, index_local: torch.Tensor, normalize_input: bool = True) -> torch.Tensor:
+def build_gallery(engine, index_features: torch.Tensor, index_local: torch.Tensor, normalize_input: bool = True, prepared: bool = False):
     """Fused gallery [N, D] on every rank.  ``index_features`` / ``index_local`` are the FULL raw index (every rank
-    holds or can address it); each rank fuses only its shard, then one all_gather replicates the result."""
+    holds or can address it); each rank fuses only its shard, then one all_gather replicates the result.
+    ``prepared`` (world > 1, an engine with `prepare_gallery`): return the gathered `PreparedGallery` (`all_gather_prepared`: each rank
+    prepares only its shard) instead of the fp32 tensor."""
     rank, world = world_info()
     n, d = index_features.shape
     if world == 1:
@@ -83,6 +85,8 @@ def build_gallery(engine, index_features: torch.Tensor, index_local: torch.Tenso
     if stop > start:
         block[: stop - start] = engine.index_fuse(index_features[start:stop], index_local[start:stop],
                                                   normalize_input=normalize_input)
+    if prepared and hasattr(engine, "prepare_gallery") and d % 4 == 0:
+        return all_gather_prepared(engine, block, n)
     full = torch.empty((world * per, d), dtype=torch.float32, device=dev)
     _all_gather_into(full, block)
     return full[:n]
@@ -106,6 +110,43 @@ def all_gather_shards(block: torch.Tensor, n_total: int, out: Optional[torch.Ten
     full = out if out is not None else torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
     _all_gather_into(full, block)      # as bytes: a bf16 gallery (config 5) needs no bf16 support from the backend (gloo has none)
     return full[:n_total]
+
+
+def _all_reduce_max(x: torch.Tensor) -> torch.Tensor:
+    """In-place MAX all-reduce of a small fp32 tensor (through the host under the gloo debug backend with device tensors)."""
+    if dist.get_backend() == "gloo" and x.is_cuda:
+        h = x.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        x.copy_(h)
+    else:
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+    return x
+
+
+def all_gather_prepared(engine, block: torch.Tensor, n_total: int, out=None):
+    """The replicated gallery in its PREPARED form (engine.prepare_gallery: fp32 rows + certified bf16 pre-filter copy + the three norms)
+    without any rank preparing more than its own shard (round 5 all-gathered the fp32 blocks and then ran
+    `fern_gallery_prepare` over the WHOLE gallery on every rank -- 35 ms at 1M rows, W times the work).  `block` [per, D] fp32 is this
+    rank's fused shard, zero-padded to ``per = ceil(n_total / world)`` rows.  Each rank prepares its block; the fp32 blocks and the
+    bf16 blocks are all-gathered (as bytes) and the norms MAX-reduced: a maximum of maxima is exact and a zero padding row has norm 0,
+    so rows, bf16 copy and the four floats are bit for bit what preparing the gathered gallery gives.
+    `out`: a `PreparedGallery` whose tensors are [world * per, D] stores to gather into (a serving process's gallery)."""
+    from .engine import PreparedGallery
+    rank, world = world_info()
+    block = block.contiguous()
+    mine = engine.prepare_gallery(block)
+    if world == 1:
+        if out is None:
+            return PreparedGallery(mine.f32[:n_total], mine.bf16[:n_total], mine.meta)
+        out.f32.copy_(mine.f32)
+        out.bf16.copy_(mine.bf16)
+        out.meta.copy_(mine.meta)
+        return PreparedGallery(out.f32[:n_total], out.bf16[:n_total], out.meta)
+    f32 = all_gather_shards(mine.f32, n_total, out=None if out is None else out.f32)
+    b16 = all_gather_shards(mine.bf16, n_total, out=None if out is None else out.bf16)
+    meta = mine.meta.clone() if out is None else out.meta.copy_(mine.meta)
+    _all_reduce_max(meta)
+    return PreparedGallery(f32, b16, meta)
 
 
 def build_gallery_from_shard(engine, shard_features: torch.Tensor, shard_local: torch.Tensor, n_total: int,

@@ -223,9 +223,11 @@ def _submit_fuse(pipe_box, clip_model, model, device, *args):
         return pipe_box[0].submit_fuse(*args)
 
 
-def fuse_index(model, index_features, index_local_features):
-    """test_fiq.py:45-46.  N ranks: each fuses ceil(N/W) rows, ONE all-gather replicates the fused gallery."""
-    return fd.build_gallery(_engine_of(model), index_features, index_local_features, normalize_input=True)
+def fuse_index(model, index_features, index_local_features, prepared: bool = False):
+    """test_fiq.py:45-46.  N ranks: each fuses ceil(N/W) rows, ONE all-gather replicates the fused gallery.  ``prepared``: under
+    torch.distributed the ranking form of the gallery (`PreparedGallery`) is gathered too -- every rank prepares only its shard --
+    and returned instead of the tensor (what `_ranked` would otherwise build from the whole gallery on every rank)."""
+    return fd.build_gallery(_engine_of(model), index_features, index_local_features, normalize_input=True, prepared=prepared)
 
 
 def _my_rows(q: int):

@@ -15,7 +15,7 @@ def compute_cirr_val_metrics(relative_val_dataset, clip_model, index_features, i
     predicted, reference_names, target_names, group_members = generate_cirr_val_predictions(
         clip_model, relative_val_dataset, model, index_names, index_features, device, feature_dim, batch_size, num_workers,
         clip_model_name)
-    index_fused = _common.fuse_index(model, index_features, index_local_features)
+    index_fused = _common.fuse_index(model, index_features, index_local_features, prepared=True)
     return _common.recalls_cirr(model, predicted, index_fused, index_names, reference_names, target_names, group_members)
 
 

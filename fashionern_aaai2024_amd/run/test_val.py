@@ -16,7 +16,7 @@ def compute_fiq_val_metrics(relative_val_dataset, clip_model, index_features, in
                             feature_dim, batch_size, num_workers, clip_model_name):
     predicted, target_names = generate_fiq_val_predictions(clip_model, relative_val_dataset, model, index_names, index_features,
                                                            device, feature_dim, batch_size, num_workers, clip_model_name)
-    index_fused = _common.fuse_index(model, index_features, index_local_features)
+    index_fused = _common.fuse_index(model, index_features, index_local_features, prepared=True)
     return _common.recalls_unique(model, predicted, index_fused, index_names, target_names, KS)
 
 

@@ -68,11 +68,27 @@ class OracleEngine:
     def l2_normalize(self, x):
         return F.normalize(x.float().cpu(), dim=-1)
 
+    def prepare_gallery(self, gallery, out=None):
+        """CPU restatement of fern_gallery_prepare (include/fern.h): bf16 copy (round to nearest even) + {max ||g - bf16(g)||,
+        max ||bf16(g)||, max ||g||, 0} -- so that the distributed helpers that move PREPARED galleries run under gloo."""
+        from fashionern_aaai2024_amd.engine import PreparedGallery
+        g = gallery.float().cpu().contiguous()
+        b = g.bfloat16()
+        bf = b.float()
+        zero = torch.zeros(())
+        meta = torch.stack([(g - bf).norm(dim=-1).max() if len(g) else zero, bf.norm(dim=-1).max() if len(g) else zero,
+                            g.norm(dim=-1).max() if len(g) else zero, zero]).float()
+        return PreparedGallery(g, b, meta)
+
+    @staticmethod
+    def _rows(gallery):
+        return gallery.f32 if hasattr(gallery, "bf16") and hasattr(gallery, "meta") else gallery
+
     def sim_topk(self, q, gallery, k, idx_offset=0, exclude_idx=None):
-        return orank.cosine_topk(q.float().cpu(), gallery.float().cpu(), k, idx_offset, exclude_idx)
+        return orank.cosine_topk(q.float().cpu(), self._rows(gallery).float().cpu(), k, idx_offset, exclude_idx)
 
     def gather_scores(self, q, gallery, idx):
-        return orank.gather_scores(q.float().cpu(), gallery.float().cpu(), torch.as_tensor(idx))
+        return orank.gather_scores(q.float().cpu(), self._rows(gallery).float().cpu(), torch.as_tensor(idx))
 
     def topk_merge(self, scores, idx):
         return orank.topk_merge(scores.float().cpu(), torch.as_tensor(idx).cpu())

@@ -50,6 +50,22 @@ def _worker(rank, world, port, n, out_dir):
     blk = torch.zeros((per, d), dtype=torch.bfloat16)
     blk[: stop - start] = gallery[start:stop].bfloat16()
     assert torch.equal(fd.all_gather_shards(blk, n), gallery.bfloat16())
+    # the PREPARED form of the replicated gallery: every rank prepares only its own shard, the fp32 and bf16 blocks
+    # are all-gathered and the norms MAX-reduced -- rows, bf16 copy and the four floats equal those of preparing the whole gallery here
+    pblk = torch.zeros((per, d))
+    pblk[: stop - start] = gallery[start:stop]
+    pg = fd.all_gather_prepared(eng, pblk, n)
+    whole = eng.prepare_gallery(gallery)
+    assert torch.equal(pg.f32, whole.f32) and torch.equal(pg.bf16.view(torch.int16), whole.bf16.view(torch.int16))
+    assert torch.equal(pg.meta, whole.meta) and pg.meta[3] == 0 and tuple(pg.shape) == (n, d)
+    store = eng.prepare_gallery(torch.zeros((world * per, d)))                  # a serving process's pre-allocated store
+    pg2 = fd.all_gather_prepared(eng, pblk, n, out=store)
+    assert torch.equal(pg2.f32, whole.f32) and torch.equal(pg2.bf16.view(torch.int16), whole.bf16.view(torch.int16)) and torch.equal(pg2.meta, whole.meta)
+    assert pg2.f32.data_ptr() == store.f32.data_ptr() and pg2.bf16.data_ptr() == store.bf16.data_ptr()
+    pgb = fd.build_gallery(eng, raw, loc, prepared=True)                        # what the harness's compute_* functions call
+    assert torch.equal(pgb.f32, gallery) and torch.equal(pgb.meta, whole.meta)
+    ps, pi = fd.rank_replicated(eng, q_mine, pgb, 7)
+    assert torch.equal(pi, i) and torch.equal(ps, s)
     wrong = 0 if stop > start else 1                                             # any row count but the shard's own is refused
     with pytest.raises(ValueError):
         fd.build_gallery_from_shard(eng, raw[:wrong], loc[:wrong], n)
