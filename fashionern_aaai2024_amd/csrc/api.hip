@@ -817,11 +817,11 @@ extern "C" int fern_finalize_clip(fern_ctx* c, const fern_clip_config* cfg) {
 extern "C" int fern_set_precision(fern_ctx* c, int precision) {
     if (!c) return fail(FERN_ERR_ARG, "fern_set_precision: ctx is NULL");
     if (precision != FERN_PREC_FP32 && precision != FERN_PREC_BF16 && precision != FERN_PREC_FP8 && precision != FERN_PREC_MX8 &&
-        precision != FERN_PREC_F32X3 && precision != FERN_PREC_MX8_MLP)
+        precision != FERN_PREC_F32X3 && precision != FERN_PREC_MX8_MLP && precision != FERN_PREC_MX8_IMG)
         return fail(FERN_ERR_ARG, "fern_set_precision: unknown precision");
     const bool split = precision == FERN_PREC_F32X3;
     if (split) precision = FERN_PREC_FP32;         // fp32 data flow; only the GEMM arithmetic changes
-    if ((precision == FERN_PREC_MX8 || precision == FERN_PREC_MX8_MLP) && c->clip.ready) {
+    if ((precision == FERN_PREC_MX8 || precision == FERN_PREC_MX8_MLP || precision == FERN_PREC_MX8_IMG) && c->clip.ready) {
         for (const auto* blocks : {&c->clip.vblocks, &c->clip.tblocks})
             for (const auto& b : *blocks)
                 if (!b.qkv.wm || !b.out.wm || !b.fc.wm || !b.proj.wm)
@@ -1259,21 +1259,39 @@ static int clip_block_mx8(fern_ctx* c, const ClipBlockW& Bk, unsigned short* Xb,
 // attention), the MLP half -- two thirds of a block's GEMM flops -- as in the block-scaled block (LayerNorm -> e4m3fn + E8M0 scales,
 // c_fc quantising its GELU output where it is produced, c_proj), over the fp32 residual stream of the bf16 / fp8 modes.  Half of the
 // fp8 rounding points of the MX8 mode (and its bf16 residual stream) are gone; bench.py's `reduced_modes` table has what that buys.
+// attn_mx (FERN_PREC_MX8_IMG, round 6): the attention half block-scaled too -- LayerNorm-1 writes e4m3fn + scales, the attention kernel
+// quantises its own output, QKV and out-proj run on the scaled MFMA -- still over the FP32 residual stream: all four GEMMs at the fp8
+// rate without FERN_PREC_MX8's bf16 stream, whose 24 extra roundings per tower cost more Recall than the four GEMMs' operands do.
 static int clip_block_mxmlp(fern_ctx* c, const ClipBlockW& Bk, float* X, float* XN, unsigned short* QKVb, unsigned short* ATTb, unsigned char* H8,
-                            int batch, int S, int width, int heads, int causal, hipStream_t s) {
+                            int batch, int S, int width, int heads, int causal, hipStream_t s, bool attn_mx = false) {
     const long R = (long)batch * S;
     const int hd = width / heads, mlp = Bk.fc.out;
     unsigned short* XNb = reinterpret_cast<unsigned short*>(XN);
-    HIP_TRY(launch_layernorm_bf16(X, Bk.ln1.g, Bk.ln1.b, XNb, R, width, width, width, 1e-5f, s));
-    FERN_TRY(run_gemm_b(c, gemm_desc_b(XNb, width, Bk.qkv, QKVb, 3 * width, (int)R, EPI_BIAS, true), s));
-    AttnParams a{nullptr, nullptr, nullptr, nullptr, 3L * width, 3L * width, 3L * width, (long)width,
-                 batch, heads, hd, S, S, causal, 1.0f / std::sqrt((float)hd), ATTb, QKVb, QKVb + width, QKVb + 2 * width};
-    FERN_TRY(run_attention(c, a, s));
-    GemmParams po = gemm_desc_b(ATTb, width, Bk.out, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
-    po.R = X;
-    FERN_TRY(run_gemm_b(c, po, s));
     unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
     unsigned char* SM = reinterpret_cast<unsigned char*>(XN + ((size_t)R * width / 4 + 63) / 64 * 64);
+    const bool qkv_mx = attn_mx && hd % 32 == 0;
+    if (qkv_mx) {
+        HIP_TRY(launch_layernorm_mx8(X, Bk.ln1.g, Bk.ln1.b, XN8, SM, R, R, width, width, width, 1e-5f, s));
+        FERN_TRY(run_gemm_b(c, gemm_desc_mx(XN8, SM, R, width, Bk.qkv, QKVb, 3 * width, (int)R, EPI_BIAS, true), s));
+    } else {
+        HIP_TRY(launch_layernorm_bf16(X, Bk.ln1.g, Bk.ln1.b, XNb, R, width, width, width, 1e-5f, s));
+        FERN_TRY(run_gemm_b(c, gemm_desc_b(XNb, width, Bk.qkv, QKVb, 3 * width, (int)R, EPI_BIAS, true), s));
+    }
+    AttnParams a{nullptr, nullptr, nullptr, nullptr, 3L * width, 3L * width, 3L * width, (long)width,
+                 batch, heads, hd, S, S, causal, 1.0f / std::sqrt((float)hd), ATTb, QKVb, QKVb + width, QKVb + 2 * width};
+    if (qkv_mx) {      // the attention kernel quantises its output itself (the QKV GEMM is done with SM by now)
+        unsigned char* ATT8 = reinterpret_cast<unsigned char*>(ATTb) + (size_t)R * width * 2;
+        a.out_b = nullptr; a.out_q8 = ATT8; a.out_scales = SM; a.out_srows = R;
+        FERN_TRY(run_attention(c, a, s));
+        GemmParams po = gemm_desc_mx(ATT8, SM, R, width, Bk.out, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
+        po.R = X;
+        FERN_TRY(run_gemm_b(c, po, s));
+    } else {
+        FERN_TRY(run_attention(c, a, s));
+        GemmParams po = gemm_desc_b(ATTb, width, Bk.out, X, width, (int)R, EPI_BIAS_RESIDUAL, false);
+        po.R = X;
+        FERN_TRY(run_gemm_b(c, po, s));
+    }
     HIP_TRY(launch_layernorm_mx8(X, Bk.ln2.g, Bk.ln2.b, XN8, SM, R, R, width, width, width, 1e-5f, s));
     unsigned char* SH = SM + ((size_t)R * (width / 32) + 255) / 256 * 256;      // H's scales, behind the LayerNorm output's
     GemmParams pf = gemm_desc_mx(XN8, SM, R, width, Bk.fc, H8, mlp, (int)R, EPI_BIAS_GELU, false);
@@ -1316,7 +1334,7 @@ static int clip_block_cls_only(fern_ctx* c, const ClipBlockW& Bk, const float* X
         FERN_TRY(run_gemm_b(c, gemm_desc_f8(XN8, SA, width, kv, QKV + width, 3 * width, (int)R, EPI_BIAS, false), s));
         HIP_TRY(launch_gather_rows(X, width, T1, width, batch, width, 1, S, 0, nullptr, s));
         HIP_TRY(launch_layernorm(T1, nullptr, Bk.ln1.g, Bk.ln1.b, T0, batch, width, width, width, 1e-5f, s));
-    } else if (c->precision == FERN_PREC_BF16 || c->precision == FERN_PREC_MX8_MLP) {
+    } else if (c->precision == FERN_PREC_BF16 || c->precision == FERN_PREC_MX8_MLP || c->precision == FERN_PREC_MX8_IMG) {
         // perf mode: the token-level K/V projection takes bf16 operands; the class-row chain below stays fp32
         unsigned short* XNb = reinterpret_cast<unsigned short*>(XN);
         HIP_TRY(launch_layernorm_bf16(X, Bk.ln1.g, Bk.ln1.b, XNb, R, width, width, width, 1e-5f, s));
@@ -1412,9 +1430,9 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
                                     reinterpret_cast<unsigned short*>(ATT), reinterpret_cast<unsigned char*>(ATT) + (size_t)R * vw * 2,
                                     reinterpret_cast<unsigned short*>(H), reinterpret_cast<unsigned char*>(H) + (size_t)R * cf.v_mlp * 2,
                                     b, S, vw, cf.v_heads, 0, s));
-        } else if (c->precision == FERN_PREC_MX8_MLP) {
+        } else if (c->precision == FERN_PREC_MX8_MLP || c->precision == FERN_PREC_MX8_IMG) {
             FERN_TRY(clip_block_mxmlp(c, W.vblocks[l], X, XN, reinterpret_cast<unsigned short*>(QKV), reinterpret_cast<unsigned short*>(ATT),
-                                      reinterpret_cast<unsigned char*>(H), b, S, vw, cf.v_heads, 0, s));
+                                      reinterpret_cast<unsigned char*>(H), b, S, vw, cf.v_heads, 0, s, c->precision == FERN_PREC_MX8_IMG));
         } else if (c->precision == FERN_PREC_BF16)     // XN / ATT / H double as the bf16 operand buffers (half filled)
             FERN_TRY(clip_block_bf16(c, W.vblocks[l], X, reinterpret_cast<unsigned short*>(XN), reinterpret_cast<unsigned short*>(QKV),
                                      reinterpret_cast<unsigned short*>(ATT),
@@ -1544,13 +1562,14 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
     FERN_TRY(ws_get(c, (size_t)R * cf.t_mlp, &H));
     FERN_TRY(ws_get(c, (size_t)B, &eot));
     HIP_TRY(launch_text_embed(tokens, W.tok_emb, W.tpos, X, eot, B, T, tw, cf.vocab_size, c->tok_flag, s));
+    const bool text_mx = c->precision == FERN_PREC_MX8;
     unsigned short* Xb = nullptr;              // FERN_PREC_MX8: the bf16 residual stream of the blocks (clip_block_mx8)
-    if (c->precision == FERN_PREC_MX8) {
+    if (text_mx) {
         FERN_TRY(ws_get(c, (size_t)R * tw, &Xb));
         HIP_TRY(launch_f32_to_bf16(X, Xb, R * tw, s));
     }
     for (int l = 0; l < cf.t_layers; ++l) {
-        if (c->precision == FERN_PREC_MX8) {
+        if (text_mx) {
             unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
             FERN_TRY(clip_block_mx8(c, W.tblocks[l], Xb, XN8, reinterpret_cast<unsigned char*>(XN + ((size_t)R * tw / 4 + 63) / 64 * 64),
                                     reinterpret_cast<unsigned short*>(QKV), reinterpret_cast<unsigned short*>(ATT),
@@ -1562,10 +1581,10 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
                                     reinterpret_cast<unsigned short*>(ATT), reinterpret_cast<unsigned char*>(ATT) + (size_t)R * tw * 2,
                                     reinterpret_cast<unsigned short*>(H), reinterpret_cast<unsigned char*>(H) + (size_t)R * cf.t_mlp * 2,
                                     B, T, tw, cf.t_heads, 1, s));
-        } else if (c->precision == FERN_PREC_MX8_MLP) {
-            FERN_TRY(clip_block_mxmlp(c, W.tblocks[l], X, XN, reinterpret_cast<unsigned short*>(QKV), reinterpret_cast<unsigned short*>(ATT),
-                                      reinterpret_cast<unsigned char*>(H), B, T, tw, cf.t_heads, 1, s));
-        } else if (c->precision == FERN_PREC_BF16)
+        } else if (c->precision == FERN_PREC_BF16 || c->precision == FERN_PREC_MX8_MLP || c->precision == FERN_PREC_MX8_IMG)
+            // FERN_PREC_MX8_MLP / _IMG (round 6): the TEXT tower runs the bf16 block throughout -- its GEMMs (M = 77 B rows, K = 512) are
+            // the ones the block-scaled kernels run worst (0.07-0.12 of their peak) and its rounding points sit directly on the query:
+            // e4m3 there cost 0.9 pp of Recall@50 (bench.py `reduced_modes`: mx8mlp -1.03 -> -0.15 pp) for ~0.1 ms of a 4 ms step
             FERN_TRY(clip_block_bf16(c, W.tblocks[l], X, reinterpret_cast<unsigned short*>(XN), reinterpret_cast<unsigned short*>(QKV),
                                      reinterpret_cast<unsigned short*>(ATT),
                                      reinterpret_cast<unsigned short*>(H), B, T, tw, cf.t_heads, 1, s));

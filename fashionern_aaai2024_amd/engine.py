@@ -21,8 +21,8 @@ COMBINER_TARGET, COMBINER_DVR_GLOBAL, COMBINER_DVR_LOCAL, COMBINER_DVR_FINAL = 0
 SR_TARGET, SR_DVR = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
 PART_DVR, PART_TARGET_SR, PART_TARGET_COMBINER, PART_ALL = 1, 2, 4, 7
-PREC_FP32, PREC_BF16, PREC_FP8, PREC_MX8, PREC_F32X3, PREC_MX8_MLP = 0, 1, 2, 3, 4, 5
-_PREC_NAMES = {"fp32": PREC_FP32, "bf16": PREC_BF16, "fp8": PREC_FP8, "mx8": PREC_MX8, "f32x3": PREC_F32X3, "mx8mlp": PREC_MX8_MLP}
+PREC_FP32, PREC_BF16, PREC_FP8, PREC_MX8, PREC_F32X3, PREC_MX8_MLP, PREC_MX8_IMG = 0, 1, 2, 3, 4, 5, 6
+_PREC_NAMES = {"fp32": PREC_FP32, "bf16": PREC_BF16, "fp8": PREC_FP8, "mx8": PREC_MX8, "f32x3": PREC_F32X3, "mx8mlp": PREC_MX8_MLP, "mx8img": PREC_MX8_IMG}
 PATCH_NUM = 13
 
 
@@ -96,7 +96,8 @@ class FernEngine:
 
     def set_precision(self, precision) -> None:
         """Operand precision of the CLIP towers' token-level GEMMs: "fp32" (parity mode, default), "bf16", "fp8" (per-row
-        scales), "mx8" (block-scaled fp8 on the scaled MFMA) -- or "f32x3": fp32 data, every large plain GEMM computed from three
+        scales), "mx8" (block-scaled fp8 on the scaled MFMA; "mx8mlp": only the image tower's MLP pair, "mx8img": the image tower's
+        four GEMMs over the fp32 residual stream -- both with a bf16 text tower; bench.py's c5 default is "mx8img") -- or "f32x3": fp32 data, every large plain GEMM computed from three
         bf16 planes per operand (fp32-accurate, ~1.4x faster, not the bit-exact fma chain) -- include/fern.h:fern_precision."""
         prec = _PREC_NAMES[precision] if isinstance(precision, str) else int(precision)
         _lib.check(self.lib.fern_set_precision(self._h, prec), "fern_set_precision")

@@ -101,9 +101,18 @@ typedef enum {
      * tile shapes and batch sizes).  The ranking stage never uses it: fern_sim_topk* scores stay the exact chain.  No reference
      * counterpart (cuBLAS's own TF32x3-style modes are the closest relative). */
     FERN_PREC_F32X3 = 4,
-    /* MX8 for the MLP pair only (c_fc + c_proj: two thirds of a block's GEMM flops), BF16 for LayerNorm-1 / QKV / attention / out-proj,
-     * fp32 residual stream: half of MX8's fp8 rounding points at roughly the middle of the two modes' speed (bench.py `reduced_modes`). */
-    FERN_PREC_MX8_MLP = 5
+    /* MX8 for the MLP pair (c_fc + c_proj: two thirds of a block's GEMM flops) of the IMAGE tower, BF16 for LayerNorm-1 / QKV /
+     * attention / out-proj and (round 6) for the whole text tower, fp32 residual stream: the fp8 rounding points that remain sit where
+     * the flops are (the ViT's 12608-row MLP GEMMs), none on the query's text side; between the two modes in speed and the fastest
+     * mode that keeps Recall@50 within 1 pp of the fp32 encoder on bench.py's `reduced_modes` table -- the c5 default since round 6. */
+    FERN_PREC_MX8_MLP = 5,
+    /* Round 6, the c5 default: block-scaled fp8 (MX8) operands for ALL FOUR token-level GEMMs of the IMAGE tower -- LayerNorm-1 / -2 and
+     * the attention kernel write e4m3fn + E8M0 scales, c_fc quantises its GELU output -- over the FP32 residual stream (not MX8's bf16
+     * stream), and the bf16 block for the text tower and the fusion BERT.  All of the ViT's GEMM flops at the fp8 MFMA rate; on bench.py's
+     * `reduced_modes` table (2 048 queries x 8 192 images) Recall@50 moves by 0.0 pp and the top-50 overlap is 0.942, against -2.7 pp /
+     * 0.893 for FERN_PREC_MX8: what costs MX8 its Recall is the text tower's operands (-1.5 pp) and the bf16 residual stream (-1 pp),
+     * not the image tower's fp8 GEMMs. */
+    FERN_PREC_MX8_IMG = 6
 } fern_precision;
 
 typedef enum {

@@ -21,7 +21,7 @@ class OracleEngine:
         self.precision = "fp32"
 
     def set_precision(self, precision):
-        if precision not in ("fp32", "f32x3", "bf16", "fp8", "mx8"):
+        if precision not in ("fp32", "f32x3", "bf16", "fp8", "mx8", "mx8mlp", "mx8img"):
             raise ValueError(precision)
         self.precision = "fp32" if precision == "f32x3" else precision      # f32x3 is fp32-accurate: the fp32 oracle is its checker
 
