@@ -434,15 +434,21 @@ def retrieval_quality_leg(torch, eng, cfg, D, device, modes, n_gallery=8192, que
         return float(hit[:, :10].any(1).float().mean() * 100), float(hit[:, :50].any(1).float().mean() * 100)
 
     r10_0, r50_0 = recalls(base)
+    hit50_0 = (base == target[:, None])[:, :50].any(1)
     for mode in modes:
         idx = ranked[mode]
         r10, r50 = recalls(idx)
         ov = np.mean([len(set(a.tolist()) & set(b.tolist())) / 50.0 for a, b in zip(base[:, :50], idx[:, :50])])
+        hit50 = (idx == target[:, None])[:, :50].any(1)
+        n_in, n_out = int((hit50 & ~hit50_0).sum()), int((~hit50 & hit50_0).sum())      # queries whose target entered / left the top-50
         out[mode] = {"recall_at_10": r10, "recall_at_50": r50, "delta_recall_at_10_pp": r10 - r10_0, "delta_recall_at_50_pp": r50 - r50_0,
+                     "recall_at_50_flips_in_out": [n_in, n_out], "delta_recall_at_50_se_pp": float(np.sqrt(n_in + n_out) / queries * 100),
                      "top1_same": float((idx[:, 0] == base[:, 0]).float().mean()), "top50_overlap": float(ov)}
     return {"queries": queries, "gallery_rows": n_gallery, "reference_mode": modes[0], "modes": out,
             "note": "targets = the fp32 ranking's row at a uniform position 0..63 per query; deltas in percentage points of queries "
-                    "(1 pp = 1 query in 100)"}
+                    "(1 pp = 1 query in 100).  delta_recall_at_50 = (targets that entered the top-50 - targets that left it) / queries: a "
+                    "difference of two counts of boundary flips, with a standard error of sqrt(in + out) / queries (~0.5 pp here) -- two "
+                    "modes whose deltas differ by less than that are not distinguishable on this table; top50_overlap is the stable figure"}
 
 
 def harness_leg(torch, eng, clip, model, cfg, D, device, n_gal, lookup_qps, enc_ips, queries=2048, images=2048):
@@ -578,6 +584,7 @@ def compact_record(full: dict, cap: int = COMPACT_CAP_BYTES) -> dict:
             rcl = (rec.get("accuracy_vs_fp32_encoder") or {}).get("recall") or {}
             if rcl:
                 e["dR50_pp"] = _r(rcl.get("delta_recall_at_50_pp"), 3)
+                e["dR50_se_pp"] = _r(rcl.get("delta_recall_at_50_se_pp"), 2)
                 e["top50_overlap"] = _r(rcl.get("top50_overlap"), 3)
             o[name] = e
         extras.append(("other_configs", o))
@@ -599,7 +606,8 @@ def compact_record(full: dict, cap: int = COMPACT_CAP_BYTES) -> dict:
             if info:
                 e.update({"qps": _r(info.get("value")), "gemm_frac": _r(info.get("gemm_frac"), 3)})
             if m in q:
-                e.update({"dR50_pp": _r(q[m].get("delta_recall_at_50_pp"), 3), "top50_overlap": _r(q[m].get("top50_overlap"), 3)})
+                e.update({"dR50_pp": _r(q[m].get("delta_recall_at_50_pp"), 3), "dR50_se_pp": _r(q[m].get("delta_recall_at_50_se_pp"), 2),
+                          "top50_overlap": _r(q[m].get("top50_overlap"), 3)})
             modes[m] = e
     if modes:
         extras.append(("modes", modes))

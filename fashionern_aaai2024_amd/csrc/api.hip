@@ -95,7 +95,7 @@ struct ClipW {
     ResNetW res;
     fern_clip_config cfg{};
     const float *conv_w = nullptr, *cls = nullptr, *vpos = nullptr, *vproj_t = nullptr;
-    LinearW conv_mx;                 // conv1 as a [width, 3 * patch * patch] linear layer: the block-scaled copy (FERN_PREC_MX8 patch embedding)
+    LinearW conv_mx;                 // conv1 as a [width, 3 * patch * patch] linear layer: its block-scaled copy (FERN_PREC_MX8 patch embedding) and its bf16 copy (bf16-operand modes)
     LNW ln_pre, ln_post, ln_final;
     std::vector<ClipBlockW> vblocks, tblocks;
     const float *tok_emb = nullptr, *tpos = nullptr, *tproj_t = nullptr;
@@ -790,6 +790,7 @@ extern "C" int fern_finalize_clip(fern_ctx* c, const fern_clip_config* cfg) {
         FERN_TRY(up_key(c, "visual.conv1.weight", {vw, 3, P, P}, &W.conv_w));
         W.conv_mx = LinearW{W.conv_w, nullptr, vw, 3 * P * P};
         FERN_TRY(make_mx8(c, &W.conv_mx));
+        FERN_TRY(make_bf16(c, &W.conv_mx));
         FERN_TRY(up_key(c, "visual.class_embedding", {vw}, &W.cls));
         FERN_TRY(up_key(c, "visual.positional_embedding", {tokens, vw}, &W.vpos));
         FERN_TRY(up_ln(c, "visual.ln_pre", vw, &W.ln_pre));
@@ -1399,6 +1400,16 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
         GemmParams pm = gemm_desc_mx(A8, SA, rows, kd, W.conv_mx, X, vw, (int)rows, EPI_PATCH_EMBED, false);
         pm.aux0 = W.vpos; pm.grid = g;
         FERN_TRY(run_gemm_b(c, pm, s));
+    } else if ((c->precision == FERN_PREC_BF16 || c->precision == FERN_PREC_MX8_MLP || c->precision == FERN_PREC_MX8_IMG) && W.conv_mx.wb &&
+               (3 * cf.patch_size * cf.patch_size) <= 1280) {
+        // bf16-operand modes (round 6): patch rows rounded to bf16 once (H is free until the first block), conv1 on the bf16 MFMA; same epilogue
+        const int kd = 3 * cf.patch_size * cf.patch_size;
+        const long rows = (long)b * g2;
+        unsigned short* Ab = reinterpret_cast<unsigned short*>(H);
+        HIP_TRY(launch_im2col_bf16(images, Ab, b, cf.image_size, cf.patch_size, g, s));
+        GemmParams pb = gemm_desc_b(Ab, kd, W.conv_mx, X, vw, (int)rows, EPI_PATCH_EMBED, false);
+        pb.aux0 = W.vpos; pb.grid = g;
+        FERN_TRY(run_gemm_b(c, pb, s));
     } else {
     // conv1 as an im2col-free GEMM; epilogue adds the positional embedding and skips the class slot
     GemmParams pe{};

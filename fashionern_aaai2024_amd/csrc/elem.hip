@@ -385,8 +385,10 @@ static bool launch_ln_rows(const void* x, const float* gamma, const float* beta,
 // row -- one 16-byte load and one 8-byte store per chunk, 512 contiguous bytes per half-wave -- and a 32-element MX block is 4 lanes.
 // The fp8 bytes leave with nt stores: the next kernel reads them from other XCDs anyway.  Statistics: the row's 32 lanes on the DPP
 // network, the two 16-lane rows of the half added in a fixed order; used for EVERY row count of a width it covers (batch-invariant).
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_half_kernel(const unsigned short* x, const float* gamma, const float* beta, unsigned char* y, unsigned char* scales,
+// F32IN (round 6, FERN_PREC_MX8_MLP / _MX8_IMG: block-scaled operands over the FP32 residual stream): the same kernel on fp32 rows --
+// two 16-byte loads per chunk and lane -- instead of the four-rows-per-wave kernel (14.0 us at 12608 x 768, 22 launches per step).
+template <int NV, bool F32IN = false>
+__global__ __launch_bounds__(256) void layernorm_half_kernel(const void* xin, const float* gamma, const float* beta, unsigned char* y, unsigned char* scales,
                                                              long srows, long rows, long ldx, long ldy, float eps) {
     constexpr int D = 256 * NV;
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
@@ -395,12 +397,24 @@ __global__ __launch_bounds__(256) void layernorm_half_kernel(const unsigned shor
     const long row = rowp + lh;
     const long rrow = row < rows ? row : rows - 1;             // an odd row count: the last wave's upper half re-reads the last row (not stored)
     float v[NV][8];
+    if (F32IN) {
+        const float* x = reinterpret_cast<const float*>(xin);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const uint4 w = *reinterpret_cast<const uint4*>(x + rrow * ldx + (i * 32 + l31) * 8);
-        const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+        for (int i = 0; i < NV; ++i) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + rrow * ldx + (i * 32 + l31) * 8);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(x + rrow * ldx + (i * 32 + l31) * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[i][2 * e] = __uint_as_float(ww[e] << 16); v[i][2 * e + 1] = __uint_as_float(ww[e] & 0xffff0000u); }
+            for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = b[e]; }
+        }
+    } else {
+        const unsigned short* x = reinterpret_cast<const unsigned short*>(xin);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const uint4 w = *reinterpret_cast<const uint4*>(x + rrow * ldx + (i * 32 + l31) * 8);
+            const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][2 * e] = __uint_as_float(ww[e] << 16); v[i][2 * e + 1] = __uint_as_float(ww[e] & 0xffff0000u); }
+        }
     }
     float g[NV][8], bb[NV][8];
 #pragma unroll
@@ -449,15 +463,16 @@ __global__ __launch_bounds__(256) void layernorm_half_kernel(const unsigned shor
         }
     }
 }
-static bool launch_ln_half(const unsigned short* x, const float* gamma, const float* beta, unsigned char* y, unsigned char* scales, long srows, long rows, int d,
+template <bool F32IN>
+static bool launch_ln_half(const void* x, const float* gamma, const float* beta, unsigned char* y, unsigned char* scales, long srows, long rows, int d,
                            long ldx, long ldy, float eps, hipStream_t s) {
     if (d % 256 || d > 1024 || (ldx & 7) || (ldy & 7) || ((uintptr_t)x & 15) || ((uintptr_t)y & 7) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) return false;
     const dim3 grid((unsigned)((rows + ROWS_PER_BLOCK * 2 - 1) / (ROWS_PER_BLOCK * 2)));
     switch (d / 256) {
-        case 1: hipLaunchKernelGGL((layernorm_half_kernel<1>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
-        case 2: hipLaunchKernelGGL((layernorm_half_kernel<2>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
-        case 3: hipLaunchKernelGGL((layernorm_half_kernel<3>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
-        default: hipLaunchKernelGGL((layernorm_half_kernel<4>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
+        case 1: hipLaunchKernelGGL((layernorm_half_kernel<1, F32IN>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
+        case 2: hipLaunchKernelGGL((layernorm_half_kernel<2, F32IN>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
+        case 3: hipLaunchKernelGGL((layernorm_half_kernel<3, F32IN>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
+        default: hipLaunchKernelGGL((layernorm_half_kernel<4, F32IN>), grid, dim3(256), 0, s, x, gamma, beta, y, scales, srows, rows, ldx, ldy, eps); break;
     }
     return true;
 }
@@ -489,6 +504,31 @@ __global__ __launch_bounds__(256) void im2col_mx8_kernel(const float* images, un
             const float inv = mx_inv_scale(e);
             *reinterpret_cast<unsigned*>(yr + k) = pack4_fp8(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
             if ((lane & 7) == 0) scales[mx_scale_offset(row, k >> 5, srows)] = (unsigned char)e;
+        }
+    }
+}
+
+// The same patch rows as bf16 (round to nearest even): the patch embedding of the bf16-operand modes (FERN_PREC_BF16 / _MX8_MLP /
+// _MX8_IMG, round 6) is a plain bf16 GEMM -- the im2col-loading fp32 GEMM took 166 us of a 4.9 ms step where this pair takes ~40.
+__global__ __launch_bounds__(256) void im2col_bf16_kernel(const float* images, unsigned short* y, long rows, int img, int patch, int grid) {
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int pp = patch * patch, d = 3 * pp, g2 = grid * grid;
+    const long b = row / g2;
+    const int gy = (int)(row % g2) / grid, gx = (int)(row % g2) % grid;
+    const float* src = images + b * 3L * img * img + (long)(gy * patch) * img + gx * patch;
+    unsigned short* yr = y + row * d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int k = (i * 64 + lane) * 4;
+        if (k < d) {
+            const int ch = k / pp, rem = k % pp;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((long)ch * img + rem / patch) * img + rem % patch);
+            uint2 o;
+            o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+            o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+            *reinterpret_cast<uint2*>(yr + k) = o;
         }
     }
 }
@@ -957,7 +997,9 @@ hipError_t launch_layernorm_mx8(const float* x, const float* gamma, const float*
                                 long rows, int d, long ldx, long ldy, float eps, hipStream_t s, const unsigned short* x_bf16) {
     if (rows <= 0) return hipSuccess;
     if (d <= 0 || d % 128 || d > 256 * MAXV || (ldx & 3) || (ldy & 3) || srows < rows) return hipErrorInvalidValue;
-    if (x_bf16 && launch_ln_half(x_bf16, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps, s)) return hipGetLastError();
+    if (x_bf16 ? launch_ln_half<false>(x_bf16, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps, s)
+               : launch_ln_half<true>(x, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps, s))
+        return hipGetLastError();
     if (x_bf16 ? launch_ln_rows<1, 1>(x_bf16, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps, s)
                : launch_ln_rows<0, 1>(x, gamma, beta, y, scales, srows, rows, d, ldx, ldy, eps, s))
         return hipGetLastError();
@@ -972,6 +1014,14 @@ hipError_t launch_im2col_mx8(const float* images, unsigned char* y, unsigned cha
     const int d = 3 * patch * patch;
     if (d % 128 || d > 256 * MAXV || (patch & 3) || (img & 3) || grid * patch != img || srows < rows) return hipErrorInvalidValue;
     hipLaunchKernelGGL(im2col_mx8_kernel, row_grid(rows), dim3(256), 0, s, images, y, scales, srows, rows, img, patch, grid);
+    return hipGetLastError();
+}
+hipError_t launch_im2col_bf16(const float* images, unsigned short* y, int b, int img, int patch, int grid, hipStream_t s) {
+    const long rows = (long)b * grid * grid;
+    if (rows <= 0) return hipSuccess;
+    const int d = 3 * patch * patch;
+    if (d % 32 || d > 256 * MAXV || (patch & 3) || (img & 3) || grid * patch != img) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(im2col_bf16_kernel, row_grid(rows), dim3(256), 0, s, images, y, rows, img, patch, grid);
     return hipGetLastError();
 }
 hipError_t launch_quantize_mx8(const unsigned short* x_bf16, const float* x_f32, long ldx, unsigned char* y, long ldy, unsigned char* scales,

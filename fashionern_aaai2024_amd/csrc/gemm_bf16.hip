@@ -394,8 +394,13 @@ static const TileCfgB kCfgsB[] = {
     {64, 64, 32, 8},     // 5: 4 waves of 32x32, 2 stages
     {128, 128, 64, 2},   // 6: as 0 with 128-byte rows (64-element k tiles): whole 128-byte lines per request, half the barriers, 2 per CU
     {256, 256, 32, 1},   // 7: round 6, gemm_pp.h: 8 waves of 128x64 in two groups half a phase apart, 4-slot ring of 64-byte-row k tiles (128 KiB)
+    // round 6, the short-K shapes of the text tower / fusion BERT (M = 4928 / 5824, K = 512): with 32-element k tiles and ONE tile in
+    // flight a 16-tile k loop is 16 L2 round trips -- every such GEMM took ~20 us whatever its size (129 TFLOP/s at N = 512).  128-byte
+    // rows halve the round trips, the third stage keeps two tiles in flight
+    {64, 64, 64, 3},     // 8: 4 waves of 32x32, 128-byte rows, 3 stages (48 KiB)
+    {64, 128, 64, 2},    // 9: 4 waves of 32x64, 128-byte rows, 3 stages (72 KiB)
 };
-constexpr int kNumCfgsB = 8;
+constexpr int kNumCfgsB = 10;
 
 static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
     const int nb = ((p.M + kCfgsB[c].bm - 1) / kCfgsB[c].bm) * ((p.N + kCfgsB[c].bn - 1) / kCfgsB[c].bn);
@@ -408,6 +413,8 @@ static hipError_t launch_cfg_b(int c, const GemmParams& p, hipStream_t s) {
         case 5: FERN_LAUNCH((gemm_bf16_glds_kernel<64, 64, 32, 32, 32, 2, 4>), dim3(nb), dim3(256), 0, s, p); break;
         case 6: FERN_LAUNCH((gemm_bf16_glds_kernel<128, 128, 64, 64, 64, 2, 2>), dim3(nb), dim3(256), 0, s, p); break;
         case 7: return launch_gemm_pp(false, p, s);
+        case 8: FERN_LAUNCH((gemm_bf16_glds_kernel<64, 64, 32, 32, 64, 3, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        case 9: FERN_LAUNCH((gemm_bf16_glds_kernel<64, 128, 32, 64, 64, 3, 2>), dim3(nb), dim3(256), 0, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -316,6 +316,7 @@ hipError_t launch_layernorm_mx8(const float* x, const float* gamma, const float*
 hipError_t launch_quantize_mx8(const unsigned short* x_bf16, const float* x_f32, long ldx, unsigned char* y, long ldy, unsigned char* scales,
                                long srows, long rows, int d, hipStream_t s);
 // patch rows [b * grid * grid, 3 * patch * patch] of an image batch ((channel, y, x) order = conv1's weight layout), MX-quantised
+hipError_t launch_im2col_bf16(const float* images, unsigned short* y, int b, int img, int patch, int grid, hipStream_t s);
 hipError_t launch_im2col_mx8(const float* images, unsigned char* y, unsigned char* scales, long srows, int b, int img, int patch, int grid,
                              hipStream_t s);
 // mode 0: x / max(||x||, eps) (F.normalize); mode 1: x / (||x|| + eps) (VisualSR.l2norm)

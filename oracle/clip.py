@@ -211,6 +211,10 @@ def encode_image(sd, cfg, images, precision="fp32"):
         # the block-scaled mode runs conv1 as a linear layer over patch rows ((channel, y, x) order) with block-scaled operands
         patches = F.unfold(images, kernel_size=cfg.patch_size, stride=cfg.patch_size).transpose(1, 2)    # [b, g*g, 3*P*P]
         x = _linear(patches, w.flatten(1), None, "mx8")
+    elif precision == "bf16" and w[0].numel() % 32 == 0 and w[0].numel() <= 1280:
+        # the bf16-operand modes (round 6) run conv1 as a linear layer over bf16-rounded patch rows and the bf16 copy of its weight
+        patches = F.unfold(images, kernel_size=cfg.patch_size, stride=cfg.patch_size).transpose(1, 2)    # [b, g*g, 3*P*P]
+        x = _linear(patches, w.flatten(1), None, "bf16")
     else:
         x = F.conv2d(images, w, stride=cfg.patch_size)                  # modeling_clip.py:180-196
         x = x.flatten(2).transpose(1, 2)                                # [b, g*g, width]

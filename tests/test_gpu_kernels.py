@@ -585,7 +585,7 @@ def test_tuner_concurrency_score_never_changes_a_result(engine):
 
 @pytest.mark.gpu
 @pytest.mark.slow
-@pytest.mark.parametrize("family,n,key", [("bf16", 8, "test_gemm_bf16"), ("fp8", 6, "test_gemm_fp8"), ("mx8", 12, "test_gemm_mx8")])
+@pytest.mark.parametrize("family,n,key", [("bf16", 10, "test_gemm_bf16"), ("fp8", 6, "test_gemm_fp8"), ("mx8", 12, "test_gemm_mx8")])
 def test_every_reduced_precision_gemm_tile_variant(family, n, key):
     """The bf16 / fp8 / block-scaled launchers pick (or tune) a tile per shape; each variant is also forced over its family's suite."""
     r = _forced_family_result(family, list(range(n)), key)
