@@ -675,6 +675,7 @@ def main():
         tensors[0].copy_(host[0])
 
     # ---- weights (random init, real architecture) and synthetic inputs, resident in HBM --------------------
+    stamp("imports_done")
     clip_sd = synth.clip_state_dict(cfg, seed=0)
     fusion_sd = synth.fusion_state_dict(D, seed=0)
     clip = create_model(cfg, device=device)
@@ -738,6 +739,7 @@ def main():
             return fd.all_gather_prepared(eng, block, n_gal, out=prep_store)
         return fd.all_gather_shards(block, n_gal, out=gallery_store)      # bytes on the wire; the gloo debug backend is staged through the host in there
 
+    stamp("weights_and_inputs_resident")
     shard = build_shard()
     gallery = gather(shard)                    # warm (RCCL connection setup, workspaces)
     barrier()
@@ -838,7 +840,9 @@ def main():
             step_serial(j)
         barrier()
         return
+    stamp("gallery_built_and_warm")
     elapsed, last, gap_median = timed_loop(step, args.steps)
+    stamp("timed_region_done")
     value = world * B * args.steps / elapsed
     headline_latency = last_latency[0]
 
@@ -955,6 +959,7 @@ def main():
             quality["modes"][precision]["queries_per_s"] = value
             accuracy["recall"] = quality["modes"][precision]
 
+    stamp("mode_and_quality_legs_done")
     # ---- roofline: instrumented passes (events around every kernel class), outside the timed region ----------
     for j in range(n_batches):
         step_serial(j)
@@ -1110,6 +1115,7 @@ def main():
         torch.cuda.empty_cache()
         harness_info = harness_leg(torch, eng, clip, model, cfg, D, device, n_gal, lookup_qps, enc_ips) if rank == 0 else None
 
+    stamp("roofline_lookup_pcie_1M_harness_legs_done")
     result = None
     if rank == 0:
         traffic = traffic_src = alg_bytes = sweep_traffic = None
