@@ -32,6 +32,7 @@
 #pragma once
 #include "gemm_epilogue.h"
 
+
 namespace fern {
 
 typedef short pp_bf16x8 __attribute__((ext_vector_type(8)));
@@ -49,6 +50,8 @@ __device__ __forceinline__ void pp_wait_vmcnt() {
 }
 // wait until all but the `younger` most recent vector-memory operations of this wave are done (wave-uniform value, 0 .. 9+)
 __device__ __forceinline__ void pp_wait_vmcnt_dyn(int younger) {
+    if (younger == 8) { pp_wait_vmcnt<8>(); return; }      // the steady states of the two operand kinds first (one compare each)
+    if (younger == 9) { pp_wait_vmcnt<9>(); return; }
     switch (younger) {
         case 0: pp_wait_vmcnt<0>(); break;
         case 1: pp_wait_vmcnt<1>(); break;
@@ -64,6 +67,56 @@ __device__ __forceinline__ void pp_wait_vmcnt_dyn(int younger) {
         case 11: pp_wait_vmcnt<11>(); break;
         default: pp_wait_vmcnt<12>(); break;
     }
+}
+
+
+// Quantising epilogue (gemm_mx8_kernel's): bias (+ GELU) in the accumulator layout, each 32x32 tile turned through a private LDS patch so
+// that a lane holds 16 consecutive columns of ONE row (2 lanes per row = one 32-column MX block): block maximum -> E8M0 byte -> 16 e4m3fn
+// bytes, one 16-byte store per lane.  The caller has passed the barrier after which no wave reads the operand ring any more.
+template <int TM, int TN>
+__device__ __forceinline__ void pp_quant_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], char* smem, int row_w, int col_w, int wave, int lane, int l31, int lh) {
+    constexpr int PS = 36;
+    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PS);
+    const int rr = lane >> 1, hh = lane & 1;
+    unsigned char* C8 = reinterpret_cast<unsigned char*>(p.C);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row0 = row_w + i * 32, col0 = col_w + j * 32;
+            if (row0 >= p.M || col0 >= p.N) continue;
+            const float bia = p.bias ? p.bias[col0 + l31] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 v2 = {acc[i][j][r] + bia, acc[i][j][r + 1] + bia};
+                if (p.epi == EPI_BIAS_GELU) v2 = gelu_tanh2(v2);
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PS + l31] = v2[0];
+                patch[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh) * PS + l31] = v2[1];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f32x4 v4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const f32x4*>(patch + rr * PS + hh * 16 + q * 4);
+            float am = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(v4[q][e]));
+            am = fmaxf(am, __shfl_xor(am, 1));
+            const unsigned e8 = mx_scale_byte(am);
+            const float inv = mx_inv_scale(e8);
+            uint4 o;
+            o.x = pack4_fp8(v4[0][0] * inv, v4[0][1] * inv, v4[0][2] * inv, v4[0][3] * inv);
+            o.y = pack4_fp8(v4[1][0] * inv, v4[1][1] * inv, v4[1][2] * inv, v4[1][3] * inv);
+            o.z = pack4_fp8(v4[2][0] * inv, v4[2][1] * inv, v4[2][2] * inv, v4[2][3] * inv);
+            o.w = pack4_fp8(v4[3][0] * inv, v4[3][1] * inv, v4[3][2] * inv, v4[3][3] * inv);
+            const int row = row0 + rr;
+            if (row < p.M) {
+                *reinterpret_cast<uint4*>(C8 + (long)row * p.ldc + col0 + hh * 16) = o;
+                if (hh == 0) p.mxc[mx_scale_offset(row, col0 >> 5, p.mxc_rows)] = (unsigned char)e8;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
 }
 
 // MX = false: bf16 operands (p.Ab / p.Wb bf16 bit patterns, strides in elements).  MX = true: e4m3fn bytes + E8M0 block scales
@@ -340,54 +393,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
         gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N, true, MX ? 2 : 1, !MX>(p, acc, bm, bn, nbn, wr, wc, l31, lh, tid);
         return;
     }
-    if constexpr (MX) {
-        // Quantising epilogue (gemm_mx8_kernel's): bias (+ GELU) in the accumulator layout, each 32x32 tile turned through a private LDS
-        // patch so that a lane holds 16 consecutive columns of ONE row (2 lanes per row = one 32-column MX block): block maximum ->
-        // E8M0 byte -> 16 e4m3fn bytes, one 16-byte store per lane.  The barrier above is the "every wave is done with the ring" one.
-        constexpr int PS = 36;
-        float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PS);
-        const int row_w = bm * BM + wr * WM, col_w = bn * BN + wc * WN;
-        const int rr = lane >> 1, hh = lane & 1;
-        unsigned char* C8 = reinterpret_cast<unsigned char*>(p.C);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row0 = row_w + i * 32, col0 = col_w + j * 32;
-                if (row0 >= p.M || col0 >= p.N) continue;
-                const float bia = p.bias ? p.bias[col0 + l31] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    f32x2 v2 = {acc[i][j][r] + bia, acc[i][j][r + 1] + bia};
-                    if (p.epi == EPI_BIAS_GELU) v2 = gelu_tanh2(v2);
-                    patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PS + l31] = v2[0];
-                    patch[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh) * PS + l31] = v2[1];
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                f32x4 v4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const f32x4*>(patch + rr * PS + hh * 16 + q * 4);
-                float am = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(v4[q][e]));
-                am = fmaxf(am, __shfl_xor(am, 1));
-                const unsigned e8 = mx_scale_byte(am);
-                const float inv = mx_inv_scale(e8);
-                uint4 o;
-                o.x = pack4_fp8(v4[0][0] * inv, v4[0][1] * inv, v4[0][2] * inv, v4[0][3] * inv);
-                o.y = pack4_fp8(v4[1][0] * inv, v4[1][1] * inv, v4[1][2] * inv, v4[1][3] * inv);
-                o.z = pack4_fp8(v4[2][0] * inv, v4[2][1] * inv, v4[2][2] * inv, v4[2][3] * inv);
-                o.w = pack4_fp8(v4[3][0] * inv, v4[3][1] * inv, v4[3][2] * inv, v4[3][3] * inv);
-                const int row = row0 + rr;
-                if (row < p.M) {
-                    *reinterpret_cast<uint4*>(C8 + (long)row * p.ldc + col0 + hh * 16) = o;
-                    if (hh == 0) p.mxc[mx_scale_offset(row, col0 >> 5, p.mxc_rows)] = (unsigned char)e8;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-    }
+    if constexpr (MX) pp_quant_epilogue<TM, TN>(p, acc, smem, bm * BM + wr * WM, bn * BN + wc * WN, wave, lane, l31, lh);
 }
+
 
 }  // namespace fern

@@ -7,7 +7,8 @@
 namespace fern {
 
 // FERN_PP_VAR (lab switch, read once): kernel variant -- 0: LDS-DMA staging in the load sections, 1 (default): in the MFMA sections
-// (profiles/r06_pp_lab.txt: bf16 4096^3 965 -> 1083 TFLOP/s).  Every variant returns the same bits.
+// (profiles/r06_pp_lab.txt: bf16 4096^3 965 -> 1083 TFLOP/s).  Every variant returns the same bits.  (A software-pipelined form with one barrier per phase --
+// next phase's fragment reads between this phase's MFMAs -- was built, bit-identical and slower: profiles/r06_pp_lab.txt)
 static int pp_variant() {
     static const int v = [] { const char* e = getenv("FERN_PP_VAR"); return e ? atoi(e) : 1; }();
     return v;
