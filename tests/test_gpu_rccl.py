@@ -43,6 +43,24 @@ out["preflight"] = {"rccl_world": info["rccl_world"], "backend": info["backend"]
 t = torch.tensor([1.5], dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 out["all_reduce"] = t.item()
+# round 6: the prepared gallery gathered shard-wise (distributed.all_gather_prepared) on the real engine: rows, bf16 copy and the four
+# norms equal those of preparing the whole gallery, also into a pre-allocated store; its MAX-reduce of the norms on the device
+from fashionern_aaai2024_amd.engine import FernEngine, PreparedGallery
+eng = FernEngine(dev)
+g = torch.nn.functional.normalize(torch.randn(1000, 512, device=dev), dim=-1)
+whole = eng.prepare_gallery(g)
+pg = fd.all_gather_prepared(eng, g, 1000)
+store = PreparedGallery(torch.empty_like(g), torch.empty(g.shape, dtype=torch.bfloat16, device=dev), torch.zeros(4, device=dev))
+pg2 = fd.all_gather_prepared(eng, g, 1000, out=store)
+m = fd._all_reduce_max(whole.meta.clone())
+q = torch.nn.functional.normalize(torch.randn(8, 512, device=dev), dim=-1)
+s0, i0 = eng.sim_topk(q, whole, 50)
+s1, i1 = eng.sim_topk(q, pg2, 50)
+torch.cuda.synchronize()
+out["prepared"] = bool(torch.equal(pg.f32, whole.f32) and torch.equal(pg.bf16.view(torch.int16), whole.bf16.view(torch.int16)) and torch.equal(pg.meta, whole.meta)
+                       and torch.equal(pg2.bf16.view(torch.int16), whole.bf16.view(torch.int16)) and torch.equal(pg2.meta, whole.meta) and torch.equal(m, whole.meta)
+                       and pg2.f32.data_ptr() == store.f32.data_ptr() and torch.equal(i0, i1) and torch.equal(s0, s1))
+eng.close()
 dist.barrier()
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out))
@@ -64,3 +82,4 @@ def test_rccl_world1_group_runs_the_byte_view_all_gather_the_object_collectives_
     assert out["bf16"] and out["int32"] and out["f32"] and out["objects"]
     assert out["preflight"]["rccl_world"] == 1 and out["preflight"]["backend"] == "nccl" and out["preflight"]["payload_ok"]
     assert out["preflight"]["ms"] > 0 and out["all_reduce"] == 1.5
+    assert out["prepared"], "all_gather_prepared differs from preparing the whole gallery"
