@@ -8,12 +8,13 @@
 //
 //   * 8 waves = 2 (M) x 4 (N), 128 x 64 outputs each (4 x 2 accumulator tiles, 128 registers), two waves per SIMD.  The two waves
 //     of a SIMD belong to different M halves ("groups"), and the groups run HALF A PHASE APART: one s_barrier more at the start of
-//     group 1.  Every phase is  [LDS reads + LDS-DMA staging]  s_barrier  [8 MFMAs, s_setprio 1]  s_barrier , so while one
-//     group's waves issue their 256 cycles of MFMAs the other group's waves -- on the same SIMDs -- issue the loads of their
-//     next phase: memory instructions never sit in front of the matrix pipe.
+//     group 1.  Every phase is  [LDS reads]  s_barrier  [8 MFMAs under s_setprio 1]  s_barrier , so while one group's waves issue
+//     their 256 cycles of MFMAs the other group's waves -- on the same SIMDs -- issue the reads of their next phase.  The phase's two
+//     LDS-DMA instructions go out BETWEEN the MFMAs (VAR 1, the default: in the matrix pipe's shadow; VAR 0 issued them in the load
+//     section, where they were what the OTHER group's MFMAs ended up waiting for: 965 -> 1 083 TFLOP/s at 4096^3 bf16).
 //   * k tiles of 64 BYTES per row (32 bf16 / 64 fp8 k) in a ring of NB = 4 slots of 32 KiB (A rows 16 KiB + W rows 16 KiB): two
-//     phases per k tile (the wave's upper / lower 64 x 64 half of C), ONE 16 KiB unit staged per phase, 64 KiB in flight at the
-//     point where a k tile's arrival is awaited -- a unit has four phases (~1 us) to land instead of one.  The staging of a unit
+//     phases per k tile (the wave's upper / lower 64 x 64 half of C), ONE 16 KiB unit staged per phase, 48-64 KiB in flight at the
+//     point where a k tile's arrival is awaited -- a unit has three to four phases (~1 us) to land instead of one.  The staging of a unit
 //     follows the last read of the unit it replaces by exactly the barriers that order it (derivation below).
 //   * every accumulator adds its 16-wide (bf16) / 64-wide (fp8) k groups in ascending order: bit-identical to every other tile
 //     configuration of the family.
@@ -24,11 +25,13 @@
 //     WAR:    W of k tile t is last read in phase 2t: G0's reads retire (lgkmcnt(0)) after barrier 4t, G1's after barrier 4t+1, and
 //             every wave that has passed barrier 4t+2 knows it.  A of k tile t is last read in phase 2t+1: known after barrier 4t+4.
 //             The slot of k tile t is refilled with k tile t+NB: its W unit in phase 2t+2 (issued by G0 after barrier 4t+3, by G1
-//             after 4t+4), its A unit in phase 2t+3 (after barriers 4t+5 / 4t+6).
+//             after 4t+4), its A unit in phase 2t+3 (after barriers 4t+5 / 4t+6) -- VAR 1 issues them one barrier later still.
 //     RAW:    an LDS-DMA write is ordered for a ds_read only by the ISSUING wave's counted vmcnt followed by a barrier the reader
-//             has passed.  Every wave waits for k tile T+1 at the end of its load section of phase 2T+1 (all but the
-//             2 x min(NB-2, nk-2-T) units issued after it), i.e. before barrier 4T+2 (G0) / 4T+3 (G1); k tile T+1 is first read
-//             in phase 2T+2, by G0 after barrier 4T+3.
+//             has passed.  Every wave waits for k tile T+1 at the end of its load section of phase 2T+1 (all but the operations it
+//             has issued after that k tile's last one: 2 x min(NB-2, nk-2-T) units, one fewer under VAR 1, whose A unit of the
+//             newest k tile leaves after this wait), i.e. before barrier 4T+2 (G0) / 4T+3 (G1); k tile T+1 is first read in phase
+//             2T+2, by G0 after barrier 4T+3.
+// What it reaches, the elimination runs and the per-phase stamps: profiles/r06_pp_lab.txt, DESIGN.md 4 / 8 / 9.
 #pragma once
 #include "gemm_epilogue.h"
 
