@@ -784,8 +784,7 @@ def main():
 
     def step_serial(j=0):   # the same work on the current stream (instrumented / PMC passes)
         im, tk, lc = batches[j % n_batches]
-        rf = eng.encode_image(im)
-        tg, ts = eng.encode_text(tk)
+        rf, tg, ts = eng.encode_pair(im, tk)        # what the pipeline's lanes call (pipeline.py: _step)
         q = eng.dvr_fuse(rf, lc, tg, ts)
         out = eng.sim_topk_bf16(q, gallery, K, exclude_idx=ex_idx) if w["bf16_gallery"] else eng.sim_topk(q, gallery, K, exclude_idx=ex_idx)
         if members is not None:

@@ -41,6 +41,7 @@ SIGNATURES = {
     "fern_finalize_clip": (c_int, [c_void_p, C.POINTER(ClipConfigC)]),
     "fern_vit_encode_image": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fern_text_encode": (c_int, [c_void_p, c_void_p, c_void_p, C.POINTER(c_i64), c_void_p, c_void_p, c_int, c_void_p]),
+    "fern_encode_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fern_dvr_fuse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fern_index_fuse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "fern_combiner": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),

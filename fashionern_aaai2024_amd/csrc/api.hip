@@ -107,7 +107,8 @@ struct ProfRec { hipEvent_t a, b; int kind; double work; int m, n, k, tag; int d
                  /* span records (the ranking stage, round 5): kev holds EVERY dispatch of the stage in launch order; the stage's time is first
                     dispatch begin -> last dispatch end (launch boundaries between them included), the dispatches [sweep_lo, sweep_hi) are its
                     full-gallery sweep(s), `work` their bytes */
-                 bool span = false; int sweep_lo = 0, sweep_hi = 0; };
+                 bool span = false; int sweep_lo = 0, sweep_hi = 0;
+                 double extra_alg_bytes = 0.0; /* a GEMM PAIR record (run_gemm_pair): the second problem's algorithmic bytes (m, n, k are the first's) */ };
 
 namespace fern {
 thread_local LaunchTimer* g_launch_timer = nullptr;
@@ -302,6 +303,22 @@ static int run_gemm(fern_ctx* c, const GemmParams& p, hipStream_t s, int kind = 
     }
     HIP_TRY_PROF(le, c, slot);                                   // (a failed launch must not leave the timer armed, nor a 0 ms record behind)
     if (slot >= 0) c->recs[slot].dispatches = gemm_last_dispatches();
+    return prof_close(c, slot, s);
+}
+// Two plain GEMMs of the fp32 data flow in ONE launch where the family can (gemm.hip: launch_gemm_pair; two launches otherwise): the
+// image tower's GEMM of a layer and the text tower's GEMM of the same kind.  One profile record for both (shape = the first's, the
+// flops of both): the launch is what the roofline prices.
+static int run_gemm_pair(fern_ctx* c, const GemmParams& p1, const GemmParams& p2, hipStream_t s) {
+    int slot;
+    FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * p1.M * (double)p1.N * p1.K + 2.0 * p2.M * (double)p2.N * p2.K, s, &slot, p1.M, p1.N, p1.K, 50 + p1.epi));
+    GemmParams a = p1, b = p2;
+    if (c->f32x3) { a.split = 3; b.split = 3; }
+    const hipError_t le = launch_gemm_pair(a, b, s);
+    HIP_TRY_PROF(le, c, slot);
+    if (slot >= 0) {
+        c->recs[slot].dispatches = gemm_last_dispatches();
+        c->recs[slot].extra_alg_bytes = 4.0 * ((double)p2.M * p2.K + (double)p2.N * p2.K + (double)p2.M * p2.N);
+    }
     return prof_close(c, slot, s);
 }
 static GemmParams gemm_desc(const float* A, long lda, const LinearW& L, float* C, long ldc, int M, int epi) {
@@ -1617,6 +1634,87 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
     return FERN_OK;
 }
 
+// Both towers of a composed query in one pass (round 6), fp32 data flow only (FERN_PREC_FP32, also under f32x3): the
+// image tower's full blocks and the text tower's blocks are walked LAYER BY LAYER and the four GEMMs of a layer -- QKV, out-proj, c_fc,
+// c_proj -- are issued as image + text PAIRS (run_gemm_pair): the text layer's few hundred tiles ride in the image layer's launch and
+// back-fill its tail instead of running as under-filled launches of their own.  Everything else (LayerNorms, attention, the class-row
+// block, the projections) is issued exactly as vit_chunk / text_chunk issue it, and every GEMM computes the same tiles in the same k
+// order: the features are bit-identical to fern_vit_encode_image + fern_text_encode.
+static int pair_chunk(fern_ctx* c, const float* images, float* out_img, const int64_t* tokens, float* out_global, float* out_seq, int b, hipStream_t s) {
+    const ClipW& W = c->clip;
+    const fern_clip_config& cf = W.cfg;
+    const int vw = cf.v_width, g = cf.image_size / cf.patch_size, g2 = g * g, S = g2 + 1;
+    const int tw = cf.t_width, T = cf.context_length, E = cf.embed_dim;
+    const long R = (long)b * S, Rt = (long)b * T;
+    float *X, *XN, *QKV, *ATT, *H, *CLS, *Xt, *XNt, *QKVt, *ATTt, *Ht;
+    int* eot;
+    FERN_TRY(ws_get(c, (size_t)R * vw, &X));
+    FERN_TRY(ws_get(c, (size_t)R * vw, &XN));
+    FERN_TRY(ws_get(c, (size_t)R * 3 * vw, &QKV));
+    FERN_TRY(ws_get(c, (size_t)R * vw, &ATT));
+    FERN_TRY(ws_get(c, (size_t)R * cf.v_mlp, &H));
+    FERN_TRY(ws_get(c, (size_t)b * vw, &CLS));
+    FERN_TRY(ws_get(c, (size_t)Rt * tw, &Xt));
+    FERN_TRY(ws_get(c, (size_t)Rt * tw, &XNt));
+    FERN_TRY(ws_get(c, (size_t)Rt * 3 * tw, &QKVt));
+    FERN_TRY(ws_get(c, (size_t)Rt * tw, &ATTt));
+    FERN_TRY(ws_get(c, (size_t)Rt * cf.t_mlp, &Ht));
+    FERN_TRY(ws_get(c, (size_t)b, &eot));
+    // image tower front: conv1 as an im2col-free GEMM (epilogue adds the positional embedding), class token, ln_pre -- as vit_chunk
+    GemmParams pe{};
+    pe.A = images; pe.W = W.conv_w; pe.ldw = 3L * cf.patch_size * cf.patch_size; pe.C = X; pe.ldc = vw;
+    pe.M = b * g2; pe.N = vw; pe.K = 3 * cf.patch_size * cf.patch_size;
+    pe.epi = EPI_PATCH_EMBED; pe.aload = ALOAD_IM2COL; pe.aux0 = W.vpos;
+    pe.img = cf.image_size; pe.patch = cf.patch_size; pe.grid = g;
+    FERN_TRY(run_gemm(c, pe, s));
+    HIP_TRY(launch_vit_cls(W.cls, W.vpos, X, b, S, vw, s));
+    HIP_TRY(launch_layernorm(X, nullptr, W.ln_pre.g, W.ln_pre.b, X, R, vw, vw, vw, 1e-5f, s));
+    // text tower front -- as text_chunk
+    HIP_TRY(launch_text_embed(tokens, W.tok_emb, W.tpos, Xt, eot, b, T, tw, cf.vocab_size, c->tok_flag, s));
+    const int vfull = cf.v_layers - 1;                     // the image tower's last block runs for the class rows only
+    const int paired = vfull < cf.t_layers ? vfull : cf.t_layers;
+    const int vhd = vw / cf.v_heads, thd = tw / cf.t_heads;
+    for (int l = 0; l < paired; ++l) {
+        const ClipBlockW &Bv = W.vblocks[l], &Bt = W.tblocks[l];
+        HIP_TRY(launch_layernorm(X, nullptr, Bv.ln1.g, Bv.ln1.b, XN, R, vw, vw, vw, 1e-5f, s));
+        HIP_TRY(launch_layernorm(Xt, nullptr, Bt.ln1.g, Bt.ln1.b, XNt, Rt, tw, tw, tw, 1e-5f, s));
+        FERN_TRY(run_gemm_pair(c, gemm_desc(XN, vw, Bv.qkv, QKV, 3 * vw, (int)R, EPI_BIAS), gemm_desc(XNt, tw, Bt.qkv, QKVt, 3 * tw, (int)Rt, EPI_BIAS), s));
+        AttnParams av{QKV, QKV + vw, QKV + 2 * vw, ATT, 3L * vw, 3L * vw, 3L * vw, (long)vw, b, cf.v_heads, vhd, S, S, 0, 1.0f / std::sqrt((float)vhd)};
+        FERN_TRY(run_attention(c, av, s));
+        AttnParams at{QKVt, QKVt + tw, QKVt + 2 * tw, ATTt, 3L * tw, 3L * tw, 3L * tw, (long)tw, b, cf.t_heads, thd, T, T, 1, 1.0f / std::sqrt((float)thd)};
+        FERN_TRY(run_attention(c, at, s));
+        GemmParams pov = gemm_desc(ATT, vw, Bv.out, X, vw, (int)R, EPI_BIAS_RESIDUAL), pot = gemm_desc(ATTt, tw, Bt.out, Xt, tw, (int)Rt, EPI_BIAS_RESIDUAL);
+        pov.R = X; pot.R = Xt;
+        FERN_TRY(run_gemm_pair(c, pov, pot, s));
+        HIP_TRY(launch_layernorm(X, nullptr, Bv.ln2.g, Bv.ln2.b, XN, R, vw, vw, vw, 1e-5f, s));
+        HIP_TRY(launch_layernorm(Xt, nullptr, Bt.ln2.g, Bt.ln2.b, XNt, Rt, tw, tw, tw, 1e-5f, s));
+        FERN_TRY(run_gemm_pair(c, gemm_desc(XN, vw, Bv.fc, H, Bv.fc.out, (int)R, EPI_BIAS_GELU), gemm_desc(XNt, tw, Bt.fc, Ht, Bt.fc.out, (int)Rt, EPI_BIAS_GELU), s));
+        GemmParams ppv = gemm_desc(H, Bv.fc.out, Bv.proj, X, vw, (int)R, EPI_BIAS_RESIDUAL), ppt = gemm_desc(Ht, Bt.fc.out, Bt.proj, Xt, tw, (int)Rt, EPI_BIAS_RESIDUAL);
+        ppv.R = X; ppt.R = Xt;
+        FERN_TRY(run_gemm_pair(c, ppv, ppt, s));
+    }
+    for (int l = paired; l < vfull; ++l) FERN_TRY(clip_block(c, W.vblocks[l], X, XN, QKV, ATT, H, b, S, vw, cf.v_heads, 0, s));
+    for (int l = paired; l < cf.t_layers; ++l) FERN_TRY(clip_block(c, W.tblocks[l], Xt, XNt, QKVt, ATTt, Ht, b, T, tw, cf.t_heads, 1, s));
+    // image tower tail -- as vit_chunk
+    FERN_TRY(clip_block_cls_only(c, W.vblocks[cf.v_layers - 1], X, XN, QKV, CLS, ATT, ATT + (size_t)b * vw, H, b, S, vw, cf.v_heads, s, nullptr));
+    HIP_TRY(launch_layernorm(CLS, nullptr, W.ln_post.g, W.ln_post.b, CLS, b, vw, vw, vw, 1e-5f, s));
+    LinearW vproj{W.vproj_t, nullptr, E, vw};
+    FERN_TRY(run_gemm(c, gemm_desc(CLS, vw, vproj, out_img, E, b, EPI_BIAS), s));
+    // text tower tail -- as text_chunk
+    HIP_TRY(launch_layernorm(Xt, nullptr, W.ln_final.g, W.ln_final.b, XNt, Rt, tw, tw, tw, 1e-5f, s));
+    LinearW tproj{W.tproj_t, nullptr, E, tw};
+    if (out_seq) {
+        FERN_TRY(run_gemm(c, gemm_desc(XNt, tw, tproj, out_seq, E, (int)Rt, EPI_BIAS), s));
+        if (out_global) HIP_TRY(launch_gather_rows(out_seq, E, out_global, E, b, E, 1, T, 0, eot, s));
+    } else if (out_global) {
+        float* pooled;
+        FERN_TRY(ws_get(c, (size_t)b * tw, &pooled));
+        HIP_TRY(launch_gather_rows(XNt, tw, pooled, tw, b, tw, 1, T, 0, eot, s));
+        FERN_TRY(run_gemm(c, gemm_desc(pooled, tw, tproj, out_global, E, b, EPI_BIAS), s));
+    }
+    return FERN_OK;
+}
+
 // A token id outside the vocabulary cannot raise from inside a kernel (nn.Embedding does, in the reference): the embedding
 // kernel poisons the row with NaN and sets a host-mapped flag; it is turned into FERN_ERR_ARG here, at fern_sync and at the
 // next fern_text_encode -- without a synchronisation on the launch path.
@@ -1652,6 +1750,37 @@ extern "C" int fern_text_encode(fern_ctx* c, const int64_t* tokens, const float*
         const int m = std::min(CH, B - o);
         FERN_TRY(ws_begin(c, s));
         FERN_TRY(text_chunk(c, tokens + (long)o * cf.context_length, out_global ? out_global + (long)o * cf.embed_dim : nullptr,
+                            out_seq ? out_seq + (long)o * cf.context_length * cf.embed_dim : nullptr, m, s));
+    }
+    return FERN_OK;
+}
+
+extern "C" int fern_encode_pair(fern_ctx* c, const float* images, const int64_t* tokens, float* out_image, float* out_global, float* out_seq, int B,
+                                void* stream) {
+    if (!c) return fail(FERN_ERR_ARG, "fern_encode_pair: ctx is NULL");
+    if (!c->clip.ready) return fail(FERN_ERR_STATE, "fern_encode_pair: CLIP weights not finalised (fern_finalize_clip)");
+    FERN_TRY(check_fresh(c, "fern_encode_pair"));
+    if (B < 0 || (B && (!images || !tokens || !out_image || (!out_global && !out_seq)))) return fail(FERN_ERR_ARG, "fern_encode_pair: bad argument");
+    const fern_clip_config& cf = c->clip.cfg;
+    const bool pairable = c->precision == FERN_PREC_FP32 && cf.v_arch == 0 && cf.v_layers > 1 && cf.t_layers > 0;
+    if (!pairable) {      // every other mode / tower: the two entry points, one after the other (same results by definition)
+        FERN_TRY(fern_vit_encode_image(c, images, out_image, B, stream));
+        return fern_text_encode(c, tokens, nullptr, nullptr, out_global, out_seq, B, stream);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->tok_flag) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->tok_flag), sizeof(int), hipHostMallocMapped));
+        *c->tok_flag = 0;
+    }
+    FERN_TRY(check_token_flag(c, "fern_encode_pair"));
+    hipStream_t s = (hipStream_t)stream;
+    const long img_sz = 3L * cf.image_size * cf.image_size;
+    const int CH = 64;                                      // vit_chunk's chunk: the pairing keeps the image tower's launch shapes
+    for (int o = 0; o < B; o += CH) {
+        const int m = std::min(CH, B - o);
+        FERN_TRY(ws_begin(c, s));
+        FERN_TRY(pair_chunk(c, images + o * img_sz, out_image + (long)o * cf.embed_dim, tokens + (long)o * cf.context_length,
+                            out_global ? out_global + (long)o * cf.embed_dim : nullptr,
                             out_seq ? out_seq + (long)o * cf.context_length * cf.embed_dim : nullptr, m, s));
     }
     return FERN_OK;
@@ -2213,7 +2342,7 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
                 else if (r.tag >= 200) { out->gemm_fp8_ms += ms; out->gemm_fp8_flops += r.work; out->gemm_fp8_launches++; }
                 else if (r.tag >= 100) { out->gemm_bf16_ms += ms; out->gemm_bf16_flops += r.work; out->gemm_bf16_launches++; }
                 else { out->gemm_ms += ms; out->gemm_flops += r.work; out->gemm_launches++;
-                       out->gemm_alg_bytes += 4.0 * ((double)r.m * r.k + (double)r.n * r.k + (double)r.m * r.n);
+                       out->gemm_alg_bytes += 4.0 * ((double)r.m * r.k + (double)r.n * r.k + (double)r.m * r.n) + r.extra_alg_bytes;
                        out->gemm_dispatches += r.dispatches; }
                 break;
             case PROF_ATTN: out->attn_ms += ms; out->attn_flops += r.work; out->attn_launches++; break;

@@ -637,6 +637,55 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 2 : 4) void gemm_f32_mix
     }
 }
 
+// ---- two GEMMs in one launch (round 6) ------------------------------------------------------------------------
+// The text tower's GEMMs (M = 77 B = 4 928 rows, K = 512) are a few hundred small tiles each: on their own they run at 84-119 TFLOP/s
+// (2.4 rounds of 64x64 tiles on 256 CUs) while the image tower's GEMM of the same layer runs at 117-128.  The two towers are
+// independent until the fusion, so the text layer's GEMM rides in the SAME launch as the image layer's GEMM of the same kind: the first
+// problem keeps the mixed plan the tuner chose for it (macro-tiles, 128x128, 64x128 bands), the second problem follows as two more bands
+// (128x128 tiles, then 64x128 for the ragged rows) -- the dispatcher hands out its workgroups as the first problem's tail drains, so
+// its tiles back-fill CUs that would otherwise idle behind a kernel boundary.  Same tiles, same k order: bit-identical to two launches.
+template <bool WIDE, int SPLIT = 0>
+__global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 2 : 4) void gemm_f32_pair_kernel(GemmParams p, int ra, int rb, int n_a8, int n_b8, int n_c8, GemmParams p2,
+                                                                                        int rb2, int n_d8) {
+    __shared__ __attribute__((aligned(1024))) float smem[2 * 384 * 16];
+    const int bid = blockIdx.x;
+    auto band = [&](const GemmParams& g, int row0, int rows) {
+        GemmParams q = g;
+        q.A = g.A + (long)row0 * g.lda;
+        q.C = g.C + (long)row0 * g.ldc;
+        if (g.R) q.R = g.R + (long)row0 * g.ldc;
+        q.M = rows;
+        return q;
+    };
+    constexpr int BMA = WIDE ? 128 : 256, BNA = WIDE ? 256 : 128;
+    constexpr int WMA = SPLIT ? BMA / 2 : 64, WNA = SPLIT ? BNA / 2 : 64;
+    constexpr int WNS = SPLIT ? 64 : 32;                  // wave tile width of the 128x128 and 64x128 bands (8 waves, or 4 for the split family)
+    // block order: the SECOND problem's bands first (its 128x128 tiles, then its ragged 64x128 rows), then the first problem's bands in the
+    // order its plan was tuned for -- so that the launch still ends in the first problem's own small-tile band (appended BEHIND it, the second
+    // problem's few hundred long-k tiles were the new tail: 12608 x 768 x 3072 + 4928 x 512 x 2048 ran at 112.6 TFLOP/s against 119.9 as two
+    // launches)
+    const int n_e8 = (((p2.M - rb2 + 63) / 64) * ((p2.N + 127) / 128) + 7) & ~7;
+    const int n2 = n_d8 + n_e8;
+    if (bid < n_d8) {
+        const int tiles = (rb2 / 128) * ((p2.N + 127) / 128);
+        if (bid < tiles) glds_tile<128, 128, 64, WNS, 16, false, 0, false, SPLIT>(band(p2, 0, rb2), bid, smem);
+    } else if (bid < n2) {
+        const int tiles = ((p2.M - rb2 + 63) / 64) * ((p2.N + 127) / 128);
+        if (bid - n_d8 < tiles) glds_tile<64, 128, 32, WNS, 16, false, 0, false, SPLIT>(band(p2, rb2, p2.M - rb2), bid - n_d8, smem);
+    } else if (bid - n2 < n_a8) {
+        const int b1 = bid - n2;
+        const int tiles = (ra / BMA) * ((p.N + BNA - 1) / BNA);
+        if (b1 < tiles) glds_tile<BMA, BNA, WMA, WNA, 16, false, 0, false, SPLIT>(band(p, 0, ra), b1, smem);
+    } else if (bid - n2 < n_a8 + n_b8) {
+        const int b1 = bid - n2 - n_a8;
+        const int tiles = ((rb - ra + 127) / 128) * ((p.N + 127) / 128);
+        if (b1 < tiles) glds_tile<128, 128, 64, WNS, 16, false, 0, false, SPLIT>(band(p, ra, rb - ra), b1, smem);
+    } else {
+        glds_tile<64, 128, 32, WNS, 16, false, 0, false, SPLIT>(band(p, rb, p.M - rb), bid - n2 - n_a8 - n_b8, smem);
+    }
+    (void)n_c8;
+}
+
 // ---- small-M variant on v_mfma_f32_16x16x4_f32 ----------------------------------------------------------------------
 // The fusion stage is a chain of M = 64 GEMMs (combiner MLPs, class-row chain of the last ViT block): a 32x32 MFMA tile has
 // to walk its whole k chain on one SIMD (K = 4096: 2048 dependent-pipe MFMAs of 64 cycles = 57 us) and there are only
@@ -1335,6 +1384,123 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.aload == ALOAD_CONV3 && (c < 8 || c == 12 || c == 13)) c = 8 + (c & 3);     // 3x3 window: LDS-DMA family without the macro-tiles
     if (c >= 8 && p.aload == ALOAD_IM2COL) c &= 3;                        // patch loader: register-staged family only
     return launch_cfg(c, p, s);
+}
+
+// fern's GEMM pairs (api.hip: run_gemm_pair): p1 = the image tower's GEMM, p2 = the text tower's GEMM of the same layer.  One launch when
+// p1's tuned plan is a mixed plan and both calls are plain (row-independent epilogue, plain loader, same arithmetic family); two launches
+// otherwise -- also the first time a shape is seen (launch_gemm tunes it; the next call finds the plan) and for the pairs that the one-launch
+// form does not speed up (pair_wins, timed once per pair of shapes).  FERN_GEMM_PAIR=0 turns it off.
+static bool pair_enabled() {
+    static const bool on = [] { const char* e = getenv("FERN_GEMM_PAIR"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static hipError_t launch_pair_kernel(const Plan& pl, const GemmParams& p1, const GemmParams& p2, hipStream_t s);
+// per (first shape, second shape): does the ONE-launch form beat two launches?  Timed once on scratch outputs, like the tile tuners: the
+// second problem rides as 128x128 / 64x128 tiles, which is not every shape's best geometry (4928 x 512 x 2048 behind 12608 x 768 x 3072:
+// 117 TFLOP/s paired against 120 as two launches; the other three pairs of a ViT-B/16 + text layer gain 1-2 %)
+static std::map<std::pair<ShapeKey, ShapeKey>, bool> g_pair_choice;      // guarded by g_tuned_mu
+static bool pair_wins(const Plan& pl, const GemmParams& p1, const GemmParams& p2, hipStream_t s, bool& timed) {
+    LaunchTimerPause pause;
+    timed = false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+    float *c1 = nullptr, *c2 = nullptr;
+    if (hipMalloc(&c1, (size_t)p1.M * p1.ldc * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMalloc(&c2, (size_t)p2.M * p2.ldc * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(c1); return false; }
+    GemmParams q1 = p1, q2 = p2;
+    q1.C = c1; q2.C = c2;                                  // the residual inputs are only read: no side effects on the caller's buffers
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    auto timed_ms = [&](auto&& fn) {
+        float best = 1e30f;
+        for (int round = 0; round < 2; ++round) {
+            if (fn() != hipSuccess) return 1e30f;          // warm (and, for the two-launch form, the second shape's own tuning)
+            (void)hipEventRecord(e0, s);
+            (void)fn();
+            (void)fn();
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            best = std::min(best, ms);
+        }
+        return best;
+    };
+    const float t_two = timed_ms([&] { const hipError_t e = launch_gemm(q1, s); return e != hipSuccess ? e : launch_gemm(q2, s); });
+    const float t_one = timed_ms([&] { return launch_pair_kernel(pl, q1, q2, s); });
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(c1);
+    (void)hipFree(c2);
+    timed = t_two < 1e29f && t_one < 1e29f;
+    return timed && t_one < t_two;
+}
+hipError_t launch_gemm_pair(const GemmParams& p1, const GemmParams& p2, hipStream_t s) {
+    bool paired = false;
+    Plan pl{-1, 0, 0};
+    const bool same_family = (p1.split == 3) == (p2.split == 3);
+    if (pair_enabled() && same_family && split_ok(p1) && split_ok(p2) && !p1.gate && !p2.gate && p1.K % 16 == 0 && p2.K % 16 == 0 && p1.M >= 256 && p2.M >= 64 &&
+        p2.N >= 128 && !(p1.lda & 3) && !(p2.lda & 3) && !(p1.ldw & 3) && !(p2.ldw & 3) && !((uintptr_t)p1.A & 15) && !((uintptr_t)p2.A & 15) &&
+        !((uintptr_t)p1.W & 15) && !((uintptr_t)p2.W & 15) && forced_cfg() < 0 && forced_cfg_split() < 0 && tuning_enabled()) {
+        const bool sp = p1.split == 3;
+        if (!sp || (split_family_ok(p1) && split_family_ok(p2))) {
+            load_pinned_tiles();
+            const ShapeKey k1{p1.M, p1.N, p1.K, p1.epi, sp ? 3000 : p1.aload}, k2{p2.M, p2.N, p2.K, p2.epi, sp ? 3000 : p2.aload};
+            bool known = false;
+            {
+                std::lock_guard<std::mutex> lock(g_tuned_mu);
+                if (sp) {
+                    auto it = g_tuned_s.find(ShapeKey{p1.M, p1.N, p1.K, p1.epi, 0});
+                    if (it != g_tuned_s.end()) pl = it->second;
+                } else {
+                    auto it = g_tuned.find(ShapeKey{p1.M, p1.N, p1.K, p1.epi, p1.aload});
+                    if (it != g_tuned.end()) pl = it->second;
+                }
+                if (pl.cfg >= kCfgMixed && mixed_plan_ok(pl, p1.M)) {
+                    auto it = g_pair_choice.find({k1, k2});
+                    if (it != g_pair_choice.end()) { known = true; paired = it->second; }
+                } else {
+                    known = true;                           // no mixed plan (yet): two launches -- launch_gemm tunes the shape on first sight
+                }
+            }
+            if (!known) {                                   // (the trial launches call launch_gemm, which takes the mutex itself)
+                bool timed = false;
+                paired = pair_wins(pl, p1, p2, s, timed);
+                if (timed) {
+                    std::lock_guard<std::mutex> lock(g_tuned_mu);
+                    g_pair_choice[{k1, k2}] = paired;
+                }
+            }
+        }
+    }
+    if (!paired) {
+        const hipError_t e = launch_gemm(p1, s);
+        if (e != hipSuccess) return e;
+        const int d1 = g_last_dispatches;
+        const hipError_t e2 = launch_gemm(p2, s);
+        g_last_dispatches += d1;
+        return e2;
+    }
+    g_last_dispatches = 1;
+    return launch_pair_kernel(pl, p1, p2, s);
+}
+static hipError_t launch_pair_kernel(const Plan& pl, const GemmParams& p1, const GemmParams& p2, hipStream_t s) {
+    const bool wide = pl.cfg == kCfgMixed + 1;
+    const int bma = wide ? 128 : 256, bna = wide ? 256 : 128;
+    const int ra = pl.rows_a, rb = pl.cfg_b, nbn = (p1.N + 127) / 128, nbn2 = (p2.N + 127) / 128;
+    const int n_a = (ra / bma) * ((p1.N + bna - 1) / bna), n_b = ((rb - ra + 127) / 128) * nbn, n_c = ((p1.M - rb + 63) / 64) * nbn;
+    const int rb2 = (p2.M / 128) * 128;
+    const int n_d = (rb2 / 128) * nbn2, n_e = ((p2.M - rb2 + 63) / 64) * nbn2;
+    const int n_a8 = (n_a + 7) & ~7, n_b8 = (n_b + 7) & ~7, n_c8 = (n_c + 7) & ~7, n_d8 = (n_d + 7) & ~7;      // every band starts on a multiple of 8 blocks
+    const int n_e8 = (n_e + 7) & ~7;
+    const int grid = n_d8 + n_e8 + (n_c > 0 ? n_a8 + n_b8 + n_c : n_b > 0 ? n_a8 + n_b : n_a);
+    if (p1.split == 3) {
+        if (wide) FERN_LAUNCH((gemm_f32_pair_kernel<true, 3>), dim3(grid), dim3(256), 0, s, p1, ra, rb, n_a8, n_b8, n_c8, p2, rb2, n_d8);
+        else FERN_LAUNCH((gemm_f32_pair_kernel<false, 3>), dim3(grid), dim3(256), 0, s, p1, ra, rb, n_a8, n_b8, n_c8, p2, rb2, n_d8);
+    } else if (wide) FERN_LAUNCH(gemm_f32_pair_kernel<true>, dim3(grid), dim3(512), 0, s, p1, ra, rb, n_a8, n_b8, n_c8, p2, rb2, n_d8);
+    else FERN_LAUNCH(gemm_f32_pair_kernel<false>, dim3(grid), dim3(512), 0, s, p1, ra, rb, n_a8, n_b8, n_c8, p2, rb2, n_d8);
+    return hipGetLastError();
 }
 
 }  // namespace fern

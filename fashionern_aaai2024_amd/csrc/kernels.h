@@ -179,6 +179,7 @@ inline long mx_scale_offset(long r, long b, long srows) { return ((b >> 2) * sro
 // Number of column blocks the reduce epilogues write per row (depends on the tile chosen for this shape).
 int gemm_num_col_blocks(int M, int N, int K);
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+hipError_t launch_gemm_pair(const GemmParams& p1, const GemmParams& p2, hipStream_t s);      // two plain GEMMs, ONE launch when p1's tuned plan is a mixed plan (gemm.hip)
 int gemm_last_dispatches();      // kernel dispatches of the calling thread's last launch_gemm (2 for a bulk + remainder plan)
 // bf16 x bf16 -> fp32-accumulate GEMM (v_mfma_f32_32x32x16_bf16); plain epilogues only, K % 32 == 0, ALOAD_PLAIN
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s);

@@ -207,6 +207,28 @@ class FernEngine:
         _lib.check(self.lib.fern_text_encode(self._h, _ptr(t), _ptr(ve), ve_shape, _ptr(g), _ptr(s), b, _stream()), "fern_text_encode")
         return g, s
 
+    def encode_pair(self, images: torch.Tensor, tokens: torch.Tensor, want_seq: bool = True):
+        """`encode_image(images)` and `encode_text(tokens)` of the SAME query batch in one pass (include/fern.h: fern_encode_pair): the towers
+        are walked layer by layer and the text layer's GEMMs ride in the image layer's launches.  Returns (image [B,D], text global [B,D],
+        text seq [B,ctx,D] | None) -- bit-identical to the two calls; in a mode or with a tower the library does not pair, it makes them."""
+        cfg = self.clip_cfg
+        if cfg is None:
+            raise _lib.FernError("encode_pair: CLIP weights not finalised")
+        if images.dim() != 4 or tuple(images.shape[1:]) != (3, cfg.image_size, cfg.image_size):
+            raise ValueError(f"images must be [b,3,{cfg.image_size},{cfg.image_size}], got {tuple(images.shape)}")
+        if tokens.dim() != 2 or tokens.shape[1] != cfg.context_length or tokens.shape[0] != images.shape[0]:
+            raise ValueError(f"text must be int64 [{images.shape[0]},{cfg.context_length}], got {tuple(tokens.shape)}")
+        if not tokens.is_cuda and tokens.numel() and (int(tokens.min()) < 0 or int(tokens.max()) >= cfg.vocab_size):
+            raise IndexError(f"token id out of range [0, {cfg.vocab_size}): min {int(tokens.min())}, max {int(tokens.max())}")
+        x = self._f32(images)
+        t = tokens.to(device=self.device, dtype=torch.int64).contiguous()
+        b = x.shape[0]
+        out = self._empty(b, cfg.embed_dim)
+        g = self._empty(b, cfg.embed_dim)
+        s = self._empty(b, cfg.context_length, cfg.embed_dim) if want_seq else None
+        _lib.check(self.lib.fern_encode_pair(self._h, _ptr(x), _ptr(t), _ptr(out), _ptr(g), _ptr(s), b, _stream()), "fern_encode_pair")
+        return out, g, s
+
     # ---- fusion -------------------------------------------------------------------------------
     def _d(self) -> int:
         if self.feature_dim is None:

@@ -160,8 +160,11 @@ class ComposedQueryPipeline:
     @staticmethod
     def _step(eng, args, gallery, k, idx_offset):
         images, tokens, local, exclude_idx, members, ref_feats = args
-        ref = eng.encode_image(images) if ref_feats is None else ref_feats
-        tg, ts = eng.encode_text(tokens)
+        if ref_feats is None and images.shape[0] == tokens.shape[0]:
+            ref, tg, ts = eng.encode_pair(images, tokens)      # both towers in one pass: the text layers' GEMMs ride in the image layers' launches (fp32 / f32x3)
+        else:
+            ref = eng.encode_image(images) if ref_feats is None else ref_feats
+            tg, ts = eng.encode_text(tokens)
         fused = eng.dvr_fuse(ref, local, tg, ts)
         if gallery.dtype == torch.bfloat16:
             scores, idx = eng.sim_topk_bf16(fused, gallery, k, idx_offset=idx_offset, exclude_idx=exclude_idx)

@@ -205,6 +205,15 @@ FERN_API int fern_vit_encode_image(fern_ctx* ctx, const float* images, float* ou
  * next fern_text_encode on the context (nn.Embedding raises in the reference; the launch path here never synchronises). */
 FERN_API int fern_text_encode(fern_ctx* ctx, const int64_t* tokens, const float* visual_emb, const int64_t* visual_emb_shape,
                               float* out_global, float* out_seq, int B, void* stream);
+/* Both towers of B composed queries in one pass (round 6): `clip_model.encode_image(images)` + `clip_model.encode_text(text)` of the same
+ * batch -- the two calls every query batch of the reference's harness and of ERN makes (utils/utils.py:64, run/test/test_fiq.py:102-103,
+ * models/clip_model.py:10-31) -- with the towers walked layer by layer so that the text layer's GEMMs ride in the image layer's launches
+ * (models/others/modeling_clip.py:694-768 and :832-887 are independent until the fusion).  images [B,3,S,S], tokens [B,ctx] ->
+ * out_image [B,D], out_global [B,D] (may be NULL), out_seq [B,ctx,D] (may be NULL).  Results are BIT-IDENTICAL to fern_vit_encode_image +
+ * fern_text_encode; FERN_PREC_FP32 (also under F32X3) with the ViT tower pairs the launches, every other mode / tower simply makes the two
+ * calls.  Token-id errors as fern_text_encode. */
+FERN_API int fern_encode_pair(fern_ctx* ctx, const float* images, const int64_t* tokens, float* out_image, float* out_global, float* out_seq,
+                              int B, void* stream);
 
 /* fusion -------------------------------------------------------------------------------- */
 /* ERN.forward(mode="test") = DVR_module.forward -- models/model.py:68-69, fusion_model.py:26-55 */

@@ -411,3 +411,41 @@ def test_encoders_chunk_large_batches_without_changing_rows(precision):
         assert torch.equal(one, fused[i:i + 1]), i
     assert torch.isfinite(fused).all()
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f32x3", "bf16"])
+@pytest.mark.parametrize("cfg_name,b", [("ViT-B-16", 64), ("ViT-B-16", 5), ("tiny", 7)])
+def test_encode_pair_is_bit_identical_to_the_two_encoder_calls(cfg_name, b, precision):
+    """fern_encode_pair (round 6): both towers of a query batch walked layer by layer, the text layer's GEMMs riding in the image layer's
+    launches (gemm.hip: gemm_f32_pair_kernel, once the image GEMM's tuned plan is a mixed plan -- the second call of a shape).  Same tiles,
+    same k order: image features, text global and text seq equal fern_vit_encode_image + fern_text_encode BIT FOR BIT, on the first call
+    (two launches per pair while the shapes are tuned), on later calls (one launch), with pairing switched off by a forced tile, and in a
+    mode the library does not pair (bf16: the two calls)."""
+    from fashionern_aaai2024_amd.engine import FernEngine
+    cfg = synth.CLIP_CONFIGS[cfg_name]
+    eng = FernEngine("cuda:0")
+    eng.load_tensors(synth.clip_state_dict(cfg, seed=4))
+    eng.finalize_clip(cfg)
+    if precision == "bf16" and cfg_name == "tiny":
+        eng.close()
+        pytest.skip("the tiny tower's widths are outside the bf16 mode")
+    eng.set_precision(precision)
+    imgs = torch.from_numpy(synth.images(b, cfg, 11)).cuda()
+    toks = torch.from_numpy(synth.captions(b, cfg, 11)).cuda()
+    ref_i = eng.encode_image(imgs)
+    ref_g, ref_s = eng.encode_text(toks)
+    for rep in range(3):                                   # 1st: shapes seen for the first time by the pair launcher; 2nd, 3rd: tuned plans
+        pi, pg, ps = eng.encode_pair(imgs, toks)
+        assert torch.equal(pi, ref_i) and torch.equal(pg, ref_g) and torch.equal(ps, ref_s), (cfg_name, b, precision, rep)
+    pi, pg, ps = eng.encode_pair(imgs, toks, want_seq=False)      # global only: the pooled-row projection, as encode_text(want_seq=False) computes it
+    assert ps is None and torch.equal(pi, ref_i) and torch.equal(pg, eng.encode_text(toks, want_seq=False)[0])
+    if precision != "bf16":
+        eng.tuner_force_config("f32" if precision == "fp32" else "f32x3", 0)      # a forced tile: the pair launcher makes two launches
+        try:
+            pi, pg, ps = eng.encode_pair(imgs, toks)
+            assert torch.equal(pi, ref_i) and torch.equal(pg, ref_g) and torch.equal(ps, ref_s)
+        finally:
+            eng.tuner_force_config("f32" if precision == "fp32" else "f32x3", -1)
+    with pytest.raises(ValueError):
+        eng.encode_pair(imgs, toks[:-1])
+    eng.close()
