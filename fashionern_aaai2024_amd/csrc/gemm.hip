@@ -996,12 +996,20 @@ static bool mixed_plan_ok(const Plan& pl, int M) {
 static std::map<ShapeKey, Plan> g_tuned;
 static std::mutex g_tuned_mu;
 static std::map<ShapeKey, Plan>& tuned_split_map();     // the f32x3 family's choices (defined with that family below)
+static std::map<std::pair<ShapeKey, ShapeKey>, bool>& pair_choice_map();      // launch_gemm_pair's one-launch / two-launch choices (defined with it, at the end)
 constexpr int kNumCfgsS = 8;                             // ... and its number of single configurations
 
 // FERN_GEMM_TILES=<file>: pin the per-shape choices (lines "f32 M N K epi aload cfg [rows_a cfg_b]", as written by gemm_tuner_export /
 // fern_tuner_export): listed shapes are never timed again, so a run's kernels -- and its HBM / L2 traffic -- are reproducible
 // from box to box.  Loaded once, before the first tuned launch.
 static void pin_tile_line(const char* line) {      // caller holds g_tuned_mu
+    {      // "pair M1 N1 K1 epi1 a1 M2 N2 K2 epi2 a2 one": launch_gemm_pair's choice for a pair of shapes (a = aload, 3000 for the f32x3 family)
+        int v[11];
+        if (sscanf(line, "pair %d %d %d %d %d %d %d %d %d %d %d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8], &v[9], &v[10]) == 11) {
+            pair_choice_map()[{ShapeKey{v[0], v[1], v[2], v[3], v[4]}, ShapeKey{v[5], v[6], v[7], v[8], v[9]}}] = v[10] != 0;
+            return;
+        }
+    }
     {
         int M, N, K, epi, cfg, ra = 0, rb = 0;
         const int got = sscanf(line, "f32x3 %d %d %d %d %d %d %d", &M, &N, &K, &epi, &cfg, &ra, &rb);
@@ -1060,6 +1068,12 @@ void gemm_tuner_export(std::string& out) {
         char line[128];
         snprintf(line, sizeof line, "f32 %d %d %d %d %d %d %d %d\n", kv.first.M, kv.first.N, kv.first.K, kv.first.epi, kv.first.aload, kv.second.cfg,
                  kv.second.rows_a, kv.second.cfg_b);
+        out += line;
+    }
+    for (const auto& kv : pair_choice_map()) {
+        char line[192];
+        const ShapeKey &a = kv.first.first, &b = kv.first.second;
+        snprintf(line, sizeof line, "pair %d %d %d %d %d %d %d %d %d %d %d\n", a.M, a.N, a.K, a.epi, a.aload, b.M, b.N, b.K, b.epi, b.aload, kv.second ? 1 : 0);
         out += line;
     }
 }
@@ -1398,7 +1412,8 @@ static hipError_t launch_pair_kernel(const Plan& pl, const GemmParams& p1, const
 // per (first shape, second shape): does the ONE-launch form beat two launches?  Timed once on scratch outputs, like the tile tuners: the
 // second problem rides as 128x128 / 64x128 tiles, which is not every shape's best geometry (4928 x 512 x 2048 behind 12608 x 768 x 3072:
 // 117 TFLOP/s paired against 120 as two launches; the other three pairs of a ViT-B/16 + text layer gain 1-2 %)
-static std::map<std::pair<ShapeKey, ShapeKey>, bool> g_pair_choice;      // guarded by g_tuned_mu
+static std::map<std::pair<ShapeKey, ShapeKey>, bool> g_pair_choice;      // guarded by g_tuned_mu; exported / pinned / imported with the tile choices ("pair ..." lines)
+static std::map<std::pair<ShapeKey, ShapeKey>, bool>& pair_choice_map() { return g_pair_choice; }
 static bool pair_wins(const Plan& pl, const GemmParams& p1, const GemmParams& p2, hipStream_t s, bool& timed) {
     LaunchTimerPause pause;
     timed = false;

@@ -437,6 +437,16 @@ def test_encode_pair_is_bit_identical_to_the_two_encoder_calls(cfg_name, b, prec
     for rep in range(3):                                   # 1st: shapes seen for the first time by the pair launcher; 2nd, 3rd: tuned plans
         pi, pg, ps = eng.encode_pair(imgs, toks)
         assert torch.equal(pi, ref_i) and torch.equal(pg, ref_g) and torch.equal(ps, ref_s), (cfg_name, b, precision, rep)
+    if precision != "bf16" and cfg_name == "ViT-B-16" and b == 64:
+        # both forms of every pair, whatever the pair tuner chose on this box: flip each exported "pair ... 0|1" line, import, compare bits
+        pairs = [ln for ln in eng.tuner_export().splitlines() if ln.startswith("pair ")]
+        assert len(pairs) >= 3, pairs                      # QKV / out-proj / c_fc / c_proj of the ViT-B/16 + text layers (those whose image plan is a mixed plan)
+        flipped = "\n".join(ln[:-1] + ("0" if ln.endswith("1") else "1") for ln in pairs) + "\n"
+        eng.tuner_import(flipped)
+        assert all(ln in eng.tuner_export() for ln in flipped.splitlines())
+        pi, pg, ps = eng.encode_pair(imgs, toks)
+        assert torch.equal(pi, ref_i) and torch.equal(pg, ref_g) and torch.equal(ps, ref_s), "one-launch and two-launch forms of a pair differ"
+        eng.tuner_import("\n".join(pairs) + "\n")
     pi, pg, ps = eng.encode_pair(imgs, toks, want_seq=False)      # global only: the pooled-row projection, as encode_text(want_seq=False) computes it
     assert ps is None and torch.equal(pi, ref_i) and torch.equal(pg, eng.encode_text(toks, want_seq=False)[0])
     if precision != "bf16":
