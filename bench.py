@@ -36,6 +36,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# One hardware queue per lane (round 6): the ROCm runtime maps a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4)
+# and two streams that share one run back to back.  With 8 queues FOUR batches in flight beat three -- c2 3 030 -> 3 080 queries/s, c3
+# +1.7 %, c4 +0.7 %, c5 18.5 -> 19.0 k -- where with the default 4 queues a fourth lane LOSES (c5 16.8 k: it shares a queue; `profiles/
+# r06_lanes_hwq.txt`).  Must be in the environment before the first HIP call (torch is imported later, in main()); a value the user
+# exported wins.  Child processes (other configs, --gpus N ranks) inherit it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 _T0 = time.perf_counter()
 _STAMPS = {}
 
@@ -92,7 +98,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--gallery", type=int, default=None, help="override the workload's gallery rows")
-    ap.add_argument("--lanes", type=int, default=3, help="query batches kept in flight on separate HIP streams")
+    ap.add_argument("--lanes", type=int, default=4, help="query batches kept in flight on separate HIP streams (one hardware queue each: GPU_MAX_HW_QUEUES, "
+                                                         "set to 8 above unless exported)")
     ap.add_argument("--graphs", action="store_true", help="replay each lane's step from a hipGraph (captured after two eager calls)")
     ap.add_argument("--precision", choices=["fp32", "f32x3", "bf16", "fp8", "mx8", "mx8mlp", "mx8img"], default=None,
                     help="override the encoder operand precision of the TIMED path (fp32 = parity mode, the c2 headline)")
@@ -545,7 +552,7 @@ def compact_record(full: dict, cap: int = COMPACT_CAP_BYTES) -> dict:
                                            "vs_baseline", "dtype", "data")}
     cfg = full.get("config") or {}
     out["config"] = {k: cfg[k] for k in ("workload", "name", "clip", "query_batch_per_gpu", "gallery_rows", "gallery_dtype", "feature_dim", "top_k",
-                                         "batches_in_flight") if k in cfg}
+                                         "batches_in_flight", "hw_queues") if k in cfg}
     out["config"]["parallelism"] = str(cfg.get("parallelism", "")).split(";")[0]
     out["encoder_precision"] = full.get("encoder_precision")
     roof = full.get("roofline") or {}
@@ -1138,6 +1145,7 @@ def main():
             "config": {"workload": w["text"], "name": args.config, "clip": cfg.name, "query_batch_per_gpu": B, "gallery_rows": n_gal,
                        "gallery_dtype": "bf16" if w["bf16_gallery"] else "f32", "feature_dim": D, "top_k": K,
                        "image": f"3x{cfg.image_size}x{cfg.image_size}", "tokens": 77, "patch_feats": 13, "batches_in_flight": args.lanes,
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "input_batches_rotated": n_batches,
                        "parallelism": f"dp{world} queries; gallery built sharded ({per} rows per rank, seed + rank), fused blocks all-gathered once"},
             "ms_per_step_event_median": gap_median,

@@ -9,6 +9,11 @@ from . import build as _build
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
+# One hardware queue per pipeline lane: the ROCm runtime maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that
+# share one run back to back -- with 8, four lanes of a ComposedQueryPipeline overlap where with 4 the fourth LOSES throughput (bench.py;
+# profiles/r06_lanes_hwq.txt).  Effective only when set before the process's first HIP call; a value the user exported wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 class ClipConfigC(C.Structure):
     _fields_ = [(n, c_int) for n in (
