@@ -479,7 +479,7 @@ def harness_leg(torch, eng, clip, model, cfg, D, device, n_gal, lookup_qps, enc_
     host_local = torch.from_numpy(synth.local_feats(256, D, 31, "bench-ql"))
     rel = _BenchRelativeDataset(queries, n_gal, host_local)
     out = {"queries": queries, "gallery_rows": n_gal, "batch_size": 64, "tokenizer": "ClipBpeTokenizer (CLIP BPE algorithm, synthetic merge table), host",
-           "lanes": int(os.environ.get("FERN_HARNESS_LANES", "3"))}
+           "lanes": int(os.environ.get("FERN_HARNESS_LANES", "4"))}
 
     def timed(fn, reps=2):
         fn()                                          # first call: forks, workspaces, tile tuning

@@ -183,11 +183,12 @@ def generate_predictions(kind: str, clip_model, relative_val_dataset, model, ind
 
 
 def _query_pipeline(clip_model, model, device):
-    """A 3-lane ComposedQueryPipeline when the encoder and the fusion model are the HIP ones on ONE engine on a GPU, else None."""
+    """A 4-lane ComposedQueryPipeline (FERN_HARNESS_LANES; round 6: 4 -- one hardware queue per lane with GPU_MAX_HW_QUEUES=8, _lib.py) when the
+    encoder and the fusion model are the HIP ones on ONE engine on a GPU, else None."""
     import os
     from ..clip_model import FernCLIP
     from ..engine import FernEngine
-    lanes = int(os.environ.get("FERN_HARNESS_LANES", "3"))
+    lanes = int(os.environ.get("FERN_HARNESS_LANES", "4"))
     eng = getattr(model, "engine", None)
     if lanes < 1 or not isinstance(clip_model, FernCLIP) or not isinstance(eng, FernEngine) or clip_model.engine is not eng or device.type != "cuda":
         return None

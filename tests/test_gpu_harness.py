@@ -106,14 +106,14 @@ def test_full_pipeline_with_hip_clip_matches_oracle_pipeline():
 
 
 def test_precision_switch_between_two_harness_calls_reaches_every_lane():
-    """the harness caches a 3-lane pipeline on the engine and a forked context copies the parent's precision only when it is
+    """the harness caches a multi-lane pipeline on the engine and a forked context copies the parent's precision only when it is
     made.  Switching the engine's precision BETWEEN two `generate_fiq_val_predictions` calls must change all lanes: the second call
     equals a call-by-call run (FERN_HARNESS_LANES=0, the parent context alone) at the new precision, batch by batch."""
     cfg = synth.CLIP_CONFIGS["tiny-hd64"]
     d = cfg.embed_dim
     register_tokenizer("tiny-hd64", lambda texts, context_length=77: sdata.stub_tokenizer(texts, context_length, vocab=cfg.vocab_size))
     gal = sdata.Gallery(200, d, seed=31, image_size=cfg.image_size)
-    rel = sdata.RelativeDataset(gal, 96, "fiq", seed=32)           # 6 batches of 16: two per lane
+    rel = sdata.RelativeDataset(gal, 128, "fiq", seed=32)          # 8 batches of 16: two per lane
     clip = create_model(cfg, device=DEV, seed=9)
     model = ERN(clip, d, DEV, engine=clip.engine).init_random(4)
     eng = model.engine
@@ -124,10 +124,11 @@ def test_precision_switch_between_two_harness_calls_reaches_every_lane():
 
     eng.set_precision("fp32")
     p_fp32 = predictions()                                          # builds and caches the pipeline at fp32
-    assert len(eng._harness_pipe.engines) == 3
+    lanes = int(os.environ.get("FERN_HARNESS_LANES", "4"))
+    assert len(eng._harness_pipe.engines) == lanes
     eng.set_precision("bf16")                                       # the parent context only
     p_bf16 = predictions()
-    assert [e.precision for e in eng._harness_pipe.engines] == ["bf16"] * 3
+    assert [e.precision for e in eng._harness_pipe.engines] == ["bf16"] * lanes
     os.environ["FERN_HARNESS_LANES"] = "0"
     try:
         p_bf16_serial = predictions()
@@ -135,7 +136,7 @@ def test_precision_switch_between_two_harness_calls_reaches_every_lane():
         os.environ.pop("FERN_HARNESS_LANES")
     eng.set_precision("fp32")
     assert torch.equal(p_bf16, p_bf16_serial), "a lane kept the precision it was forked with"
-    for lo in range(0, 96, 16):                                     # every batch (= every lane) moved away from its fp32 bits
+    for lo in range(0, 128, 16):                                    # every batch (= every lane) moved away from its fp32 bits
         assert not torch.equal(p_bf16[lo:lo + 16], p_fp32[lo:lo + 16])
     assert torch.equal(predictions(), p_fp32)                       # and back
 
