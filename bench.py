@@ -1166,7 +1166,9 @@ def main():
                                     "fp8": "gemm_bf16_glds_kernel<FP8> (fp8 MFMA GEMM of the encoder blocks)",
                                     "mx8": "gemm_mx8_kernel (block-scaled fp8 GEMM of the encoder blocks, v_mfma_scale_f32_32x32x64_f8f6f4)",
                                     "mx8mlp": "gemm_mx8_kernel (block-scaled fp8 GEMMs of the MLP pair; QKV / out-proj run on gemm_bf16_glds_kernel)",
-                                    "mx8img": "gemm_mx8_kernel (block-scaled fp8 GEMMs of the image tower, v_mfma_scale_f32_32x32x64_f8f6f4; text tower / fusion BERT on the bf16 kernels)"}[precision],
+                                    "mx8img": "gemm_mxbf_pair_kernel / gemm_mx8_kernel (block-scaled fp8 GEMMs of the image tower, v_mfma_scale_f32_32x32x64_f8f6f4, "
+                                              "each carrying the text tower's bf16 GEMM of the same layer in its launch: the flops of both over the launch's "
+                                              "time, priced against the fp8 peak; fusion BERT on the bf16 kernels)"}[precision],
                          "peak_basis": "nominal (MI355X_MICROARCH.md, 2.4 GHz).  Measured on this pool with operands in registers and random data "
                                        "(tools/probe/mfma_issue_probe.hip, bf16_issue_probe.hip, mx_issue_probe.hip; profiles/r04_*_issue_probe.txt): the "
                                        "MFMA stream itself delivers 140-156 TFLOP/s fp32 (~2.04 GHz held inside the GEMM), 1.9-2.0 PFLOP/s bf16 and "

@@ -359,6 +359,16 @@ static int run_gemm_b(fern_ctx* c, const GemmParams& p, hipStream_t s) {
     HIP_TRY_PROF(le, c, slot);
     return prof_close(c, slot, s);
 }
+// The image tower's block-scaled GEMM of a layer and the text tower's bf16 GEMM of the same kind in ONE launch where that wins
+// (gemm_bf16.hip: launch_gemm_mxbf_pair; two launches otherwise).  One profile record, as run_gemm_pair.
+static int run_gemm_b_pair(fern_ctx* c, const GemmParams& p1, const GemmParams& p2, hipStream_t s) {
+    int slot;
+    FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * p1.M * (double)p1.N * p1.K + 2.0 * p2.M * (double)p2.N * p2.K, s, &slot, p1.M, p1.N, p1.K, 350 + p1.epi));
+    const hipError_t le = launch_gemm_mxbf_pair(p1, p2, s);
+    HIP_TRY_PROF(le, c, slot);
+    if (slot >= 0) c->recs[slot].dispatches = gemm_bf16_last_dispatches();
+    return prof_close(c, slot, s);
+}
 static int run_attention(fern_ctx* c, const AttnParams& a, hipStream_t s) {
     int slot;
     FERN_TRY(prof_open(c, PROF_ATTN, 4.0 * a.batch * a.heads * (double)a.s_q * a.s_k * a.hd, s, &slot, a.batch * a.heads, a.s_q, a.hd, a.causal));
@@ -1394,18 +1404,12 @@ static int clip_block_cls_only(fern_ctx* c, const ClipBlockW& Bk, const float* X
     return run_gemm(c, p2, s);
 }
 
-static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStream_t s) {
+// Front of the ViT tower: conv1 over the patches (its epilogue adds the positional embedding and skips the class slot) and the class token.
+// H is free until the first block: the reduced-precision modes stage their rounded patch rows there.
+static int vit_front(fern_ctx* c, const float* images, float* X, float* H, int b, hipStream_t s) {
     const ClipW& W = c->clip;
     const fern_clip_config& cf = W.cfg;
     const int vw = cf.v_width, g = cf.image_size / cf.patch_size, g2 = g * g, S = g2 + 1;
-    const long R = (long)b * S;
-    float *X, *XN, *QKV, *ATT, *H, *CLS;
-    FERN_TRY(ws_get(c, (size_t)R * vw, &X));
-    FERN_TRY(ws_get(c, (size_t)R * vw, &XN));
-    FERN_TRY(ws_get(c, (size_t)R * 3 * vw, &QKV));
-    FERN_TRY(ws_get(c, (size_t)R * vw, &ATT));
-    FERN_TRY(ws_get(c, (size_t)R * cf.v_mlp, &H));
-    FERN_TRY(ws_get(c, (size_t)b * vw, &CLS));
     if (c->precision == FERN_PREC_MX8 && W.conv_mx.wm && (3 * cf.patch_size * cf.patch_size) <= 1280) {
         // block-scaled mode: patch rows are quantised once (H is free until the first block) and conv1 runs on the scaled MFMA;
         // same epilogue (positional embedding added, class slot skipped)
@@ -1437,6 +1441,22 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
     FERN_TRY(run_gemm(c, pe, s));
     }
     HIP_TRY(launch_vit_cls(W.cls, W.vpos, X, b, S, vw, s));
+    return FERN_OK;
+}
+
+static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStream_t s) {
+    const ClipW& W = c->clip;
+    const fern_clip_config& cf = W.cfg;
+    const int vw = cf.v_width, g = cf.image_size / cf.patch_size, g2 = g * g, S = g2 + 1;
+    const long R = (long)b * S;
+    float *X, *XN, *QKV, *ATT, *H, *CLS;
+    FERN_TRY(ws_get(c, (size_t)R * vw, &X));
+    FERN_TRY(ws_get(c, (size_t)R * vw, &XN));
+    FERN_TRY(ws_get(c, (size_t)R * 3 * vw, &QKV));
+    FERN_TRY(ws_get(c, (size_t)R * vw, &ATT));
+    FERN_TRY(ws_get(c, (size_t)R * cf.v_mlp, &H));
+    FERN_TRY(ws_get(c, (size_t)b * vw, &CLS));
+    FERN_TRY(vit_front(c, images, X, H, b, s));
     unsigned short* Xb = nullptr;              // FERN_PREC_MX8: the bf16 residual stream of the full blocks
     const bool mx_stream = c->precision == FERN_PREC_MX8 && cf.v_layers > 1;
     if (mx_stream) {
@@ -1715,6 +1735,95 @@ static int pair_chunk(fern_ctx* c, const float* images, float* out_img, const in
     return FERN_OK;
 }
 
+// The same walk for FERN_PREC_MX8_IMG (the c5 default): the image tower's block-scaled GEMM of a layer and the text tower's bf16 GEMM of the
+// same kind as one launch (run_gemm_b_pair).  Everything else as vit_chunk (clip_block_mxmlp with attn_mx) / text_chunk (clip_block_bf16)
+// issue it; bit-identical to the two entry points.
+static int pair_chunk_mximg(fern_ctx* c, const float* images, float* out_img, const int64_t* tokens, float* out_global, float* out_seq, int b, hipStream_t s) {
+    const ClipW& W = c->clip;
+    const fern_clip_config& cf = W.cfg;
+    const int vw = cf.v_width, g = cf.image_size / cf.patch_size, g2 = g * g, S = g2 + 1;
+    const int tw = cf.t_width, T = cf.context_length, E = cf.embed_dim;
+    const long R = (long)b * S, Rt = (long)b * T;
+    float *X, *XN, *QKV, *ATT, *H, *CLS, *Xt, *XNt, *QKVt, *ATTt, *Ht;
+    int* eot;
+    FERN_TRY(ws_get(c, (size_t)R * vw, &X));
+    FERN_TRY(ws_get(c, (size_t)R * vw, &XN));
+    FERN_TRY(ws_get(c, (size_t)R * 3 * vw, &QKV));
+    FERN_TRY(ws_get(c, (size_t)R * vw, &ATT));
+    FERN_TRY(ws_get(c, (size_t)R * cf.v_mlp, &H));
+    FERN_TRY(ws_get(c, (size_t)b * vw, &CLS));
+    FERN_TRY(ws_get(c, (size_t)Rt * tw, &Xt));
+    FERN_TRY(ws_get(c, (size_t)Rt * tw, &XNt));
+    FERN_TRY(ws_get(c, (size_t)Rt * 3 * tw, &QKVt));
+    FERN_TRY(ws_get(c, (size_t)Rt * tw, &ATTt));
+    FERN_TRY(ws_get(c, (size_t)Rt * cf.t_mlp, &Ht));
+    FERN_TRY(ws_get(c, (size_t)b, &eot));
+    FERN_TRY(vit_front(c, images, X, H, b, s));
+    HIP_TRY(launch_layernorm(X, nullptr, W.ln_pre.g, W.ln_pre.b, X, R, vw, vw, vw, 1e-5f, s));
+    HIP_TRY(launch_text_embed(tokens, W.tok_emb, W.tpos, Xt, eot, b, T, tw, cf.vocab_size, c->tok_flag, s));
+    const int vfull = cf.v_layers - 1;
+    const int paired = vfull < cf.t_layers ? vfull : cf.t_layers;
+    const int vhd = vw / cf.v_heads, thd = tw / cf.t_heads, mlp = cf.v_mlp;
+    // operand views of the image tower's buffers (clip_block_mxmlp) and the text tower's (clip_block_bf16)
+    unsigned char* XN8 = reinterpret_cast<unsigned char*>(XN);
+    unsigned char* SM = reinterpret_cast<unsigned char*>(XN + ((size_t)R * vw / 4 + 63) / 64 * 64);
+    unsigned char* SH = SM + ((size_t)R * (vw / 32) + 255) / 256 * 256;
+    unsigned short* QKVb = reinterpret_cast<unsigned short*>(QKV);
+    unsigned short* ATTb = reinterpret_cast<unsigned short*>(ATT);
+    unsigned char* ATT8 = reinterpret_cast<unsigned char*>(ATT) + (size_t)R * vw * 2;
+    unsigned char* H8 = reinterpret_cast<unsigned char*>(H);
+    unsigned short *XNtb = reinterpret_cast<unsigned short*>(XNt), *QKVtb = reinterpret_cast<unsigned short*>(QKVt),
+                   *ATTtb = reinterpret_cast<unsigned short*>(ATTt), *Htb = reinterpret_cast<unsigned short*>(Ht);
+    for (int l = 0; l < paired; ++l) {
+        const ClipBlockW &Bv = W.vblocks[l], &Bt = W.tblocks[l];
+        HIP_TRY(launch_layernorm_mx8(X, Bv.ln1.g, Bv.ln1.b, XN8, SM, R, R, vw, vw, vw, 1e-5f, s));
+        HIP_TRY(launch_layernorm_bf16(Xt, Bt.ln1.g, Bt.ln1.b, XNtb, Rt, tw, tw, tw, 1e-5f, s));
+        FERN_TRY(run_gemm_b_pair(c, gemm_desc_mx(XN8, SM, R, vw, Bv.qkv, QKVb, 3 * vw, (int)R, EPI_BIAS, true),
+                                 gemm_desc_b(XNtb, tw, Bt.qkv, QKVtb, 3 * tw, (int)Rt, EPI_BIAS, true), s));
+        AttnParams av{nullptr, nullptr, nullptr, nullptr, 3L * vw, 3L * vw, 3L * vw, (long)vw,
+                      b, cf.v_heads, vhd, S, S, 0, 1.0f / std::sqrt((float)vhd), ATTb, QKVb, QKVb + vw, QKVb + 2 * vw};
+        av.out_b = nullptr; av.out_q8 = ATT8; av.out_scales = SM; av.out_srows = R;
+        FERN_TRY(run_attention(c, av, s));
+        AttnParams at{nullptr, nullptr, nullptr, nullptr, 3L * tw, 3L * tw, 3L * tw, (long)tw,
+                      b, cf.t_heads, thd, T, T, 1, 1.0f / std::sqrt((float)thd), ATTtb, QKVtb, QKVtb + tw, QKVtb + 2 * tw};
+        FERN_TRY(run_attention(c, at, s));
+        GemmParams pov = gemm_desc_mx(ATT8, SM, R, vw, Bv.out, X, vw, (int)R, EPI_BIAS_RESIDUAL, false);
+        GemmParams pot = gemm_desc_b(ATTtb, tw, Bt.out, Xt, tw, (int)Rt, EPI_BIAS_RESIDUAL, false);
+        pov.R = X; pot.R = Xt;
+        FERN_TRY(run_gemm_b_pair(c, pov, pot, s));
+        HIP_TRY(launch_layernorm_mx8(X, Bv.ln2.g, Bv.ln2.b, XN8, SM, R, R, vw, vw, vw, 1e-5f, s));
+        HIP_TRY(launch_layernorm_bf16(Xt, Bt.ln2.g, Bt.ln2.b, XNtb, Rt, tw, tw, tw, 1e-5f, s));
+        GemmParams pfv = gemm_desc_mx(XN8, SM, R, vw, Bv.fc, H8, mlp, (int)R, EPI_BIAS_GELU, false);
+        pfv.out_mx8 = 1; pfv.mxc = SH; pfv.mxc_rows = R;
+        FERN_TRY(run_gemm_b_pair(c, pfv, gemm_desc_b(XNtb, tw, Bt.fc, Htb, Bt.fc.out, (int)Rt, EPI_BIAS_GELU, true), s));
+        GemmParams ppv = gemm_desc_mx(H8, SH, R, mlp, Bv.proj, X, vw, (int)R, EPI_BIAS_RESIDUAL, false);
+        GemmParams ppt = gemm_desc_b(Htb, Bt.fc.out, Bt.proj, Xt, tw, (int)Rt, EPI_BIAS_RESIDUAL, false);
+        ppv.R = X; ppt.R = Xt;
+        FERN_TRY(run_gemm_b_pair(c, ppv, ppt, s));
+    }
+    for (int l = paired; l < vfull; ++l)
+        FERN_TRY(clip_block_mxmlp(c, W.vblocks[l], X, XN, QKVb, ATTb, H8, b, S, vw, cf.v_heads, 0, s, true));
+    for (int l = paired; l < cf.t_layers; ++l) FERN_TRY(clip_block_bf16(c, W.tblocks[l], Xt, XNtb, QKVtb, ATTtb, Htb, b, T, tw, cf.t_heads, 1, s));
+    // image tower tail -- as vit_chunk
+    FERN_TRY(clip_block_cls_only(c, W.vblocks[cf.v_layers - 1], X, XN, QKV, CLS, ATT, ATT + (size_t)b * vw, H, b, S, vw, cf.v_heads, s, nullptr));
+    HIP_TRY(launch_layernorm(CLS, nullptr, W.ln_post.g, W.ln_post.b, CLS, b, vw, vw, vw, 1e-5f, s));
+    LinearW vproj{W.vproj_t, nullptr, E, vw};
+    FERN_TRY(run_gemm(c, gemm_desc(CLS, vw, vproj, out_img, E, b, EPI_BIAS), s));
+    // text tower tail -- as text_chunk
+    HIP_TRY(launch_layernorm(Xt, nullptr, W.ln_final.g, W.ln_final.b, XNt, Rt, tw, tw, tw, 1e-5f, s));
+    LinearW tproj{W.tproj_t, nullptr, E, tw};
+    if (out_seq) {
+        FERN_TRY(run_gemm(c, gemm_desc(XNt, tw, tproj, out_seq, E, (int)Rt, EPI_BIAS), s));
+        if (out_global) HIP_TRY(launch_gather_rows(out_seq, E, out_global, E, b, E, 1, T, 0, eot, s));
+    } else if (out_global) {
+        float* pooled;
+        FERN_TRY(ws_get(c, (size_t)b * tw, &pooled));
+        HIP_TRY(launch_gather_rows(XNt, tw, pooled, tw, b, tw, 1, T, 0, eot, s));
+        FERN_TRY(run_gemm(c, gemm_desc(pooled, tw, tproj, out_global, E, b, EPI_BIAS), s));
+    }
+    return FERN_OK;
+}
+
 // A token id outside the vocabulary cannot raise from inside a kernel (nn.Embedding does, in the reference): the embedding
 // kernel poisons the row with NaN and sets a host-mapped flag; it is turned into FERN_ERR_ARG here, at fern_sync and at the
 // next fern_text_encode -- without a synchronisation on the launch path.
@@ -1762,7 +1871,12 @@ extern "C" int fern_encode_pair(fern_ctx* c, const float* images, const int64_t*
     FERN_TRY(check_fresh(c, "fern_encode_pair"));
     if (B < 0 || (B && (!images || !tokens || !out_image || (!out_global && !out_seq)))) return fail(FERN_ERR_ARG, "fern_encode_pair: bad argument");
     const fern_clip_config& cf = c->clip.cfg;
-    const bool pairable = c->precision == FERN_PREC_FP32 && cf.v_arch == 0 && cf.v_layers > 1 && cf.t_layers > 0;
+    const bool towers = cf.v_arch == 0 && cf.v_layers > 1 && cf.t_layers > 0;
+    // the mixed mode pairs when every image GEMM of a block is block-scaled (head dim a multiple of 32: clip_block_mxmlp) and the text GEMMs
+    // meet the bf16 family's k tiling
+    const bool pair_mx = towers && c->precision == FERN_PREC_MX8_IMG && (cf.v_width / cf.v_heads) % 32 == 0 && cf.v_width % 128 == 0 &&
+                         cf.v_mlp % 128 == 0 && cf.t_width % 32 == 0 && cf.t_mlp % 32 == 0;
+    const bool pairable = towers && (c->precision == FERN_PREC_FP32 || pair_mx);
     if (!pairable) {      // every other mode / tower: the two entry points, one after the other (same results by definition)
         FERN_TRY(fern_vit_encode_image(c, images, out_image, B, stream));
         return fern_text_encode(c, tokens, nullptr, nullptr, out_global, out_seq, B, stream);
@@ -1779,7 +1893,7 @@ extern "C" int fern_encode_pair(fern_ctx* c, const float* images, const int64_t*
     for (int o = 0; o < B; o += CH) {
         const int m = std::min(CH, B - o);
         FERN_TRY(ws_begin(c, s));
-        FERN_TRY(pair_chunk(c, images + o * img_sz, out_image + (long)o * cf.embed_dim, tokens + (long)o * cf.context_length,
+        FERN_TRY((pair_mx ? pair_chunk_mximg : pair_chunk)(c, images + o * img_sz, out_image + (long)o * cf.embed_dim, tokens + (long)o * cf.context_length,
                             out_global ? out_global + (long)o * cf.embed_dim : nullptr,
                             out_seq ? out_seq + (long)o * cf.context_length * cf.embed_dim : nullptr, m, s));
     }

@@ -32,8 +32,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // FP8: the operands are OCP e4m3fn bytes and the MFMA is v_mfma_f32_32x32x16_fp8_fp8 (same rate as bf16, half the bytes):
 // a BKE-element tile row is then BKE bytes, one ds_read_b128 holds the fragments of TWO consecutive MFMA k-steps (low /
 // high 8 bytes), and the tile loop runs half as many iterations for the same K.
-template <int BM, int BN, int WM, int WN, int BKE, int STAGES, int MINW, bool FP8 = false>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_glds_kernel(GemmParams p) {
+// bytes of LDS a configuration stages through (the wrappers and the pair kernel size their one __shared__ object with it)
+template <int BM, int BN, int BKE, int STAGES, bool FP8>
+constexpr int bf16_tile_lds() { return STAGES * (BM + BN) * BKE * (FP8 ? 1 : 2); }
+// The kernel body as a device function of (problem, block index, LDS base): gemm_bf16_glds_kernel is its one-problem wrapper, and
+// gemm_mxbf_pair_kernel below runs it on the SECOND problem of an image + text pair (round 6).
+template <int BM, int BN, int WM, int WN, int BKE, int STAGES, bool FP8 = false>
+__device__ __forceinline__ void bf16_tile_body(const GemmParams& p, const int bid, char* smem) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
     constexpr int NW = WAVES_M * WAVES_N;
@@ -50,8 +55,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
     constexpr int FMASK = C4 - 1;
     constexpr int TILE = ROWS * RB;                      // bytes per stage
 
-    // one __shared__ object (see gemm.hip: a second one makes hipcc drain the DMA before every first fragment read)
-    __shared__ __attribute__((aligned(1024))) char smem[STAGES * TILE];
+    // (the caller's ONE __shared__ object -- see gemm.hip: a second one makes hipcc drain the DMA before every first fragment read)
+    static_assert(STAGES * TILE == bf16_tile_lds<BM, BN, BKE, STAGES, FP8>(), "LDS size");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -62,7 +67,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
     // XCD-aware bijective workgroup -> tile map (n fastest inside an XCD's contiguous run)
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const int nwg = nbm * nbn;
-    const int bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int bm = swz / nbn, bn = swz % nbn;
@@ -163,6 +167,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
     }
     gemm_epilogue<BM, BN, WM, WN, TM, TN, WAVES_N, true>(p, acc, bm, bn, nbn, wm, wn, l31, lh, tid);
 }
+template <int BM, int BN, int WM, int WN, int BKE, int STAGES, int MINW, bool FP8 = false>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_glds_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(1024))) char smem[bf16_tile_lds<BM, BN, BKE, STAGES, FP8>()];
+    bf16_tile_body<BM, BN, WM, WN, BKE, STAGES, FP8>(p, blockIdx.x, smem);
+}
 
 // ---- MX (block-scaled) fp8: v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands --------------------------------------------
 // One instruction is a 32x32 tile over 64 k: lane (r = lane & 31, h = lane >> 5) supplies 32 bytes of its row of A (8 VGPRs) and of
@@ -179,8 +188,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_gl
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MINW, int RB = 128>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_kernel(GemmParams p) {
+template <int BM, int BN, int STAGES, int RB>
+constexpr int mx8_tile_lds() { return STAGES * (((BM + BN) * RB + (BM + BN) * 4 + 1023) / 1024 * 1024); }
+// body / wrapper split as for the bf16 kernel above
+template <int BM, int BN, int WM, int WN, int STAGES, int RB = 128>
+__device__ __forceinline__ void mx8_tile_body(const GemmParams& p, const int bid, char* smem) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
     constexpr int NW = WAVES_M * WAVES_N;
@@ -199,8 +211,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
     constexpr int DATA = ROWS * RB;
     constexpr int TILE = (DATA + ROWS * 4 + 1023) / 1024 * 1024;   // bytes per stage: rows, then one scale dword per row
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
-
-    __shared__ __attribute__((aligned(1024))) char smem[STAGES * TILE];
+    static_assert(STAGES * TILE == mx8_tile_lds<BM, BN, STAGES, RB>(), "LDS size");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -210,7 +221,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
 
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const int nwg = nbm * nbn;
-    const int bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int bm = swz / nbn, bn = swz % nbn;
@@ -381,6 +391,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_ker
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // reads done before the next tile overwrites the patch
         }
 }
+template <int BM, int BN, int WM, int WN, int STAGES, int MINW, int RB = 128>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_mx8_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(1024))) char smem[mx8_tile_lds<BM, BN, STAGES, RB>()];
+    mx8_tile_body<BM, BN, WM, WN, STAGES, RB>(p, blockIdx.x, smem);
+}
 
 struct TileCfgB { int bm, bn, bk, per_cu; };     // per_cu: workgroups of the configuration one CU holds (LDS / registers / waves)
 // The tuner's candidates.  Retired after A/B runs on MI355X: 3- and 4-stage rings of the 128x128 tile and
@@ -505,6 +520,11 @@ struct ShapeKeyB {
 };
 static std::map<ShapeKeyB, int> g_tuned_b;
 static std::mutex g_tuned_b_mu;
+struct PairKeyB {                                 // launch_gemm_mxbf_pair (end of this file): a (block-scaled shape, bf16 shape) pair
+    ShapeKeyB a, b;
+    bool operator<(const PairKeyB& o) const { return a < o.a || (!(o.a < a) && b < o.b); }
+};
+static std::map<PairKeyB, int>& pair_b_map();
 // Launches of other streams expected to run beside one of these GEMMs (fern_tuner_set_concurrency; the query pipeline sets its
 // lane count).  1: a trial's score is its duration.  > 1: duration x (share of the chip's workgroup slots the launch fills)^0.75 --
 // a launch that leaves CUs to its neighbours is worth more to the pipeline than its own latency says.  Measured on the c5 pipeline
@@ -518,6 +538,13 @@ void gemm_bf16_tuner_set_concurrency(int n) {
 
 // FERN_GEMM_TILES=<file>: lines "bf16 M N K epi ob cfg" / "fp8 M N K epi ob cfg" / "mx8 M N K epi ob cfg" pin the choices (see gemm.hip)
 static void pin_tile_line_b(const char* line) {      // caller holds g_tuned_b_mu
+    {      // "pairb M1 N1 K1 epi1 ob1 M2 N2 K2 epi2 ob2 choice": launch_gemm_mxbf_pair's choice for a (block-scaled, bf16) pair of shapes
+        int v[11];
+        if (sscanf(line, "pairb %d %d %d %d %d %d %d %d %d %d %d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8], &v[9], &v[10]) == 11) {
+            if (v[10] >= 0 && v[10] <= 2) pair_b_map()[PairKeyB{ShapeKeyB{v[0], v[1], v[2], v[3], v[4]}, ShapeKeyB{v[5], v[6], v[7], v[8], v[9]}}] = v[10];
+            return;
+        }
+    }
     char kind[16];
     int M, N, K, epi, ob, cfg;
     if (sscanf(line, "%15s %d %d %d %d %d %d", kind, &M, &N, &K, &epi, &ob, &cfg) != 7) return;
@@ -560,6 +587,12 @@ void gemm_bf16_tuner_export(std::string& out) {
         char line[128];
         snprintf(line, sizeof line, "%s %d %d %d %d %d %d\n", (kv.first.ob & 4) ? "mx8" : (kv.first.ob & 2) ? "fp8" : "bf16", kv.first.M, kv.first.N, kv.first.K, kv.first.epi,
                  kv.first.ob, kv.second);
+        out += line;
+    }
+    for (const auto& kv : pair_b_map()) {
+        char line[192];
+        const ShapeKeyB &a = kv.first.a, &b = kv.first.b;
+        snprintf(line, sizeof line, "pairb %d %d %d %d %d %d %d %d %d %d %d\n", a.M, a.N, a.K, a.epi, a.ob, b.M, b.N, b.K, b.epi, b.ob, kv.second);
         out += line;
     }
 }
@@ -640,19 +673,26 @@ static int tuned_cfg_b(const ShapeKeyB& key, const GemmParams& p, hipStream_t s)
     return c;
 }
 
+// the argument checks of the family (launch_gemm_bf16 and the pair launcher below)
+static bool rp_args_ok(const GemmParams& p) {
+    const int kq = p.fp8 == 2 ? 128 : p.fp8 ? 64 : 32, aq = p.fp8 ? 15 : 7;
+    if (p.K <= 0 || (p.K % kq) != 0 || (p.lda & aq) || (p.ldw & aq) || p.aload != ALOAD_PLAIN || epi_is_reduce(p.epi)) return false;
+    if (!p.Ab || !p.Wb || ((uintptr_t)p.Ab & 15) || ((uintptr_t)p.Wb & 15)) return false;
+    if ((p.scale_a == nullptr) != (p.scale_w == nullptr)) return false;
+    if (p.fp8 == 2) {
+        if (!p.mxa || !p.mxw || p.scale_a || ((uintptr_t)p.mxa & 3) || ((uintptr_t)p.mxw & 3) || p.mxa_rows < p.M || p.mxw_rows < p.N) return false;
+        if (p.epi == EPI_BIAS_RESIDUAL && (p.out_bf16 ? !p.Rb : !p.R)) return false;
+        if (p.out_mx8 && (!p.mxc || p.mxc_rows < p.M || (p.N & 31) || (p.ldc & 15) || ((uintptr_t)p.C & 15) || (p.epi != EPI_BIAS && p.epi != EPI_BIAS_GELU)))
+            return false;
+    }
+    return true;
+}
+
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     load_pinned_tiles_b();
-    const int kq = p.fp8 == 2 ? 128 : p.fp8 ? 64 : 32, aq = p.fp8 ? 15 : 7;
-    if (p.K <= 0 || (p.K % kq) != 0 || (p.lda & aq) || (p.ldw & aq) || p.aload != ALOAD_PLAIN || epi_is_reduce(p.epi)) return hipErrorInvalidValue;
-    if (!p.Ab || !p.Wb || ((uintptr_t)p.Ab & 15) || ((uintptr_t)p.Wb & 15)) return hipErrorInvalidValue;
-    if ((p.scale_a == nullptr) != (p.scale_w == nullptr)) return hipErrorInvalidValue;
+    if (!rp_args_ok(p)) return hipErrorInvalidValue;
     if (p.fp8 == 2) {
-        if (!p.mxa || !p.mxw || p.scale_a || ((uintptr_t)p.mxa & 3) || ((uintptr_t)p.mxw & 3) || p.mxa_rows < p.M || p.mxw_rows < p.N)
-            return hipErrorInvalidValue;
-        if (p.epi == EPI_BIAS_RESIDUAL && (p.out_bf16 ? !p.Rb : !p.R)) return hipErrorInvalidValue;
-        if (p.out_mx8 && (!p.mxc || p.mxc_rows < p.M || (p.N & 31) || (p.ldc & 15) || ((uintptr_t)p.C & 15) || (p.epi != EPI_BIAS && p.epi != EPI_BIAS_GELU)))
-            return hipErrorInvalidValue;
         int c = forced_value_b(g_force_mx, "FERN_GEMM_MX8_CFG");
         if (c < 0 || c >= kNumCfgsMx) {
             c = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) >= 256 ? 0 : 6;
@@ -685,6 +725,129 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
         }
     }
     return launch_cfg_b(c, p, s);
+}
+
+// ---- image + text GEMM pair of the mixed mode, ONE launch (round 6) -------------------------------------------------------------------
+// FERN_PREC_MX8_IMG runs the image tower's GEMMs block-scaled and the text tower's in bf16.  The text GEMMs (M = 77 B rows, K = 512) are a
+// few dozen big tiles each: on their own every one of them is an 18-23 us launch that fills a fraction of the chip, while the image GEMM
+// of the same layer leaves CUs idle in its last round (12608 x 768: 150 tiles of 256 x 256 on 256 CUs).  The two towers are independent until
+// the fusion, so the text layer's GEMM rides in the image layer's launch: the SECOND problem's tiles come first in block order (a tail of
+// long-k tiles behind the first problem's cost more than it saved in the fp32 family: gemm.hip, gemm_f32_pair_kernel), then the first
+// problem's.  Both halves run the bodies of the family's own kernels on the tiles those kernels would compute, in the same k order:
+// bit-identical to two launches.  V = 0: 16 waves (256 x 256 block-scaled tiles with 128-byte rows + 256 x 256 bf16 tiles); V = 1: 8 waves,
+// two workgroups per CU (256 x 128 with 64-byte rows + 256 x 128 bf16).
+template <int V>
+__global__ __launch_bounds__(V == 0 ? 1024 : 512, V == 0 ? 1 : 4) void gemm_mxbf_pair_kernel(GemmParams p1, GemmParams p2, int n2_8) {
+    constexpr int L1 = V == 0 ? mx8_tile_lds<256, 256, 2, 128>() : mx8_tile_lds<256, 128, 3, 64>();
+    constexpr int L2 = V == 0 ? bf16_tile_lds<256, 256, 32, 3, false>() : bf16_tile_lds<256, 128, 32, 3, false>();
+    __shared__ __attribute__((aligned(1024))) char smem[L1 > L2 ? L1 : L2];
+    const int bid = blockIdx.x;
+    if (bid < n2_8) {
+        constexpr int BN2 = V == 0 ? 256 : 128;
+        const int tiles = ((p2.M + 255) / 256) * ((p2.N + BN2 - 1) / BN2);
+        if (bid >= tiles) return;
+        if (V == 0) bf16_tile_body<256, 256, 64, 64, 32, 3, false>(p2, bid, smem);
+        else bf16_tile_body<256, 128, 64, 64, 32, 3, false>(p2, bid, smem);
+    } else {
+        if (V == 0) mx8_tile_body<256, 256, 64, 64, 2, 128>(p1, bid - n2_8, smem);
+        else mx8_tile_body<256, 128, 64, 64, 3, 64>(p1, bid - n2_8, smem);
+    }
+}
+static hipError_t launch_mxbf_pair(int v, const GemmParams& p1, const GemmParams& p2, hipStream_t s) {
+    const int bn = v == 0 ? 256 : 128;
+    const int n1 = ((p1.M + 255) / 256) * ((p1.N + bn - 1) / bn), n2 = ((p2.M + 255) / 256) * ((p2.N + bn - 1) / bn);
+    const int n2_8 = (n2 + 7) & ~7;                       // the first problem starts on a multiple of 8 blocks: block % 8 stays its XCD
+    if (v == 0) FERN_LAUNCH((gemm_mxbf_pair_kernel<0>), dim3(n2_8 + n1), dim3(1024), 0, s, p1, p2, n2_8);
+    else FERN_LAUNCH((gemm_mxbf_pair_kernel<1>), dim3(n2_8 + n1), dim3(512), 0, s, p1, p2, n2_8);
+    return hipGetLastError();
+}
+// per (block-scaled shape, bf16 shape): 0 = two launches (each with its own tuned tile), 1 / 2 = the pair kernel V = 0 / 1.  Timed once on
+// scratch outputs; exported / pinned / imported with the tile choices ("pairb ..." lines).
+static std::map<PairKeyB, int> g_pair_b;      // guarded by g_tuned_b_mu
+static std::map<PairKeyB, int>& pair_b_map() { return g_pair_b; }
+static thread_local int g_last_dispatches_b = 1;
+int gemm_bf16_last_dispatches() { return g_last_dispatches_b; }
+static int tune_pair_b(const GemmParams& p1, const GemmParams& p2, hipStream_t s, bool& timed) {
+    LaunchTimerPause pause;
+    timed = false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0;
+    // scratch outputs: the residual inputs are only read, so the trials have no side effects (a quantising first problem also writes scales)
+    const size_t b1 = (size_t)p1.M * p1.ldc * sizeof(float) + (p1.out_mx8 ? (size_t)p1.M * p1.N / 32 + 256 : 0), b2 = (size_t)p2.M * p2.ldc * sizeof(float);
+    char *c1 = nullptr, *c2 = nullptr;
+    if (hipMalloc(&c1, b1) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipMalloc(&c2, b2) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(c1); return 0; }
+    GemmParams q1 = p1, q2 = p2;
+    q1.C = reinterpret_cast<float*>(c1);
+    q2.C = reinterpret_cast<float*>(c2);
+    if (p1.out_mx8) { q1.mxc = reinterpret_cast<unsigned char*>(c1) + (size_t)p1.M * p1.ldc * sizeof(float); q1.mxc_rows = p1.M; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    auto timed_ms = [&](auto&& fn) {
+        float best = 1e30f;
+        for (int round = 0; round < 2; ++round) {
+            if (fn() != hipSuccess) return 1e30f;
+            (void)hipEventRecord(e0, s);
+            (void)fn();
+            (void)fn();
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            best = std::min(best, ms);
+        }
+        return best;
+    };
+    float t[3];
+    t[0] = timed_ms([&] { const hipError_t e = launch_gemm_bf16(q1, s); return e != hipSuccess ? e : launch_gemm_bf16(q2, s); });
+    t[1] = timed_ms([&] { return launch_mxbf_pair(0, q1, q2, s); });
+    t[2] = timed_ms([&] { return launch_mxbf_pair(1, q1, q2, s); });
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(c1);
+    (void)hipFree(c2);
+    if (t[0] > 1e29f) return 0;
+    timed = true;
+    int best = 0;
+    for (int i = 1; i < 3; ++i)
+        if (t[i] < t[best]) best = i;
+    return best;
+}
+static bool pair_b_enabled() {
+    static const bool on = [] { const char* e = getenv("FERN_GEMM_PAIR"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// p1: a block-scaled GEMM (fp8 == 2), p2: a bf16 GEMM (fp8 == 0); one launch where a one-off timing says it wins, two otherwise
+hipError_t launch_gemm_mxbf_pair(const GemmParams& p1, const GemmParams& p2, hipStream_t s) {
+    g_last_dispatches_b = 1;
+    int choice = 0;
+    if (pair_b_enabled() && p1.fp8 == 2 && p2.fp8 == 0 && p1.M >= 256 && p2.M >= 256 && p1.N >= 256 && p2.N >= 256 && rp_args_ok(p1) && rp_args_ok(p2) &&
+        forced_value_b(g_force_mx, "FERN_GEMM_MX8_CFG") < 0 && forced_cfg_b() < 0) {
+        const char* e = getenv("FERN_GEMM_TUNE");
+        if (!(e && e[0] == '0')) {
+            load_pinned_tiles_b();
+            const PairKeyB key{ShapeKeyB{p1.M, p1.N, p1.K, p1.epi, p1.out_bf16 | 4 | (p1.out_mx8 ? 8 : 0)}, ShapeKeyB{p2.M, p2.N, p2.K, p2.epi, p2.out_bf16}};
+            bool known = false;
+            {
+                std::lock_guard<std::mutex> lock(g_tuned_b_mu);
+                auto it = g_pair_b.find(key);
+                if (it != g_pair_b.end()) { known = true; choice = it->second; }
+            }
+            if (!known) {                                   // (the two-launch trial takes the mutex itself: tuned_cfg_b)
+                bool timed = false;
+                choice = tune_pair_b(p1, p2, s, timed);
+                if (timed) {
+                    std::lock_guard<std::mutex> lock(g_tuned_b_mu);
+                    g_pair_b[key] = choice;
+                }
+            }
+        }
+    }
+    if (choice == 1 || choice == 2) return launch_mxbf_pair(choice - 1, p1, p2, s);
+    g_last_dispatches_b = 2;
+    const hipError_t e1 = launch_gemm_bf16(p1, s);
+    return e1 != hipSuccess ? e1 : launch_gemm_bf16(p2, s);
 }
 
 }  // namespace fern

@@ -183,6 +183,8 @@ hipError_t launch_gemm_pair(const GemmParams& p1, const GemmParams& p2, hipStrea
 int gemm_last_dispatches();      // kernel dispatches of the calling thread's last launch_gemm (2 for a bulk + remainder plan)
 // bf16 x bf16 -> fp32-accumulate GEMM (v_mfma_f32_32x32x16_bf16); plain epilogues only, K % 32 == 0, ALOAD_PLAIN
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s);
+hipError_t launch_gemm_mxbf_pair(const GemmParams& p_mx8, const GemmParams& p_bf16, hipStream_t s);      // image (block-scaled) + text (bf16) GEMM of a layer, ONE launch where it wins
+int gemm_bf16_last_dispatches();
 hipError_t launch_gemm_pp(bool mx, const GemmParams& p, hipStream_t s);      // gemm_pp.hip: the ping-pong 256 x 256 tile (cfg 7 / 11 of the bf16 / block-scaled families)
 // the per-shape tile choices made so far, one text line per shape (the format FERN_GEMM_TILES=<file> reads back)
 void gemm_tuner_export(std::string& out);

@@ -413,7 +413,7 @@ def test_encoders_chunk_large_batches_without_changing_rows(precision):
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f32x3", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "f32x3", "bf16", "mx8img"])
 @pytest.mark.parametrize("cfg_name,b", [("ViT-B-16", 64), ("ViT-B-16", 5), ("tiny", 7)])
 def test_encode_pair_is_bit_identical_to_the_two_encoder_calls(cfg_name, b, precision):
     """fern_encode_pair (round 6): both towers of a query batch walked layer by layer, the text layer's GEMMs riding in the image layer's
@@ -426,9 +426,9 @@ def test_encode_pair_is_bit_identical_to_the_two_encoder_calls(cfg_name, b, prec
     eng = FernEngine("cuda:0")
     eng.load_tensors(synth.clip_state_dict(cfg, seed=4))
     eng.finalize_clip(cfg)
-    if precision == "bf16" and cfg_name == "tiny":
+    if precision in ("bf16", "mx8img") and cfg_name == "tiny":
         eng.close()
-        pytest.skip("the tiny tower's widths are outside the bf16 mode")
+        pytest.skip("the tiny tower's widths are outside the reduced-precision modes")
     eng.set_precision(precision)
     imgs = torch.from_numpy(synth.images(b, cfg, 11)).cuda()
     toks = torch.from_numpy(synth.captions(b, cfg, 11)).cuda()
@@ -437,7 +437,7 @@ def test_encode_pair_is_bit_identical_to_the_two_encoder_calls(cfg_name, b, prec
     for rep in range(3):                                   # 1st: shapes seen for the first time by the pair launcher; 2nd, 3rd: tuned plans
         pi, pg, ps = eng.encode_pair(imgs, toks)
         assert torch.equal(pi, ref_i) and torch.equal(pg, ref_g) and torch.equal(ps, ref_s), (cfg_name, b, precision, rep)
-    if precision != "bf16" and cfg_name == "ViT-B-16" and b == 64:
+    if precision in ("fp32", "f32x3") and cfg_name == "ViT-B-16" and b == 64:
         # both forms of every pair, whatever the pair tuner chose on this box: flip each exported "pair ... 0|1" line, import, compare bits
         pairs = [ln for ln in eng.tuner_export().splitlines() if ln.startswith("pair ")]
         assert len(pairs) >= 3, pairs                      # QKV / out-proj / c_fc / c_proj of the ViT-B/16 + text layers (those whose image plan is a mixed plan)
@@ -447,9 +447,21 @@ def test_encode_pair_is_bit_identical_to_the_two_encoder_calls(cfg_name, b, prec
         pi, pg, ps = eng.encode_pair(imgs, toks)
         assert torch.equal(pi, ref_i) and torch.equal(pg, ref_g) and torch.equal(ps, ref_s), "one-launch and two-launch forms of a pair differ"
         eng.tuner_import("\n".join(pairs) + "\n")
+    if precision == "mx8img" and b == 64:
+        # the mixed mode's pairs (gemm_bf16.hip: launch_gemm_mxbf_pair): two launches / the 16-wave pair kernel / the 8-wave one, all three
+        # forms of every pair whatever the pair tuner chose on this box
+        pairs = [ln for ln in eng.tuner_export().splitlines() if ln.startswith("pairb ")]
+        assert len(pairs) == 4, pairs                      # QKV / out-proj / c_fc / c_proj of the ViT-B/16 + text layers
+        for choice in "012":
+            forced = "\n".join(ln.rsplit(" ", 1)[0] + " " + choice for ln in pairs) + "\n"
+            eng.tuner_import(forced)
+            assert all(ln in eng.tuner_export() for ln in forced.splitlines())
+            pi, pg, ps = eng.encode_pair(imgs, toks)
+            assert torch.equal(pi, ref_i) and torch.equal(pg, ref_g) and torch.equal(ps, ref_s), f"pair form {choice} differs from the two calls"
+        eng.tuner_import("\n".join(pairs) + "\n")
     pi, pg, ps = eng.encode_pair(imgs, toks, want_seq=False)      # global only: the pooled-row projection, as encode_text(want_seq=False) computes it
     assert ps is None and torch.equal(pi, ref_i) and torch.equal(pg, eng.encode_text(toks, want_seq=False)[0])
-    if precision != "bf16":
+    if precision in ("fp32", "f32x3"):
         eng.tuner_force_config("f32" if precision == "fp32" else "f32x3", 0)      # a forced tile: the pair launcher makes two launches
         try:
             pi, pg, ps = eng.encode_pair(imgs, toks)

@@ -54,7 +54,8 @@ def summarise(rows, scale):
             if re.search(r"sweep_bf16_kernel<\d+,\s*true", name) or "topk_dense_rescore_kernel" in nxt or "topk_tiles_rescore_kernel" in nxt or "sweep_bf16_kernel" in nxt:
                 sweep_ids.add(r[0])
     fam = lambda key: [r for r in rows if key in r[1] and r[0] not in rank_ids]  # noqa: E731
-    gemm, mx8, b16 = fam("gemm_f32"), fam("gemm_mx8_kernel"), fam("gemm_bf16_glds_kernel")
+    # (gemm_mxbf_pair_kernel: a block-scaled image-tower GEMM carrying the text tower's bf16 GEMM of the same layer -- the mx8 family's launch)
+    gemm, mx8, b16 = fam("gemm_f32"), fam("gemm_mx8_kernel") + fam("gemm_mxbf_pair_kernel"), fam("gemm_bf16_glds_kernel")
     rank = [r for r in rows if r[0] in rank_ids]
     sweep = [r for r in rows if r[0] in sweep_ids]
     # one select kernel per ranking call (the gated exact-pass launch no longer closes every call: the dense form on small galleries ranks
