@@ -210,8 +210,9 @@ FERN_API int fern_text_encode(fern_ctx* ctx, const int64_t* tokens, const float*
  * models/clip_model.py:10-31) -- with the towers walked layer by layer so that the text layer's GEMMs ride in the image layer's launches
  * (models/others/modeling_clip.py:694-768 and :832-887 are independent until the fusion).  images [B,3,S,S], tokens [B,ctx] ->
  * out_image [B,D], out_global [B,D] (may be NULL), out_seq [B,ctx,D] (may be NULL).  Results are BIT-IDENTICAL to fern_vit_encode_image +
- * fern_text_encode; FERN_PREC_FP32 (also under F32X3) with the ViT tower pairs the launches, every other mode / tower simply makes the two
- * calls.  Token-id errors as fern_text_encode. */
+ * fern_text_encode.  With the ViT tower the launches are paired under FERN_PREC_FP32 (also under F32X3: two fp32-data-flow GEMMs per launch)
+ * and under FERN_PREC_MX8_IMG (the image layer's block-scaled GEMM carries the text layer's bf16 GEMM); every other mode / tower simply
+ * makes the two calls.  Token-id errors as fern_text_encode. */
 FERN_API int fern_encode_pair(fern_ctx* ctx, const float* images, const int64_t* tokens, float* out_image, float* out_global, float* out_seq,
                               int B, void* stream);
 
