@@ -30,7 +30,8 @@ class ProfStats(C.Structure):
                 ("gemm_fp8_ms", C.c_double), ("gemm_fp8_flops", C.c_double), ("gemm_fp8_launches", c_i64),
                 ("gemm_bf16_ms", C.c_double), ("gemm_bf16_flops", C.c_double), ("gemm_bf16_launches", c_i64),
                 ("gemm_alg_bytes", C.c_double), ("gemm_dispatches", c_i64),
-                ("gemm_mx8_ms", C.c_double), ("gemm_mx8_flops", C.c_double), ("gemm_mx8_launches", c_i64)]
+                ("gemm_mx8_ms", C.c_double), ("gemm_mx8_flops", C.c_double), ("gemm_mx8_launches", c_i64),
+                ("gemm_mx8_bf16_flops", C.c_double)]
 
 
 # name -> (restype, argtypes); must list every symbol include/fern.h declares (tests check this)
@@ -118,7 +119,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.fern_abi_version() != 2:
+    if lib.fern_abi_version() != 3:
         raise RuntimeError("libfern.so ABI version mismatch")
     _lib = lib
     return lib

@@ -108,6 +108,7 @@ struct ProfRec { hipEvent_t a, b; int kind; double work; int m, n, k, tag; int d
                     dispatch begin -> last dispatch end (launch boundaries between them included), the dispatches [sweep_lo, sweep_hi) are its
                     full-gallery sweep(s), `work` their bytes */
                  bool span = false; int sweep_lo = 0, sweep_hi = 0;
+                 double extra_flops = 0.0; /* run_gemm_b_pair: the flops of `work` that belong to the second (bf16) problem */
                  double extra_alg_bytes = 0.0; /* a GEMM PAIR record (run_gemm_pair): the second problem's algorithmic bytes (m, n, k are the first's) */ };
 
 namespace fern {
@@ -366,7 +367,10 @@ static int run_gemm_b_pair(fern_ctx* c, const GemmParams& p1, const GemmParams& 
     FERN_TRY(prof_open(c, PROF_GEMM, 2.0 * p1.M * (double)p1.N * p1.K + 2.0 * p2.M * (double)p2.N * p2.K, s, &slot, p1.M, p1.N, p1.K, 350 + p1.epi));
     const hipError_t le = launch_gemm_mxbf_pair(p1, p2, s);
     HIP_TRY_PROF(le, c, slot);
-    if (slot >= 0) c->recs[slot].dispatches = gemm_bf16_last_dispatches();
+    if (slot >= 0) {
+        c->recs[slot].dispatches = gemm_bf16_last_dispatches();
+        c->recs[slot].extra_flops = 2.0 * p2.M * (double)p2.N * p2.K;
+    }
     return prof_close(c, slot, s);
 }
 static int run_attention(fern_ctx* c, const AttnParams& a, hipStream_t s) {
@@ -2452,7 +2456,7 @@ extern "C" int fern_prof_collect(fern_ctx* c, fern_prof_stats* out) {
         if (dump) std::fprintf(dump, "%d,%d,%d,%d,%d,%.6f,%.0f\n", r.kind, r.m, r.n, r.k, r.tag, ms, r.work);
         switch (r.kind) {
             case PROF_GEMM:
-                if (r.tag >= 300) { out->gemm_mx8_ms += ms; out->gemm_mx8_flops += r.work; out->gemm_mx8_launches++; }
+                if (r.tag >= 300) { out->gemm_mx8_ms += ms; out->gemm_mx8_flops += r.work; out->gemm_mx8_launches++; out->gemm_mx8_bf16_flops += r.extra_flops; }
                 else if (r.tag >= 200) { out->gemm_fp8_ms += ms; out->gemm_fp8_flops += r.work; out->gemm_fp8_launches++; }
                 else if (r.tag >= 100) { out->gemm_bf16_ms += ms; out->gemm_bf16_flops += r.work; out->gemm_bf16_launches++; }
                 else { out->gemm_ms += ms; out->gemm_flops += r.work; out->gemm_launches++;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FERN_ABI_VERSION 2
+#define FERN_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define FERN_API __attribute__((visibility("default")))
@@ -167,6 +167,9 @@ typedef struct {
     double gemm_mx8_ms;    /* block-scaled fp8 GEMM launches (FERN_PREC_MX8, fern_gemm_mx8): not included in any of the above */
     double gemm_mx8_flops;
     int64_t gemm_mx8_launches;
+    double gemm_mx8_bf16_flops; /* the part of gemm_mx8_flops done on the BF16 MFMA: the text tower's GEMMs that ride in the image tower's
+                                   block-scaled launches under FERN_PREC_MX8_IMG (fern_encode_pair) -- a roofline of those launches prices
+                                   the two parts against their own peaks (ABI 3) */
 } fern_prof_stats;
 
 FERN_API int fern_abi_version(void);

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_ctypes_loader_and_error_reporting_without_gpu():
     lib = _lib.load()
-    assert lib.fern_abi_version() == 2
+    assert lib.fern_abi_version() == 3
     # argument validation happens before any HIP call
     assert lib.fern_finalize_fusion(None, 512, 7) == -1
     assert b"ctx is NULL" in lib.fern_last_error()
