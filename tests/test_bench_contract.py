@@ -153,3 +153,14 @@ def test_bench_multi_rank_preflight_and_latency_keys(tmp_path):
     env.pop("FERN_BENCH_SHARE_GPU")
     r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r2.returncode != 0      # one GPU here: rank 1 has no cuda:1 (on a node where two ranks name one device the pre-flight refuses)
+
+
+def test_mixed_peak_prices_each_part_of_a_paired_launch_against_its_own_peak():
+    """bench.mixed_peak: the c5 default mode's block-scaled launches carry the text tower's bf16 GEMMs (fern_prof_stats.gemm_mx8_bf16_flops);
+    the roofline peak of such launches is total flops / (fp8 flops / 5 PFLOP/s + bf16 flops / 2.5 PFLOP/s)."""
+    import bench
+    assert bench.mixed_peak({"gemm_mx8_flops": 0.0}) == bench.MX8_MFMA_PEAK_TFLOPS
+    assert bench.mixed_peak({"gemm_mx8_flops": 3e12, "gemm_mx8_bf16_flops": 0.0}) == bench.MX8_MFMA_PEAK_TFLOPS
+    assert abs(bench.mixed_peak({"gemm_mx8_flops": 2e12, "gemm_mx8_bf16_flops": 2e12}) - bench.BF16_MFMA_PEAK_TFLOPS) < 1e-9
+    p = bench.mixed_peak({"gemm_mx8_flops": 2.335e12, "gemm_mx8_bf16_flops": 0.372e12})      # a c5 step: 1.963 TFLOP fp8 + 0.372 TFLOP bf16
+    assert abs(p - 2.335 / (1.963 / 5000.0 + 0.372 / 2500.0)) < 1e-6 and 4300 < p < 4330
