@@ -1448,6 +1448,39 @@ static int vit_front(fern_ctx* c, const float* images, float* X, float* H, int b
     return FERN_OK;
 }
 
+// Tail of the ViT tower: the last block for the class rows only, ln_post, the visual projection (modeling_clip.py:876-887).  ATT / H are
+// free after the last full block: their heads are the [b, width] / [b, mlp] temporaries.  Xb: the bf16 residual stream of FERN_PREC_MX8.
+static int vit_tail(fern_ctx* c, float* X, float* XN, float* QKV, float* ATT, float* H, float* CLS, float* out, int b, hipStream_t s,
+                    const unsigned short* Xb = nullptr) {
+    const ClipW& W = c->clip;
+    const fern_clip_config& cf = W.cfg;
+    const int vw = cf.v_width, g = cf.image_size / cf.patch_size, S = g * g + 1;
+    FERN_TRY(clip_block_cls_only(c, W.vblocks[cf.v_layers - 1], X, XN, QKV, CLS, ATT, ATT + (size_t)b * vw, H, b, S, vw, cf.v_heads, s, Xb));
+    HIP_TRY(launch_layernorm(CLS, nullptr, W.ln_post.g, W.ln_post.b, CLS, b, vw, vw, vw, 1e-5f, s));
+    LinearW proj{W.vproj_t, nullptr, cf.embed_dim, vw};
+    return run_gemm(c, gemm_desc(CLS, vw, proj, out, cf.embed_dim, b, EPI_BIAS), s);
+}
+// Tail of the text tower: ln_final over every token, the text projection of all rows (out_seq; global == seq[EOT]) or of the EOT rows only
+// (modeling_clip.py:760-768, models/clip_model.py:23-31).
+static int text_tail(fern_ctx* c, const float* X, float* XN, const int* eot, float* out_global, float* out_seq, int B, hipStream_t s) {
+    const ClipW& W = c->clip;
+    const fern_clip_config& cf = W.cfg;
+    const int tw = cf.t_width, T = cf.context_length, E = cf.embed_dim;
+    const long R = (long)B * T;
+    HIP_TRY(launch_layernorm(X, nullptr, W.ln_final.g, W.ln_final.b, XN, R, tw, tw, tw, 1e-5f, s));
+    LinearW proj{W.tproj_t, nullptr, E, tw};
+    if (out_seq) {
+        FERN_TRY(run_gemm(c, gemm_desc(XN, tw, proj, out_seq, E, (int)R, EPI_BIAS), s));
+        if (out_global) HIP_TRY(launch_gather_rows(out_seq, E, out_global, E, B, E, 1, T, 0, eot, s));   // global == seq[EOT]
+    } else if (out_global) {
+        float* pooled;
+        FERN_TRY(ws_get(c, (size_t)B * tw, &pooled));
+        HIP_TRY(launch_gather_rows(XN, tw, pooled, tw, B, tw, 1, T, 0, eot, s));
+        FERN_TRY(run_gemm(c, gemm_desc(pooled, tw, proj, out_global, E, B, EPI_BIAS), s));
+    }
+    return FERN_OK;
+}
+
 static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStream_t s) {
     const ClipW& W = c->clip;
     const fern_clip_config& cf = W.cfg;
@@ -1492,13 +1525,8 @@ static int vit_chunk(fern_ctx* c, const float* images, float* out, int b, hipStr
         else
             FERN_TRY(clip_block(c, W.vblocks[l], X, XN, QKV, ATT, H, b, S, vw, cf.v_heads, 0, s));
     }
-    // ATT / H are free after the last full block: reuse their heads as the [b, width] / [b, mlp] temporaries.  The class-row chain of the
-    // last block is fp32; with the bf16 stream only the class rows are widened (exactly), inside the block
-    FERN_TRY(clip_block_cls_only(c, W.vblocks[cf.v_layers - 1], X, XN, QKV, CLS, ATT, ATT + (size_t)b * vw, H, b, S, vw, cf.v_heads, s,
-                                 mx_stream ? Xb : nullptr));
-    HIP_TRY(launch_layernorm(CLS, nullptr, W.ln_post.g, W.ln_post.b, CLS, b, vw, vw, vw, 1e-5f, s));
-    LinearW proj{W.vproj_t, nullptr, cf.embed_dim, vw};
-    return run_gemm(c, gemm_desc(CLS, vw, proj, out, cf.embed_dim, b, EPI_BIAS), s);
+    // the class-row chain of the last block is fp32; with the bf16 stream only the class rows are widened (exactly), inside the block
+    return vit_tail(c, X, XN, QKV, ATT, H, CLS, out, b, s, mx_stream ? Xb : nullptr);
 }
 
 // ---- open_clip ModifiedResNet (RN50x4).  Activations are NHWC, so every 1x1 convolution is a plain GEMM over the pixel
@@ -1603,7 +1631,7 @@ extern "C" int fern_vit_encode_image(fern_ctx* c, const float* images, float* ou
 static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, float* out_seq, int B, hipStream_t s) {
     const ClipW& W = c->clip;
     const fern_clip_config& cf = W.cfg;
-    const int tw = cf.t_width, T = cf.context_length, E = cf.embed_dim;
+    const int tw = cf.t_width, T = cf.context_length;
     const long R = (long)B * T;
     float *X, *XN, *QKV, *ATT, *H;
     int* eot;
@@ -1644,18 +1672,7 @@ static int text_chunk(fern_ctx* c, const int64_t* tokens, float* out_global, flo
             FERN_TRY(clip_block(c, W.tblocks[l], X, XN, QKV, ATT, H, B, T, tw, cf.t_heads, 1, s));
     }
     if (Xb) HIP_TRY(launch_bf16_to_f32(Xb, X, R * tw, s));
-    HIP_TRY(launch_layernorm(X, nullptr, W.ln_final.g, W.ln_final.b, XN, R, tw, tw, tw, 1e-5f, s));
-    LinearW proj{W.tproj_t, nullptr, E, tw};
-    if (out_seq) {
-        FERN_TRY(run_gemm(c, gemm_desc(XN, tw, proj, out_seq, E, (int)R, EPI_BIAS), s));
-        if (out_global) HIP_TRY(launch_gather_rows(out_seq, E, out_global, E, B, E, 1, T, 0, eot, s));   // global == seq[EOT]
-    } else if (out_global) {
-        float* pooled;
-        FERN_TRY(ws_get(c, (size_t)B * tw, &pooled));
-        HIP_TRY(launch_gather_rows(XN, tw, pooled, tw, B, tw, 1, T, 0, eot, s));
-        FERN_TRY(run_gemm(c, gemm_desc(pooled, tw, proj, out_global, E, B, EPI_BIAS), s));
-    }
-    return FERN_OK;
+    return text_tail(c, X, XN, eot, out_global, out_seq, B, s);
 }
 
 // Both towers of a composed query in one pass (round 6), fp32 data flow only (FERN_PREC_FP32, also under f32x3): the
@@ -1668,7 +1685,7 @@ static int pair_chunk(fern_ctx* c, const float* images, float* out_img, const in
     const ClipW& W = c->clip;
     const fern_clip_config& cf = W.cfg;
     const int vw = cf.v_width, g = cf.image_size / cf.patch_size, g2 = g * g, S = g2 + 1;
-    const int tw = cf.t_width, T = cf.context_length, E = cf.embed_dim;
+    const int tw = cf.t_width, T = cf.context_length;
     const long R = (long)b * S, Rt = (long)b * T;
     float *X, *XN, *QKV, *ATT, *H, *CLS, *Xt, *XNt, *QKVt, *ATTt, *Ht;
     int* eot;
@@ -1719,24 +1736,8 @@ static int pair_chunk(fern_ctx* c, const float* images, float* out_img, const in
     }
     for (int l = paired; l < vfull; ++l) FERN_TRY(clip_block(c, W.vblocks[l], X, XN, QKV, ATT, H, b, S, vw, cf.v_heads, 0, s));
     for (int l = paired; l < cf.t_layers; ++l) FERN_TRY(clip_block(c, W.tblocks[l], Xt, XNt, QKVt, ATTt, Ht, b, T, tw, cf.t_heads, 1, s));
-    // image tower tail -- as vit_chunk
-    FERN_TRY(clip_block_cls_only(c, W.vblocks[cf.v_layers - 1], X, XN, QKV, CLS, ATT, ATT + (size_t)b * vw, H, b, S, vw, cf.v_heads, s, nullptr));
-    HIP_TRY(launch_layernorm(CLS, nullptr, W.ln_post.g, W.ln_post.b, CLS, b, vw, vw, vw, 1e-5f, s));
-    LinearW vproj{W.vproj_t, nullptr, E, vw};
-    FERN_TRY(run_gemm(c, gemm_desc(CLS, vw, vproj, out_img, E, b, EPI_BIAS), s));
-    // text tower tail -- as text_chunk
-    HIP_TRY(launch_layernorm(Xt, nullptr, W.ln_final.g, W.ln_final.b, XNt, Rt, tw, tw, tw, 1e-5f, s));
-    LinearW tproj{W.tproj_t, nullptr, E, tw};
-    if (out_seq) {
-        FERN_TRY(run_gemm(c, gemm_desc(XNt, tw, tproj, out_seq, E, (int)Rt, EPI_BIAS), s));
-        if (out_global) HIP_TRY(launch_gather_rows(out_seq, E, out_global, E, b, E, 1, T, 0, eot, s));
-    } else if (out_global) {
-        float* pooled;
-        FERN_TRY(ws_get(c, (size_t)b * tw, &pooled));
-        HIP_TRY(launch_gather_rows(XNt, tw, pooled, tw, b, tw, 1, T, 0, eot, s));
-        FERN_TRY(run_gemm(c, gemm_desc(pooled, tw, tproj, out_global, E, b, EPI_BIAS), s));
-    }
-    return FERN_OK;
+    FERN_TRY(vit_tail(c, X, XN, QKV, ATT, H, CLS, out_img, b, s));
+    return text_tail(c, Xt, XNt, eot, out_global, out_seq, b, s);
 }
 
 // The same walk for FERN_PREC_MX8_IMG (the c5 default): the image tower's block-scaled GEMM of a layer and the text tower's bf16 GEMM of the
@@ -1746,7 +1747,7 @@ static int pair_chunk_mximg(fern_ctx* c, const float* images, float* out_img, co
     const ClipW& W = c->clip;
     const fern_clip_config& cf = W.cfg;
     const int vw = cf.v_width, g = cf.image_size / cf.patch_size, g2 = g * g, S = g2 + 1;
-    const int tw = cf.t_width, T = cf.context_length, E = cf.embed_dim;
+    const int tw = cf.t_width, T = cf.context_length;
     const long R = (long)b * S, Rt = (long)b * T;
     float *X, *XN, *QKV, *ATT, *H, *CLS, *Xt, *XNt, *QKVt, *ATTt, *Ht;
     int* eot;
@@ -1808,24 +1809,8 @@ static int pair_chunk_mximg(fern_ctx* c, const float* images, float* out_img, co
     for (int l = paired; l < vfull; ++l)
         FERN_TRY(clip_block_mxmlp(c, W.vblocks[l], X, XN, QKVb, ATTb, H8, b, S, vw, cf.v_heads, 0, s, true));
     for (int l = paired; l < cf.t_layers; ++l) FERN_TRY(clip_block_bf16(c, W.tblocks[l], Xt, XNtb, QKVtb, ATTtb, Htb, b, T, tw, cf.t_heads, 1, s));
-    // image tower tail -- as vit_chunk
-    FERN_TRY(clip_block_cls_only(c, W.vblocks[cf.v_layers - 1], X, XN, QKV, CLS, ATT, ATT + (size_t)b * vw, H, b, S, vw, cf.v_heads, s, nullptr));
-    HIP_TRY(launch_layernorm(CLS, nullptr, W.ln_post.g, W.ln_post.b, CLS, b, vw, vw, vw, 1e-5f, s));
-    LinearW vproj{W.vproj_t, nullptr, E, vw};
-    FERN_TRY(run_gemm(c, gemm_desc(CLS, vw, vproj, out_img, E, b, EPI_BIAS), s));
-    // text tower tail -- as text_chunk
-    HIP_TRY(launch_layernorm(Xt, nullptr, W.ln_final.g, W.ln_final.b, XNt, Rt, tw, tw, tw, 1e-5f, s));
-    LinearW tproj{W.tproj_t, nullptr, E, tw};
-    if (out_seq) {
-        FERN_TRY(run_gemm(c, gemm_desc(XNt, tw, tproj, out_seq, E, (int)Rt, EPI_BIAS), s));
-        if (out_global) HIP_TRY(launch_gather_rows(out_seq, E, out_global, E, b, E, 1, T, 0, eot, s));
-    } else if (out_global) {
-        float* pooled;
-        FERN_TRY(ws_get(c, (size_t)b * tw, &pooled));
-        HIP_TRY(launch_gather_rows(XNt, tw, pooled, tw, b, tw, 1, T, 0, eot, s));
-        FERN_TRY(run_gemm(c, gemm_desc(pooled, tw, tproj, out_global, E, b, EPI_BIAS), s));
-    }
-    return FERN_OK;
+    FERN_TRY(vit_tail(c, X, XN, QKV, ATT, H, CLS, out_img, b, s));
+    return text_tail(c, Xt, XNt, eot, out_global, out_seq, b, s);
 }
 
 // A token id outside the vocabulary cannot raise from inside a kernel (nn.Embedding does, in the reference): the embedding
