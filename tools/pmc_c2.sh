@@ -1,3 +1,5 @@
+#!/bin/bash
+# PMC traffic passes of the c2 step alone (superseded by tools/final_check.sh, which also pins the tuner choices of both passes)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh
