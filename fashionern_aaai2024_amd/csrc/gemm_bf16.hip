@@ -607,6 +607,13 @@ static int heuristic_b(int M, int N) {
     return 5;
 }
 
+// With several batches in flight (fern_tuner_set_concurrency) a launch that leaves workgroup slots free is cheaper than its isolated time:
+// the other lanes' kernels run in them.  The tuners score a candidate as time x share^e, share = the fraction of the chip's slots it fills.
+static double share_exponent() {
+    static const double expo = [] { const char* e = getenv("FERN_TUNE_SHARE_EXP"); return e ? atof(e) : 0.75; }();      // A/B knob (tools/c5_exp_ab.sh: 0 = latency score 17.9-18.3 k queries/s on c5, 0.5 ... 1.5 all 19.2-19.5 k)
+    return expo;
+}
+
 // `tuned` = false: nothing was timed (tuning off, stream capture, no scratch): the caller must not cache the fallback
 static int tune_shape_b(const GemmParams& p, hipStream_t s, bool& tuned) {
     LaunchTimerPause pause;
@@ -652,8 +659,7 @@ static int tune_shape_b(const GemmParams& p, hipStream_t s, bool& tuned) {
         if (g_tune_concurrency > 1) {      // caller holds g_tuned_b_mu
             const double nwg = (double)((p.M + cfgs[c].bm - 1) / cfgs[c].bm) * ((p.N + cfgs[c].bn - 1) / cfgs[c].bn);
             const double share = std::min(1.0, nwg / (256.0 * cfgs[c].per_cu));
-            static const double expo = [] { const char* e = getenv("FERN_TUNE_SHARE_EXP"); return e ? atof(e) : 0.75; }();      // A/B knob (tools/c5_exp_ab.sh: 0 = latency score 17.9-18.3 k queries/s on c5, 0.5 ... 1.5 all 19.2-19.5 k)
-            score *= (float)std::pow(share, expo);
+            score *= (float)std::pow(share, share_exponent());
         }
         if (score < best_ms) { best_ms = score; best = c; }
     }
@@ -688,11 +694,10 @@ static bool rp_args_ok(const GemmParams& p) {
     return true;
 }
 
-hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
-    if (p.M <= 0 || p.N <= 0) return hipSuccess;
-    load_pinned_tiles_b();
-    if (!rp_args_ok(p)) return hipErrorInvalidValue;
+// the tile configuration launch_gemm_bf16 runs p with (forced / tuned per shape / heuristic); fam: 2 block-scaled, 1 per-row fp8, 0 bf16
+static int resolve_cfg_b(const GemmParams& p, hipStream_t s, int* fam) {
     if (p.fp8 == 2) {
+        *fam = 2;
         int c = forced_value_b(g_force_mx, "FERN_GEMM_MX8_CFG");
         if (c < 0 || c >= kNumCfgsMx) {
             c = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) >= 256 ? 0 : 6;
@@ -701,9 +706,10 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
                 c = tuned_cfg_b(key, p, s);
             }
         }
-        return launch_cfg_mx(c, p, s);
+        return c;
     }
     if (p.fp8) {
+        *fam = 1;
         int c = forced_value_b(g_force_f8, "FERN_GEMM_FP8_CFG");
         if (c < 0 || c >= kNumCfgsF8) {
             c = 0;
@@ -712,8 +718,9 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
                 c = tuned_cfg_b(key, p, s);
             }
         }
-        return launch_cfg_f8(c, p, s);
+        return c;
     }
+    *fam = 0;
     int c = forced_cfg_b();
     if (c < 0 || c >= kNumCfgsB || p.K % kCfgsB[c].bk) {
         const double flops = 2.0 * p.M * (double)p.N * p.K;
@@ -724,7 +731,16 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
             c = heuristic_b(p.M, p.N);
         }
     }
-    return launch_cfg_b(c, p, s);
+    return c;
+}
+
+hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    load_pinned_tiles_b();
+    if (!rp_args_ok(p)) return hipErrorInvalidValue;
+    int fam = 0;
+    const int c = resolve_cfg_b(p, s, &fam);
+    return fam == 2 ? launch_cfg_mx(c, p, s) : fam == 1 ? launch_cfg_f8(c, p, s) : launch_cfg_b(c, p, s);
 }
 
 // ---- image + text GEMM pair of the mixed mode, ONE launch (round 6) -------------------------------------------------------------------
@@ -810,10 +826,24 @@ static int tune_pair_b(const GemmParams& p1, const GemmParams& p2, hipStream_t s
     (void)hipFree(c2);
     if (t[0] > 1e29f) return 0;
     timed = true;
-    int best = 0;
-    for (int i = 1; i < 3; ++i)
-        if (t[i] < t[best]) best = i;
-    return best;
+    // Which pair form: with several batches in flight the tile tuner's score (tune_shape_b: time x (fraction of the chip's workgroup slots the
+    // launch fills)^e) -- the 8-wave form is a few per cent faster alone on the N = 768 shapes and 1-3 % slower than the 16-wave form with four
+    // lanes (tools/pairb_forms_ab.sh).  Pair or two launches: plain times -- the score overrates what the other lanes make of the short text
+    // launches' free slots (it chose two launches for three of the four pairs; measured 2-4 % below the pairs).
+    int conc;
+    {
+        std::lock_guard<std::mutex> lock(g_tuned_b_mu);
+        conc = g_tune_concurrency;
+    }
+    float sc[2] = {t[1], t[2]};
+    if (conc > 1)
+        for (int v = 0; v < 2; ++v) {
+            const int bn = v == 0 ? 256 : 128;
+            const double nwg = (double)((p1.M + 255) / 256) * ((p1.N + bn - 1) / bn) + (double)((p2.M + 255) / 256) * ((p2.N + bn - 1) / bn);
+            sc[v] *= (float)std::pow(std::min(1.0, nwg / (256.0 * (v == 0 ? 1 : 2))), share_exponent());
+        }
+    const int form = sc[1] < sc[0] ? 2 : 1;
+    return t[form] < t[0] ? form : 0;
 }
 static bool pair_b_enabled() {
     static const bool on = [] { const char* e = getenv("FERN_GEMM_PAIR"); return !(e && e[0] == '0'); }();
