@@ -1235,9 +1235,8 @@ def main():
         children = None
 
         def start_children():
-            """The other BASELINE configs as child runs of this script, one after the other on a background thread.  Started when THIS process
-            has made its last GPU call: beside the CPU-baseline leg when there is one (the GPU is idle while the host times the oracle on 32 of
-            its cores; the children are GPU-bound with one busy host thread each) -- 62 -> ~45 s for the driver's command."""
+            """The other BASELINE configs as child runs of this script, one after the other on a background thread, started when THIS process
+            has made its last GPU call: after the CPU-baseline leg, or beside it under FERN_BENCH_OVERLAP_CHILDREN=1 (see there)."""
             if not (world == 1 and args.config == "c2" and not args.headline_only and not args.no_other_configs and not args.pmc_mode):
                 return None
             import threading
@@ -1270,7 +1269,11 @@ def main():
                 torch.cuda.synchronize()
                 pipe.set_precision("fp32")
             gal_cpu = gallery[:n_cpu].cpu()
-            children = start_children()      # this process is done with the GPU: the c3 / c4 / c5 child runs use it while the host times the oracle
+            # FERN_BENCH_OVERLAP_CHILDREN=1: start the c3 / c4 / c5 child runs here, beside the CPU-oracle leg (this process is done with the GPU):
+            # 59 -> 47 s for the default command.  Off by default: on one box, alternating, the overlapped c4 child read 2 928 / 3 117 queries/s
+            # against 3 111 / 3 111 after the leg, and the CPU figure itself 16.3 / 19.1 against 22.7 / 19.9 -- the legs disturb each other.
+            if os.environ.get("FERN_BENCH_OVERLAP_CHILDREN"):
+                children = start_children()
             result["cpu_baseline"] = cpu_baseline(clip_sd, fusion_sd, cfg, w, im, tk, lc, gal_cpu, args.cpu_sample, gpu_topk, extra_topk=extra_topk,
                                                   all_cores_leg=args.cpu_all_cores)
             if children is not None:
