@@ -826,22 +826,19 @@ static int tune_pair_b(const GemmParams& p1, const GemmParams& p2, hipStream_t s
     (void)hipFree(c2);
     if (t[0] > 1e29f) return 0;
     timed = true;
-    // Which pair form: with several batches in flight the tile tuner's score (tune_shape_b: time x (fraction of the chip's workgroup slots the
-    // launch fills)^e) -- the 8-wave form is a few per cent faster alone on the N = 768 shapes and 1-3 % slower than the 16-wave form with four
-    // lanes (tools/pairb_forms_ab.sh).  Pair or two launches: plain times -- the score overrates what the other lanes make of the short text
-    // launches' free slots (it chose two launches for three of the four pairs; measured 2-4 % below the pairs).
+    // Which pair form: alone the two are within a few per cent of each other on the ViT shapes (the choice flipped from run to run); with four
+    // batches in flight the 8-wave form costs 1 % (out-proj) to 3 % (c_proj) of the c5 step (tools/pairb_forms_ab.sh: all pairs 16-wave
+    // 19.58-19.74 k queries/s, out-proj + c_proj 8-wave 18.86-19.17 k) -- its two workgroups hold 156 of a CU's 160 KiB of LDS, the 16-wave
+    // form leaves 28 KiB and 16 wave slots to the other lanes' kernels.  The tile tuner's share score does not see that (both forms fill the
+    // same fraction of their slots), so under concurrency the 8-wave form must win alone by 10 %.  Pair or two launches: plain times -- the
+    // share score overrates what the other lanes make of a short text launch's free slots (it chose two launches for three of the four
+    // pairs; measured 2-4 % below the pairs).
     int conc;
     {
         std::lock_guard<std::mutex> lock(g_tuned_b_mu);
         conc = g_tune_concurrency;
     }
-    float sc[2] = {t[1], t[2]};
-    if (conc > 1)
-        for (int v = 0; v < 2; ++v) {
-            const int bn = v == 0 ? 256 : 128;
-            const double nwg = (double)((p1.M + 255) / 256) * ((p1.N + bn - 1) / bn) + (double)((p2.M + 255) / 256) * ((p2.N + bn - 1) / bn);
-            sc[v] *= (float)std::pow(std::min(1.0, nwg / (256.0 * (v == 0 ? 1 : 2))), share_exponent());
-        }
+    const float sc[2] = {t[1], conc > 1 ? t[2] * 1.10f : t[2]};
     const int form = sc[1] < sc[0] ? 2 : 1;
     return t[form] < t[0] ? form : 0;
 }
