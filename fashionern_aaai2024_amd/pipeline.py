@@ -180,7 +180,7 @@ class ComposedQueryPipeline:
     def _step(eng, args, gallery, k, idx_offset):
         images, tokens, local, exclude_idx, members, ref_feats = args
         if ref_feats is None and images.shape[0] == tokens.shape[0]:
-            ref, tg, ts = eng.encode_pair(images, tokens)      # both towers in one pass: the text layers' GEMMs ride in the image layers' launches (fp32 / f32x3)
+            ref, tg, ts = eng.encode_pair(images, tokens)      # both towers in one pass: the text layers' GEMMs ride in the image layers' launches (fp32 / f32x3 / mx8img)
         else:
             ref = eng.encode_image(images) if ref_feats is None else ref_feats
             tg, ts = eng.encode_text(tokens)
